@@ -1,0 +1,184 @@
+// hv_api.cpp -- the C ABI (include/humanvid_hip.h) over the gfx950 kernels.
+// Built by __graft_entry__.build():  hipcc --offload-arch=gfx950 -O3 -shared -fPIC ...
+#include "humanvid_hip.h"
+
+#include <stdio.h>
+#include <string.h>
+
+#include "hv_common.h"
+#include "hv_kernels.h"
+
+static thread_local char g_err[512] = "";
+
+static int hv_fail(int code, const char* what) {
+    snprintf(g_err, sizeof(g_err), "%s", what);
+    return code;
+}
+
+static int hv_check_launch(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        snprintf(g_err, sizeof(g_err), "%s: %s", what, hipGetErrorString(e));
+        return HV_EHIP;
+    }
+    return HV_OK;
+}
+
+extern "C" {
+
+const char* hv_last_error(void) { return g_err; }
+int hv_abi_version(void) { return 1; }
+
+int hv_struct_sizes(int* out, int capacity) {
+    const int s[] = {(int)sizeof(hv_gemm_params),      (int)sizeof(hv_conv3x3_params),
+                     (int)sizeof(hv_groupnorm_params), (int)sizeof(hv_attention_params),
+                     (int)sizeof(hv_temporal_attention_params)};
+    const int n = (int)(sizeof(s) / sizeof(s[0]));
+    for (int i = 0; i < n && i < capacity; ++i) out[i] = s[i];
+    return n;
+}
+
+int hv_gemm(const hv_gemm_params* p, void* stream) {
+    if (!p || !p->X || !p->W || !p->Y) return hv_fail(HV_EINVAL, "hv_gemm: null operand");
+    if (hvk_gemm(*p, (hipStream_t)stream) != 0)
+        return hv_fail(HV_EINVAL, "hv_gemm: need K % 64 == 0, N % 4 == 0 (geglu: N % 32 == 0)");
+    return hv_check_launch("hv_gemm");
+}
+
+int hv_conv3x3(const hv_conv3x3_params* p, void* stream) {
+    if (!p || !p->X || !p->W || !p->Y) return hv_fail(HV_EINVAL, "hv_conv3x3: null operand");
+    if (hvk_conv3x3(*p, (hipStream_t)stream) != 0)
+        return hv_fail(HV_EINVAL, "hv_conv3x3: need C1 % 32 == 0, C2 % 32 == 0, Cout % 4 == 0, consistent sizes");
+    return hv_check_launch("hv_conv3x3");
+}
+
+int hv_groupnorm_affine(const hv_groupnorm_params* p, void* stream) {
+    if (!p || !p->X || !p->partial || !p->scale || !p->shift) return hv_fail(HV_EINVAL, "hv_groupnorm: null");
+    if (hvk_groupnorm(*p, (hipStream_t)stream) != 0)
+        return hv_fail(HV_EINVAL, "hv_groupnorm: need C1 % 8 == 0, C2 % 8 == 0, C % groups == 0, C <= 4096");
+    return hv_check_launch("hv_groupnorm_affine");
+}
+
+int hv_layernorm_stats(const uint16_t* X, long ldx, int M, int C, float eps, float* mean, float* rstd,
+                       void* stream) {
+    if (!X || !mean || !rstd || M <= 0) return hv_fail(HV_EINVAL, "hv_layernorm_stats: null");
+    if (C % 8 != 0 || C > 2048) return hv_fail(HV_EINVAL, "hv_layernorm_stats: C % 8, C <= 2048");
+    hvk_layernorm(X, ldx, M, C, eps, mean, rstd, (hipStream_t)stream);
+    return hv_check_launch("hv_layernorm_stats");
+}
+
+int hv_attention(const hv_attention_params* p, void* stream) {
+    if (!p || !p->Q || !p->K || !p->Vt || !p->O) return hv_fail(HV_EINVAL, "hv_attention: null operand");
+    int rc = hvk_attention(*p, (hipStream_t)stream);
+    if (rc == -2) return hv_fail(HV_ENOTSUP, "hv_attention: head dim must be 40, 80 or 160");
+    if (rc != 0) return hv_fail(HV_EINVAL, "hv_attention: need L1 % 8 == 0, L2 % 8 == 0, 16-byte aligned strides");
+    return hv_check_launch("hv_attention");
+}
+
+int hv_temporal_attention(const hv_temporal_attention_params* p, void* stream) {
+    if (!p || !p->QKV || !p->O) return hv_fail(HV_EINVAL, "hv_temporal_attention: null operand");
+    int rc = hvk_temporal(*p, (hipStream_t)stream);
+    if (rc == -2) return hv_fail(HV_ENOTSUP, "hv_temporal_attention: head dim must be 40, 80 or 160, F <= 32");
+    if (rc != 0) return hv_fail(HV_EINVAL, "hv_temporal_attention: bad sizes");
+    return hv_check_launch("hv_temporal_attention");
+}
+
+int hv_pack_ncfhw(const void* src, int src_is_bf16, int B, int C, int F, int H, int W, int rep, uint16_t* dst,
+                  int Cpad, void* stream) {
+    if (!src || !dst || Cpad < C || Cpad % 8 != 0) return hv_fail(HV_EINVAL, "hv_pack_ncfhw: bad args");
+    hvk_pack(src, src_is_bf16, B, C, F, H, W, rep, dst, Cpad, (hipStream_t)stream);
+    return hv_check_launch("hv_pack_ncfhw");
+}
+
+int hv_unpack_nhwc(const uint16_t* src, int ldc, int B, int C, int F, int H, int W, void* dst, int dst_is_bf16,
+                   void* stream) {
+    if (!src || !dst) return hv_fail(HV_EINVAL, "hv_unpack_nhwc: null");
+    hvk_unpack(src, ldc, B, C, F, H, W, dst, dst_is_bf16, (hipStream_t)stream);
+    return hv_check_launch("hv_unpack_nhwc");
+}
+
+int hv_pixel_unshuffle(const float* src, int B, int C, int F, int H, int W, int r, uint16_t* dst, void* stream) {
+    if (!src || !dst || H % r || W % r) return hv_fail(HV_EINVAL, "hv_pixel_unshuffle: bad args");
+    hvk_unshuffle(src, B, C, F, H, W, r, dst, (hipStream_t)stream);
+    return hv_check_launch("hv_pixel_unshuffle");
+}
+
+int hv_timestep_embedding(const float* t, int B, int dim, uint16_t* dst, void* stream) {
+    if (!t || !dst || dim % 2) return hv_fail(HV_EINVAL, "hv_timestep_embedding: bad args");
+    hvk_timestep(t, B, dim, dst, (hipStream_t)stream);
+    return hv_check_launch("hv_timestep_embedding");
+}
+
+int hv_accumulate_window(const uint16_t* pred, int ldc, int rep, int C, int f_win, int H, int W, const int* frames,
+                         int F, float* acc, float* counter, void* stream) {
+    if (!pred || !frames || !acc || !counter) return hv_fail(HV_EINVAL, "hv_accumulate_window: null");
+    hvk_accumulate(pred, ldc, rep, C, f_win, H, W, frames, F, acc, counter, (hipStream_t)stream);
+    return hv_check_launch("hv_accumulate_window");
+}
+
+int hv_cfg_ddim_step(float* latents, float* acc, float* counter, int rep, int C, int F, int H, int W,
+                     float guidance, float sqrt_a, float sqrt_1ma, float sqrt_ap, float sqrt_1map, void* stream) {
+    if (!latents || !acc || !counter || (rep != 1 && rep != 2)) return hv_fail(HV_EINVAL, "hv_cfg_ddim_step: bad args");
+    hvk_cfg_ddim(latents, acc, counter, rep, C, F, H, W, guidance, sqrt_a, sqrt_1ma, sqrt_ap, sqrt_1map,
+                       (hipStream_t)stream);
+    return hv_check_launch("hv_cfg_ddim_step");
+}
+
+#ifndef HV_EMU
+int hv_graph_begin(void* stream) {
+    hipError_t e = hipStreamBeginCapture((hipStream_t)stream, hipStreamCaptureModeRelaxed);
+    if (e != hipSuccess) return hv_fail(HV_EHIP, hipGetErrorString(e));
+    return HV_OK;
+}
+int hv_graph_end(void* stream, void** graph_exec_out) {
+    hipGraph_t g = nullptr;
+    hipError_t e = hipStreamEndCapture((hipStream_t)stream, &g);
+    if (e != hipSuccess) return hv_fail(HV_EHIP, hipGetErrorString(e));
+    hipGraphExec_t ex = nullptr;
+    e = hipGraphInstantiate(&ex, g, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(g);
+    if (e != hipSuccess) return hv_fail(HV_EHIP, hipGetErrorString(e));
+    *graph_exec_out = (void*)ex;
+    return HV_OK;
+}
+int hv_graph_launch(void* graph_exec, void* stream) {
+    hipError_t e = hipGraphLaunch((hipGraphExec_t)graph_exec, (hipStream_t)stream);
+    if (e != hipSuccess) return hv_fail(HV_EHIP, hipGetErrorString(e));
+    return HV_OK;
+}
+int hv_graph_destroy(void* graph_exec) {
+    (void)hipGraphExecDestroy((hipGraphExec_t)graph_exec);
+    return HV_OK;
+}
+int hv_event_create(void** ev) {
+    hipEvent_t e;
+    if (hipEventCreate(&e) != hipSuccess) return hv_fail(HV_EHIP, "hipEventCreate");
+    *ev = (void*)e;
+    return HV_OK;
+}
+int hv_event_record(void* ev, void* stream) {
+    if (hipEventRecord((hipEvent_t)ev, (hipStream_t)stream) != hipSuccess) return hv_fail(HV_EHIP, "hipEventRecord");
+    return HV_OK;
+}
+int hv_event_elapsed_ms(void* start, void* stop, float* ms) {
+    if (hipEventSynchronize((hipEvent_t)stop) != hipSuccess) return hv_fail(HV_EHIP, "hipEventSynchronize");
+    if (hipEventElapsedTime(ms, (hipEvent_t)start, (hipEvent_t)stop) != hipSuccess)
+        return hv_fail(HV_EHIP, "hipEventElapsedTime");
+    return HV_OK;
+}
+int hv_event_destroy(void* ev) {
+    (void)hipEventDestroy((hipEvent_t)ev);
+    return HV_OK;
+}
+#else
+int hv_graph_begin(void*) { return hv_fail(HV_ENOTSUP, "emulator build"); }
+int hv_graph_end(void*, void**) { return hv_fail(HV_ENOTSUP, "emulator build"); }
+int hv_graph_launch(void*, void*) { return hv_fail(HV_ENOTSUP, "emulator build"); }
+int hv_graph_destroy(void*) { return HV_OK; }
+int hv_event_create(void**) { return hv_fail(HV_ENOTSUP, "emulator build"); }
+int hv_event_record(void*, void*) { return hv_fail(HV_ENOTSUP, "emulator build"); }
+int hv_event_elapsed_ms(void*, void*, float*) { return hv_fail(HV_ENOTSUP, "emulator build"); }
+int hv_event_destroy(void*) { return HV_OK; }
+#endif
+
+}  // extern "C"

@@ -1,0 +1,281 @@
+// hv_attention.h -- flash-style spatial self-attention with reference-bank keys on MFMA (gfx950).
+//
+// Reference semantics: diffusers Attention + AttnProcessor2_0 (F.scaled_dot_product_attention,
+// scale d^-0.5, no mask) as called by the read-mode patched transformer block,
+// /root/reference/src/models/mutual_self_attention.py:147-186: for the conditional images keys and
+// values are [own tokens || bank tokens]; for the CFG-unconditional images the result is
+// overwritten by plain self-attention, i.e. they attend to their own tokens only.  This kernel
+// computes exactly that "overwritten" result, selecting the bank per image.
+//
+// Design (MI355X, head dims 40 / 80 / 160 = SD-1.5 widths 320/640/1280 over 8 heads):
+//  * S^T = K.Q^T with mfma_f32_16x16x32_bf16 (A = key rows, B = query rows): a lane then holds
+//    scores of ONE query (column lane&15) for 4 keys per fragment, so the softmax row reduction is
+//    16 in-register values + two cross-quad shuffles, and the running max / sum / rescale factor of
+//    a query live in the same lane as its O^T accumulator column (no broadcast needed).
+//  * key rows are staged into LDS in a permuted order (bits 2 and 3-4 rotated) so that the
+//    probabilities of two adjacent score fragments concatenate, in-register, into the B operand of
+//    O^T += V^T.P^T with natural key order -- no cross-lane traffic between the two matmuls.
+//  * V arrives already transposed ([channel][token], written by the QKV GEMM epilogue), so both
+//    K and V^T fragments are single 16-byte LDS reads; LDS rows are padded to an odd number of
+//    16-byte slots.
+//  * head dim is zero-padded in LDS/registers only (40->64 for the QK^T reduction, 40->48 rows of
+//    V^T); HBM traffic is unpadded.
+//  * K/V tiles (64 keys) are double-buffered through registers, one barrier per tile; online
+//    softmax in the exp2 domain; fp32 accumulation throughout.
+#pragma once
+#include "hv_common.h"
+#include "humanvid_hip.h"
+
+template <int D, int QT>
+struct HvAttnGeom {
+    static constexpr int DS = (D + 31) / 32;   // 32-wide reduction steps of QK^T
+    static constexpr int DT = (D + 15) / 16;   // 16-row fragments of V^T / O^T
+    static constexpr int DK = 32 * DS;
+    static constexpr int DV = 16 * DT;
+    static constexpr int KRS = DK * 2 + 16;    // K row stride in LDS (bytes), odd multiple of 16
+    static constexpr int VRS = 64 * 2 + 16;    // V^T row stride (64 keys)
+    static constexpr int KBYTES = 64 * KRS;
+    static constexpr int VBYTES = DV * VRS;
+    static constexpr int KCH = 64 * (D / 8);   // 16-byte chunks of a K tile
+    static constexpr int VCH = D * 8;          // 16-byte chunks of a V^T tile
+    static constexpr int KIT = (KCH + 255) / 256;
+    static constexpr int VIT = (VCH + 255) / 256;
+    static constexpr int BQ = 4 * 16 * QT;     // queries per workgroup
+};
+
+template <int D, int QT>
+__global__ __launch_bounds__(256) void hv_attention_kernel(hv_attention_params p) {
+    using G = HvAttnGeom<D, QT>;
+    constexpr int DS = G::DS, DT = G::DT;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * (G::KBYTES + G::VBYTES)];
+    unsigned char* Ks = smem;
+    unsigned char* Vs = smem + 2 * G::KBYTES;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r16 = lane & 15, quad = lane >> 4;
+
+    const int nqb = (p.Lq + G::BQ - 1) / G::BQ;
+    const int total = nqb * p.heads * p.n_images;
+    const int cpx = gridDim.x / 8;
+    int t = (blockIdx.x % 8) * cpx + blockIdx.x / 8;
+    if (t >= total) return;
+    const int qb = t % nqb;
+    t /= nqb;
+    const int head = t % p.heads;
+    const int img = t / p.heads;
+    const int sel = (p.bank_sel != nullptr && p.L2 > 0) ? p.bank_sel[img] : -1;
+    const int T1 = (p.L1 + 63) / 64;
+    const int T2 = sel >= 0 ? (p.L2 + 63) / 64 : 0;
+    const int ntiles = T1 + T2;
+
+    // zero the padding of both LDS buffers once (never overwritten by the tile stores)
+    for (int i = tid; i < 2 * (G::KBYTES + G::VBYTES) / 16; i += 256) {
+        u32x4 z = {0u, 0u, 0u, 0u};
+        hv_st16(smem + i * 16, z);
+    }
+
+    // ---- query fragments (B operand of S^T = K.Q^T), resident for the whole kernel
+    bf16x8 qf[QT][DS];
+    const int q_wave = qb * G::BQ + wave * 16 * QT;
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) {
+        const int q = q_wave + 16 * qt + r16;
+#pragma unroll
+        for (int s = 0; s < DS; ++s) {
+            const int d = 32 * s + 8 * quad;
+            u32x4 v = {0u, 0u, 0u, 0u};
+            if (q < p.Lq && d + 8 <= D) v = hv_ld16(p.Q + ((long)img * p.Lq + q) * p.ldq + head * D + d);
+            qf[qt][s] = hv_as_bf16x8(v);
+        }
+    }
+
+    u32x4 kreg[G::KIT], vreg[G::VIT];
+    auto load_tile = [&](int ti) {
+        const bool bank = ti >= T1;
+        const int kv0 = (bank ? ti - T1 : ti) * 64;
+        const int L = bank ? p.L2 : p.L1;
+        const long rowbase = bank ? (long)sel * p.L2 : (long)img * p.L1;
+        const bf16_t* Kp = bank ? p.K2 : p.K;
+        const long ldk = bank ? p.ldk2 : p.ldk;
+        const bf16_t* Vp = bank ? p.Vt2 : p.Vt;
+        const long ldv = bank ? p.ldvt2 : p.ldvt;
+#pragma unroll
+        for (int i = 0; i < G::KIT; ++i) {
+            const int id = tid + 256 * i;
+            u32x4 v = {0u, 0u, 0u, 0u};
+            if (id < G::KCH) {
+                const int r = id / (D / 8), c = id % (D / 8);
+                if (kv0 + r < L) v = hv_ld16(Kp + (rowbase + kv0 + r) * ldk + head * D + c * 8);
+            }
+            kreg[i] = v;
+        }
+#pragma unroll
+        for (int i = 0; i < G::VIT; ++i) {
+            const int id = tid + 256 * i;
+            u32x4 v = {0u, 0u, 0u, 0u};
+            if (id < G::VCH) {
+                const int d = id >> 3, c = id & 7;
+                if (kv0 + c * 8 < L) v = hv_ld16(Vp + (long)(head * D + d) * ldv + rowbase + kv0 + c * 8);
+            }
+            vreg[i] = v;
+        }
+    };
+    auto store_tile = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < G::KIT; ++i) {
+            const int id = tid + 256 * i;
+            if (id < G::KCH) {
+                const int r = id / (D / 8), c = id % (D / 8);
+                // key kv = 32a + 8b + 4c' + e  ->  LDS row 32a + 16c' + 4b + e
+                const int lr = (r & ~0x1c) | ((r & 4) << 2) | ((r & 0x18) >> 1);
+                hv_st16(Ks + buf * G::KBYTES + lr * G::KRS + c * 16, kreg[i]);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < G::VIT; ++i) {
+            const int id = tid + 256 * i;
+            if (id < G::VCH) hv_st16(Vs + buf * G::VBYTES + (id >> 3) * G::VRS + (id & 7) * 16, vreg[i]);
+        }
+    };
+
+    f32x4 oacc[QT][DT];
+    float mrun[QT], lrun[QT];
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) {
+        mrun[qt] = -INFINITY;
+        lrun[qt] = 0.f;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) oacc[qt][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    const float c2 = p.scale * 1.44269504089f;
+
+    load_tile(0);
+    __syncthreads();  // padding zero-fill complete before the first tile store
+    for (int ti = 0; ti < ntiles; ++ti) {
+        const int buf = ti & 1;
+        store_tile(buf);
+        __syncthreads();
+        if (ti + 1 < ntiles) load_tile(ti + 1);
+        const bool bank = ti >= T1;
+        const int kv0 = (bank ? ti - T1 : ti) * 64;
+        const int L = bank ? p.L2 : p.L1;
+        const unsigned char* kb = Ks + buf * G::KBYTES + r16 * G::KRS + quad * 16;
+        const unsigned char* vb = Vs + buf * G::VBYTES + r16 * G::VRS + quad * 16;
+
+        // ---- S^T fragments: sacc[kvf][qt], lane = (query r16, quad), reg r <-> key
+        //      kv = 32*(kvf>>1) + 8*quad + 4*(kvf&1) + r
+        f32x4 sacc[4][QT];
+#pragma unroll
+        for (int kvf = 0; kvf < 4; ++kvf) {
+#pragma unroll
+            for (int qt = 0; qt < QT; ++qt) sacc[kvf][qt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s = 0; s < DS; ++s) {
+                const bf16x8 kf = hv_as_bf16x8(hv_ld16(kb + (16 * kvf) * G::KRS + s * 64));
+#pragma unroll
+                for (int qt = 0; qt < QT; ++qt)
+                    sacc[kvf][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[qt][s], sacc[kvf][qt], 0, 0, 0);
+            }
+        }
+        // ---- mask the ragged tail of this source
+        if (kv0 + 64 > L) {
+#pragma unroll
+            for (int kvf = 0; kvf < 4; ++kvf)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int kv = kv0 + 32 * (kvf >> 1) + 8 * quad + 4 * (kvf & 1) + r;
+                    if (kv >= L) {
+#pragma unroll
+                        for (int qt = 0; qt < QT; ++qt) sacc[kvf][qt][r] = -INFINITY;
+                    }
+                }
+        }
+        // ---- online softmax (exp2 domain) and P^T fragments
+        bf16x8 pf[QT][2];
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt) {
+            float mx = -INFINITY;
+#pragma unroll
+            for (int kvf = 0; kvf < 4; ++kvf)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) mx = fmaxf(mx, sacc[kvf][qt][r]);
+            mx = fmaxf(mx, __shfl_xor(mx, 16));
+            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            const float mnew = fmaxf(mrun[qt], mx * c2);
+            const float alpha = __builtin_amdgcn_exp2f(mrun[qt] - mnew);
+            mrun[qt] = mnew;
+            float psum = 0.f;
+            float pv[4][4];
+#pragma unroll
+            for (int kvf = 0; kvf < 4; ++kvf)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float e = __builtin_amdgcn_exp2f(sacc[kvf][qt][r] * c2 - mnew);
+                    pv[kvf][r] = e;
+                    psum += e;
+                }
+            lrun[qt] = lrun[qt] * alpha + psum;
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) oacc[qt][dt] *= alpha;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                u32x4 w = {hv_pack2(pv[2 * ks][0], pv[2 * ks][1]), hv_pack2(pv[2 * ks][2], pv[2 * ks][3]),
+                           hv_pack2(pv[2 * ks + 1][0], pv[2 * ks + 1][1]),
+                           hv_pack2(pv[2 * ks + 1][2], pv[2 * ks + 1][3])};
+                pf[qt][ks] = hv_as_bf16x8(w);
+            }
+        }
+        // ---- O^T += V^T . P^T
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const bf16x8 vf = hv_as_bf16x8(hv_ld16(vb + (16 * dt) * G::VRS + ks * 64));
+#pragma unroll
+                for (int qt = 0; qt < QT; ++qt)
+                    oacc[qt][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[qt][ks], oacc[qt][dt], 0, 0, 0);
+            }
+    }
+
+    // ---- normalise and store: lane owns query r16, channels 16*dt + 4*quad + 0..3
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) {
+        float l = lrun[qt];
+        l += __shfl_xor(l, 16);
+        l += __shfl_xor(l, 32);
+        const float inv = 1.0f / l;
+        const int q = q_wave + 16 * qt + r16;
+        if (q >= p.Lq) continue;
+        bf16_t* dst = p.O + ((long)img * p.Lq + q) * p.ldo + head * D;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+            const int d = 16 * dt + 4 * quad;
+            if (d < D) {
+                u32x2 o = {hv_pack2(oacc[qt][dt][0] * inv, oacc[qt][dt][1] * inv),
+                           hv_pack2(oacc[qt][dt][2] * inv, oacc[qt][dt][3] * inv)};
+                hv_st8(dst + d, o);
+            }
+        }
+    }
+}
+
+template <int D, int QT>
+static inline void hv_attention_launch_t(const hv_attention_params& p, hipStream_t stream) {
+    using G = HvAttnGeom<D, QT>;
+    const int total = ((p.Lq + G::BQ - 1) / G::BQ) * p.heads * p.n_images;
+    const int grid = ((total + 7) / 8) * 8;
+    hv_launch(hv_attention_kernel<D, QT>, dim3(grid), dim3(256), stream, p);
+}
+
+static inline int hv_attention_launch(const hv_attention_params& p, hipStream_t stream) {
+    if (p.L1 <= 0 || p.L1 % 8 != 0 || p.L2 % 8 != 0 || p.Lq <= 0) return -1;
+    if (p.ldq % 8 || p.ldk % 8 || p.ldvt % 8 || p.ldo % 4) return -1;
+    if (p.L2 > 0 && p.bank_sel != nullptr && (!p.K2 || !p.Vt2 || p.ldk2 % 8 || p.ldvt2 % 8)) return -1;
+    switch (p.D) {
+        case 40: hv_attention_launch_t<40, 4>(p, stream); break;
+        case 80: hv_attention_launch_t<80, 2>(p, stream); break;
+        case 160: hv_attention_launch_t<160, 2>(p, stream); break;
+        default: return -2;
+    }
+    return 0;
+}

@@ -1,0 +1,98 @@
+// hv_common.h -- shared device helpers for the gfx950 (MI355X / CDNA4) kernels.
+//
+// Everything here is written for 64-lane wavefronts and the gfx950 MFMA shapes
+// (16x16x32 bf16: 8 bf16 per lane for A and B, 4 fp32 accumulators per lane).
+// Activations live in HBM as bf16, channels-last: [image][y][x][channel] == [image][token][channel];
+// all accumulation is fp32.
+#pragma once
+#ifndef HV_EMU
+#include <hip/hip_runtime.h>
+#endif
+#include <stdint.h>
+#include "humanvid_hip.h"  // HV_ACT_* and the parameter structs
+
+typedef unsigned short bf16_t;  // raw bfloat16 bits
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+typedef short bf16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+#define HV_DEV __device__ __forceinline__
+
+HV_DEV float hv_bf2f(bf16_t b) {
+    union {
+        uint32_t u;
+        float f;
+    } c;
+    c.u = ((uint32_t)b) << 16;
+    return c.f;
+}
+
+HV_DEV bf16_t hv_f2bf(float f) {  // round-to-nearest-even, NaN preserved
+    union {
+        uint32_t u;
+        float f;
+    } c;
+    c.f = f;
+    uint32_t u = c.u;
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)0x7fc0;
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (bf16_t)(u >> 16);
+}
+
+HV_DEV uint32_t hv_pack2(float lo, float hi) { return (uint32_t)hv_f2bf(lo) | ((uint32_t)hv_f2bf(hi) << 16); }
+
+HV_DEV float hv_silu(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504089f * x)); }
+
+HV_DEV float hv_gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+
+// 16-byte global / LDS vector access
+HV_DEV u32x4 hv_ld16(const void* p) { return *reinterpret_cast<const u32x4*>(p); }
+HV_DEV void hv_st16(void* p, u32x4 v) { *reinterpret_cast<u32x4*>(p) = v; }
+HV_DEV u32x2 hv_ld8(const void* p) { return *reinterpret_cast<const u32x2*>(p); }
+HV_DEV void hv_st8(void* p, u32x2 v) { *reinterpret_cast<u32x2*>(p) = v; }
+
+HV_DEV bf16x8 hv_as_bf16x8(u32x4 v) {
+    union {
+        u32x4 u;
+        bf16x8 s;
+    } c;
+    c.u = v;
+    return c.s;
+}
+
+HV_DEV void hv_unpack8(u32x4 v, float* f) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        f[2 * i] = hv_bf2f((bf16_t)(v[i] & 0xffffu));
+        f[2 * i + 1] = hv_bf2f((bf16_t)(v[i] >> 16));
+    }
+}
+
+HV_DEV u32x4 hv_pack8(const float* f) {
+    u32x4 v;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = hv_pack2(f[2 * i], f[2 * i + 1]);
+    return v;
+}
+
+
+HV_DEV float hv_act(float x, int act) {
+    if (act == HV_ACT_SILU) return hv_silu(x);
+    if (act == HV_ACT_RELU) return x > 0.f ? x : 0.f;
+    return x;
+}
+
+// ---- launch plumbing ----------------------------------------------------------------------
+// One launch helper for both builds: the real one uses the HIP triple-chevron launch on the
+// caller's stream, the emulator (tests only) runs the workgroups on host fibers.
+template <class... KArgs, class... Args>
+static inline void hv_launch(void (*kernel)(KArgs...), dim3 grid, dim3 block, hipStream_t stream, Args... args) {
+#ifdef HV_EMU
+    (void)stream;
+    hvemu::launch(grid, block, [&]() { kernel(args...); });
+#else
+    kernel<<<grid, block, 0, stream>>>(args...);
+#endif
+}

@@ -1,0 +1,181 @@
+// hv_elementwise.h -- layout adaptors at the drop-in boundary and the per-step scalar-rate tail
+// (window accumulation, classifier-free guidance, DDIM v-prediction update).  All HBM-bound,
+// grid-stride, one thread per output vector.
+#pragma once
+#include "hv_common.h"
+#include "humanvid_hip.h"
+
+// [b][c][f][h][w] (fp32 / bf16)  ->  [(rep b) f][h][w][Cpad] bf16, zero channel padding.
+// The reference's 'b c f h w -> (b f) c h w' rearrange (src/models/resnet.py:12) plus the CFG
+// `.repeat(2, ...)` of src/pipelines/pipeline_pose2vid_long.py:516-520 in one pass.
+__global__ __launch_bounds__(256) void hv_pack_kernel(const void* src, int src_bf16, int B, int C, int F, int H, int W,
+                                                      int rep, bf16_t* dst, int Cpad) {
+    const long npix = (long)B * F * H * W;
+    const int cvs = Cpad / 8;
+    const long total = npix * cvs;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int cv = (int)(i % cvs);
+        long pix = i / cvs;
+        const int x = (int)(pix % W);
+        pix /= W;
+        const int y = (int)(pix % H);
+        pix /= H;
+        const int f = (int)(pix % F);
+        const int b = (int)(pix / F);
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int c = cv * 8 + e;
+            float a = 0.f;
+            if (c < C) {
+                const long si = ((((long)b * C + c) * F + f) * H + y) * W + x;
+                a = src_bf16 ? hv_bf2f(reinterpret_cast<const bf16_t*>(src)[si]) : reinterpret_cast<const float*>(src)[si];
+            }
+            v[e] = a;
+        }
+        const u32x4 o = hv_pack8(v);
+        for (int r = 0; r < rep; ++r) {
+            const long di = ((((long)(r * B + b) * F + f) * H + y) * W + x) * Cpad + cv * 8;
+            hv_st16(dst + di, o);
+        }
+    }
+}
+
+// [(b f)][h][w][ldc] bf16 -> [b][C][f][h][w] fp32 / bf16 ('(b f) c h w -> b c f h w')
+__global__ __launch_bounds__(256) void hv_unpack_kernel(const bf16_t* src, int ldc, int B, int C, int F, int H, int W,
+                                                        void* dst, int dst_bf16) {
+    const long total = (long)B * C * F * H * W;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        long r = i;
+        const int x = (int)(r % W);
+        r /= W;
+        const int y = (int)(r % H);
+        r /= H;
+        const int f = (int)(r % F);
+        r /= F;
+        const int c = (int)(r % C);
+        const int b = (int)(r / C);
+        const bf16_t v = src[((((long)b * F + f) * H + y) * W + x) * ldc + c];
+        if (dst_bf16)
+            reinterpret_cast<bf16_t*>(dst)[i] = v;
+        else
+            reinterpret_cast<float*>(dst)[i] = hv_bf2f(v);
+    }
+}
+
+// nn.PixelUnshuffle(r): out[(b f)][y][x][c*r*r + i*r + j] = in[b][c][f][y*r+i][x*r+j]
+__global__ __launch_bounds__(256) void hv_unshuffle_kernel(const float* src, int B, int C, int F, int H, int W, int r,
+                                                           bf16_t* dst) {
+    const int Ho = H / r, Wo = W / r, Co = C * r * r;
+    const long total = (long)B * F * Ho * Wo * Co;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        long t = i;
+        const int co = (int)(t % Co);
+        t /= Co;
+        const int x = (int)(t % Wo);
+        t /= Wo;
+        const int y = (int)(t % Ho);
+        t /= Ho;
+        const int f = (int)(t % F);
+        const int b = (int)(t / F);
+        const int c = co / (r * r), ij = co % (r * r), ii = ij / r, jj = ij % r;
+        dst[i] = hv_f2bf(src[((((long)b * C + c) * F + f) * H + y * r + ii) * W + x * r + jj]);
+    }
+}
+
+// diffusers Timesteps(dim, flip_sin_to_cos=True, downscale_freq_shift=0): [cos | sin]
+__global__ __launch_bounds__(256) void hv_timestep_kernel(const float* t, int B, int dim, bf16_t* dst) {
+    const int half = dim / 2;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * half) return;
+    const int b = i / half, k = i % half;
+    const float freq = expf(-9.210340371976184f * (float)k / (float)half);  // ln(10000)
+    const float a = t[b] * freq;
+    dst[(long)b * dim + k] = hv_f2bf(cosf(a));
+    dst[(long)b * dim + half + k] = hv_f2bf(sinf(a));
+}
+
+// noise_pred[:, :, c] += pred ; counter[:, :, c] += 1   (pipeline_pose2vid_long.py:550-552)
+__global__ __launch_bounds__(256) void hv_accumulate_kernel(const bf16_t* pred, int ldc, int rep, int C, int f_win,
+                                                            int H, int W, const int* frames, int F, float* acc,
+                                                            float* counter) {
+    const long total = (long)rep * C * f_win * H * W;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        long t = i;
+        const int x = (int)(t % W);
+        t /= W;
+        const int y = (int)(t % H);
+        t /= H;
+        const int fw = (int)(t % f_win);
+        t /= f_win;
+        const int c = (int)(t % C);
+        const int r = (int)(t / C);
+        const int f = frames[fw];
+        const float v = hv_bf2f(pred[((((long)r * f_win + fw) * H + y) * W + x) * ldc + c]);
+        acc[((((long)r * C + c) * F + f) * H + y) * W + x] += v;
+        if (r == 0 && c == 0 && y == 0 && x == 0) counter[f] += 1.0f;
+    }
+}
+
+// (noise_pred / counter).chunk(2) -> u + s (t - u) -> DDIM v-prediction step, eta = 0
+// (pipeline_pose2vid_long.py:555-563; diffusers DDIMScheduler.step).
+// Also clears the accumulators for the next step.
+__global__ __launch_bounds__(256) void hv_cfg_ddim_kernel(float* latents, float* acc, float* counter, int rep, int C,
+                                                          int F, int H, int W, float guidance, float sqrt_a,
+                                                          float sqrt_1ma, float sqrt_ap, float sqrt_1map) {
+    const long per = (long)C * F * H * W;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < per; i += (long)gridDim.x * blockDim.x) {
+        const int f = (int)((i / ((long)H * W)) % F);
+        const float cnt = counter[f];
+        float v = acc[i] / cnt;
+        acc[i] = 0.f;
+        if (rep == 2) {
+            const float c = acc[per + i] / cnt;
+            acc[per + i] = 0.f;
+            v = v + guidance * (c - v);
+        }
+        const float x = latents[i];
+        const float x0 = sqrt_a * x - sqrt_1ma * v;
+        const float eps = sqrt_a * v + sqrt_1ma * x;
+        latents[i] = sqrt_ap * x0 + sqrt_1map * eps;
+    }
+}
+
+__global__ void hv_clear_kernel(float* p, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = 0.f;
+}
+
+static inline int hv_ew_grid(long total) {
+    long g = (total + 255) / 256;
+    return (int)(g < 1 ? 1 : (g > 4096 ? 4096 : g));
+}
+
+static inline void hv_pack_launch(const void* src, int src_bf16, int B, int C, int F, int H, int W, int rep,
+                                  bf16_t* dst, int Cpad, hipStream_t s) {
+    hv_launch(hv_pack_kernel, dim3(hv_ew_grid((long)B * F * H * W * (Cpad / 8))), dim3(256), s, src, src_bf16, B, C, F,
+              H, W, rep, dst, Cpad);
+}
+static inline void hv_unpack_launch(const bf16_t* src, int ldc, int B, int C, int F, int H, int W, void* dst,
+                                    int dst_bf16, hipStream_t s) {
+    hv_launch(hv_unpack_kernel, dim3(hv_ew_grid((long)B * C * F * H * W)), dim3(256), s, src, ldc, B, C, F, H, W, dst,
+              dst_bf16);
+}
+static inline void hv_unshuffle_launch(const float* src, int B, int C, int F, int H, int W, int r, bf16_t* dst,
+                                       hipStream_t s) {
+    hv_launch(hv_unshuffle_kernel, dim3(hv_ew_grid((long)B * C * F * H * W)), dim3(256), s, src, B, C, F, H, W, r, dst);
+}
+static inline void hv_timestep_launch(const float* t, int B, int dim, bf16_t* dst, hipStream_t s) {
+    hv_launch(hv_timestep_kernel, dim3((B * dim / 2 + 255) / 256), dim3(256), s, t, B, dim, dst);
+}
+static inline void hv_accumulate_launch(const bf16_t* pred, int ldc, int rep, int C, int f_win, int H, int W,
+                                        const int* frames, int F, float* acc, float* counter, hipStream_t s) {
+    hv_launch(hv_accumulate_kernel, dim3(hv_ew_grid((long)rep * C * f_win * H * W)), dim3(256), s, pred, ldc, rep, C,
+              f_win, H, W, frames, F, acc, counter);
+}
+static inline void hv_cfg_ddim_launch(float* latents, float* acc, float* counter, int rep, int C, int F, int H, int W,
+                                      float guidance, float sa, float s1a, float sap, float s1ap, hipStream_t s) {
+    hv_launch(hv_cfg_ddim_kernel, dim3(hv_ew_grid((long)C * F * H * W)), dim3(256), s, latents, acc, counter, rep, C, F,
+              H, W, guidance, sa, s1a, sap, s1ap);
+    hv_launch(hv_clear_kernel, dim3((F + 255) / 256), dim3(256), s, counter, F);
+}

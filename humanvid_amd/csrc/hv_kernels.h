@@ -1,0 +1,30 @@
+// hv_kernels.h -- launch entry points of the kernel translation units (k_*.hip).
+// Each family is its own TU so hipcc can build them in parallel; the emulator build (tests)
+// defines HV_SINGLE_TU and pulls the kernels in here instead.
+#pragma once
+#include "hv_common.h"
+
+int hvk_gemm(const hv_gemm_params& p, hipStream_t s);
+int hvk_conv3x3(const hv_conv3x3_params& p, hipStream_t s);
+int hvk_groupnorm(const hv_groupnorm_params& p, hipStream_t s);
+void hvk_layernorm(const bf16_t* X, long ldx, int M, int C, float eps, float* mean, float* rstd, hipStream_t s);
+int hvk_attention(const hv_attention_params& p, hipStream_t s);
+int hvk_temporal(const hv_temporal_attention_params& p, hipStream_t s);
+void hvk_pack(const void* src, int src_bf16, int B, int C, int F, int H, int W, int rep, bf16_t* dst, int Cpad,
+              hipStream_t s);
+void hvk_unpack(const bf16_t* src, int ldc, int B, int C, int F, int H, int W, void* dst, int dst_bf16, hipStream_t s);
+void hvk_unshuffle(const float* src, int B, int C, int F, int H, int W, int r, bf16_t* dst, hipStream_t s);
+void hvk_timestep(const float* t, int B, int dim, bf16_t* dst, hipStream_t s);
+void hvk_accumulate(const bf16_t* pred, int ldc, int rep, int C, int f_win, int H, int W, const int* frames, int F,
+                    float* acc, float* counter, hipStream_t s);
+void hvk_cfg_ddim(float* latents, float* acc, float* counter, int rep, int C, int F, int H, int W, float guidance,
+                  float sa, float s1a, float sap, float s1ap, hipStream_t s);
+
+#ifdef HV_SINGLE_TU
+#include "k_gemm.hip"
+#include "k_conv.hip"
+#include "k_norm.hip"
+#include "k_attention.hip"
+#include "k_temporal.hip"
+#include "k_elementwise.hip"
+#endif

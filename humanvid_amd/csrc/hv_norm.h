@@ -1,0 +1,173 @@
+// hv_norm.h -- normalisation statistics (HBM-bound reductions); the normalise/affine step itself
+// is always fused into the consumer kernel (hv_conv3x3 / hv_gemm), never materialised.
+//
+//  * GroupNorm(32) per image (InflatedGroupNorm, /root/reference/src/models/resnet.py:18-26;
+//    torch.nn.GroupNorm in transformer_3d.py:58-60 and motion_module.py:119-121): one pass over
+//    the channels-last activation with 16-byte loads, fp32 sum / sum-of-squares per channel in
+//    registers, reduced to groups in LDS; deterministic two-level reduction (no atomics); a tiny
+//    second kernel turns (mean, rstd, gamma, beta) into per-(image,channel) scale/shift.
+//    Supports the two-source channel concat of the up-blocks (groups may straddle the seam).
+//  * LayerNorm row statistics (mean, rstd), one wavefront per token row, two-pass in registers.
+#pragma once
+#include "hv_common.h"
+#include "humanvid_hip.h"
+
+#define HV_GN_MAXREP 2  // channel-vectors per thread: supports C <= 256 * 8 * 2 = 4096
+
+__global__ __launch_bounds__(256) void hv_gn_partial_kernel(hv_groupnorm_params p) {
+    // grid: (splits, n_images).  Each workgroup reduces a contiguous pixel range of one image.
+    __shared__ float red[2][4096];  // per-channel sum / sumsq
+    const int tid = threadIdx.x;
+    const int C = p.C1 + p.C2, CV = C / 8;
+    const int img = blockIdx.y, split = blockIdx.x;
+    const int per = (p.pixels + p.splits - 1) / p.splits;
+    const int pb = split * per, pe = min(pb + per, p.pixels);
+
+    // thread -> (channel vector, pixel lane)
+    const int P = CV <= 256 ? 256 / CV : 1;   // pixels processed concurrently
+    const int nrep = CV <= 256 ? 1 : (CV + 255) / 256;
+    float s[HV_GN_MAXREP][8], q[HV_GN_MAXREP][8];
+#pragma unroll
+    for (int r = 0; r < HV_GN_MAXREP; ++r)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s[r][e] = q[r][e] = 0.f;
+
+    const int cv0 = CV <= 256 ? tid % CV : tid;
+    const int pl = CV <= 256 ? tid / CV : 0;
+    const bool active = pl < P;
+    if (active) {
+        for (int pix = pb + pl; pix < pe; pix += P) {
+#pragma unroll
+            for (int r = 0; r < HV_GN_MAXREP; ++r) {
+                const int cv = cv0 + 256 * r;
+                if (r < nrep && cv < CV) {
+                    const int c = cv * 8;
+                    const bf16_t* src = c < p.C1 ? p.X + ((long)img * p.pixels + pix) * p.C1 + c
+                                                 : p.X2 + ((long)img * p.pixels + pix) * p.C2 + (c - p.C1);
+                    float f[8];
+                    hv_unpack8(hv_ld16(src), f);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        s[r][e] += f[e];
+                        q[r][e] += f[e] * f[e];
+                    }
+                }
+            }
+        }
+    }
+    // reduce across pixel lanes: lane pl == 0 initialises, the others add in turn (P <= 64 rounds
+    // only when C is tiny; typical P is 1..6)
+    for (int round = 0; round < P; ++round) {
+        if (active && pl == round) {
+#pragma unroll
+            for (int r = 0; r < HV_GN_MAXREP; ++r) {
+                const int cv = cv0 + 256 * r;
+                if (r < nrep && cv < CV) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        if (round == 0) {
+                            red[0][cv * 8 + e] = s[r][e];
+                            red[1][cv * 8 + e] = q[r][e];
+                        } else {
+                            red[0][cv * 8 + e] += s[r][e];
+                            red[1][cv * 8 + e] += q[r][e];
+                        }
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+    const int cg = C / p.groups;
+    for (int g = tid; g < p.groups; g += 256) {
+        float a = 0.f, b = 0.f;
+        for (int c = g * cg; c < (g + 1) * cg; ++c) {
+            a += red[0][c];
+            b += red[1][c];
+        }
+        float* dst = p.partial + (((long)img * p.splits + split) * p.groups + g) * 2;
+        dst[0] = a;
+        dst[1] = b;
+    }
+}
+
+__global__ __launch_bounds__(256) void hv_gn_finalize_kernel(hv_groupnorm_params p) {
+    // grid: (ceil(C/256), n_images): scale/shift per (image, channel)
+    const int C = p.C1 + p.C2;
+    const int c = blockIdx.x * 256 + threadIdx.x, img = blockIdx.y;
+    if (c >= C) return;
+    const int cg = C / p.groups, g = c / cg;
+    float a = 0.f, b = 0.f;
+    for (int sp = 0; sp < p.splits; ++sp) {
+        const float* src = p.partial + (((long)img * p.splits + sp) * p.groups + g) * 2;
+        a += src[0];
+        b += src[1];
+    }
+    const float cnt = (float)cg * (float)p.pixels;
+    const float mean = a / cnt;
+    float var = b / cnt - mean * mean;
+    var = var > 0.f ? var : 0.f;
+    const float rstd = 1.0f / sqrtf(var + p.eps);
+    const float sc = rstd * p.gamma[c];
+    p.scale[(long)img * C + c] = sc;
+    p.shift[(long)img * C + c] = p.beta[c] - mean * sc;
+}
+
+static inline int hv_groupnorm_launch(const hv_groupnorm_params& p, hipStream_t stream) {
+    const int C = p.C1 + p.C2;
+    if (p.C1 % 8 != 0 || p.C2 % 8 != 0 || C % p.groups != 0 || C > 4096 || p.splits < 1) return -1;
+    if (p.C2 > 0 && p.X2 == nullptr) return -1;
+    hv_launch(hv_gn_partial_kernel, dim3(p.splits, p.n_images), dim3(256), stream, p);
+    hv_launch(hv_gn_finalize_kernel, dim3((C + 255) / 256, p.n_images), dim3(256), stream, p);
+    return 0;
+}
+
+// ---- LayerNorm statistics: one wavefront per row -----------------------------------------------
+#define HV_LN_MAXV 4  // 16-byte vectors per lane: C <= 64 * 8 * 4 = 2048
+
+__global__ __launch_bounds__(256) void hv_ln_stats_kernel(const bf16_t* X, long ldx, int M, int C, float eps,
+                                                          float* mean_out, float* rstd_out) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int row = blockIdx.x * 4 + wave;
+    const int CV = C / 8;
+    // no early return: every lane takes part in the wave shuffles below
+    const bool live = row < M;
+    float f[HV_LN_MAXV][8];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < HV_LN_MAXV; ++i) {
+        const int cv = lane + 64 * i;
+        const bool on = live && cv < CV;
+        u32x4 v = {0u, 0u, 0u, 0u};
+        if (on) v = hv_ld16(X + (long)row * ldx + cv * 8);
+        hv_unpack8(v, f[i]);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s += f[i][e];
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o);
+    const float mean = s / (float)C;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < HV_LN_MAXV; ++i) {
+        const int cv = lane + 64 * i;
+        if (cv < CV) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float d = f[i][e] - mean;
+                q += d * d;
+            }
+        }
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) q += __shfl_xor(q, o);
+    if (live && lane == 0) {
+        mean_out[row] = mean;
+        rstd_out[row] = 1.0f / sqrtf(q / (float)C + eps);
+    }
+}
+
+static inline void hv_layernorm_launch(const bf16_t* X, long ldx, int M, int C, float eps, float* mean, float* rstd,
+                                       hipStream_t stream) {
+    hv_launch(hv_ln_stats_kernel, dim3((M + 3) / 4), dim3(256), stream, X, ldx, M, C, eps, mean, rstd);
+}

@@ -1,0 +1,23 @@
+// k_elementwise.hip -- translation unit for hv_elementwise.h (see hv_kernels.h)
+#include "hv_elementwise.h"
+#include "hv_kernels.h"
+
+void hvk_pack(const void* src, int src_bf16, int B, int C, int F, int H, int W, int rep, bf16_t* dst, int Cpad,
+              hipStream_t s) {
+    hv_pack_launch(src, src_bf16, B, C, F, H, W, rep, dst, Cpad, s);
+}
+void hvk_unpack(const bf16_t* src, int ldc, int B, int C, int F, int H, int W, void* dst, int dst_bf16, hipStream_t s) {
+    hv_unpack_launch(src, ldc, B, C, F, H, W, dst, dst_bf16, s);
+}
+void hvk_unshuffle(const float* src, int B, int C, int F, int H, int W, int r, bf16_t* dst, hipStream_t s) {
+    hv_unshuffle_launch(src, B, C, F, H, W, r, dst, s);
+}
+void hvk_timestep(const float* t, int B, int dim, bf16_t* dst, hipStream_t s) { hv_timestep_launch(t, B, dim, dst, s); }
+void hvk_accumulate(const bf16_t* pred, int ldc, int rep, int C, int f_win, int H, int W, const int* frames, int F,
+                    float* acc, float* counter, hipStream_t s) {
+    hv_accumulate_launch(pred, ldc, rep, C, f_win, H, W, frames, F, acc, counter, s);
+}
+void hvk_cfg_ddim(float* latents, float* acc, float* counter, int rep, int C, int F, int H, int W, float guidance,
+                  float sa, float s1a, float sap, float s1ap, hipStream_t s) {
+    hv_cfg_ddim_launch(latents, acc, counter, rep, C, F, H, W, guidance, sa, s1a, sap, s1ap, s);
+}

@@ -1,0 +1,5 @@
+// k_gemm.hip -- translation unit for hv_gemm.h (see hv_kernels.h)
+#include "hv_gemm.h"
+#include "hv_kernels.h"
+
+int hvk_gemm(const hv_gemm_params& p, hipStream_t s) { return hv_gemm_launch(p, s); }

@@ -1,0 +1,8 @@
+// k_norm.hip -- translation unit for hv_norm.h (see hv_kernels.h)
+#include "hv_norm.h"
+#include "hv_kernels.h"
+
+int hvk_groupnorm(const hv_groupnorm_params& p, hipStream_t s) { return hv_groupnorm_launch(p, s); }
+void hvk_layernorm(const bf16_t* X, long ldx, int M, int C, float eps, float* mean, float* rstd, hipStream_t s) {
+    hv_layernorm_launch(X, ldx, M, C, eps, mean, rstd, s);
+}

@@ -1,0 +1,135 @@
+"""Typed Python entry points over the C ABI: build the parameter structs from tensors.
+
+Tensors are only used for their `data_ptr()`, shape and stride -- PyTorch is the allocator, not
+the compute engine.  Every function takes the loaded library (`HvLibrary`) and a raw stream handle.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from typing import Optional
+
+import torch
+
+from . import _abi as A
+
+BF16 = torch.bfloat16
+
+
+def _p(t: Optional[torch.Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+def _chk(t: torch.Tensor, dtype, what: str):
+    if t.dtype != dtype:
+        raise ValueError(f"{what}: expected {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise ValueError(f"{what}: must be contiguous")
+
+
+def gemm(lib, stream, x, w, y, *, x2=None, k1=0, yt=None, n_split=0, pro_scale=None, pro_shift=None,
+         rows_per_image=1, pro_act=A.ACT_NONE, bias=None, row_mean=None, row_rstd=None, colsum=None, pe=None,
+         pe_period=1, pe_frames=1, rowvec=None, rowvec_period=1, residual=None, geglu=False, out_act=A.ACT_NONE,
+         M=None, ldx=None, ldy=None, ldr=None, ldx2=None):
+    """y[M, N(/2)] = epi(pro(x)[M, K] @ w[N, K]^T); x/x2/y/residual may be row-strided views."""
+    N, K = w.shape
+    M = x.shape[0] if M is None else M
+    p = A.GemmParams(
+        X=_p(x), ldx=x.stride(0) if ldx is None else ldx, X2=_p(x2),
+        ldx2=(x2.stride(0) if x2 is not None else 0) if ldx2 is None else ldx2, K1=k1,
+        W=_p(w), Y=_p(y), ldy=y.stride(0) if ldy is None else ldy, out_f32=int(y.dtype == torch.float32),
+        Yt=_p(yt), ldyt=yt.stride(0) if yt is not None else 0, n_split=n_split,
+        M=M, N=N, K=K, pro_scale=_p(pro_scale), pro_shift=_p(pro_shift), rows_per_image=rows_per_image,
+        pro_act=pro_act, bias=_p(bias), row_mean=_p(row_mean), row_rstd=_p(row_rstd), colsum=_p(colsum),
+        pe=_p(pe), pe_period=pe_period, pe_frames=pe_frames, rowvec=_p(rowvec), rowvec_period=rowvec_period,
+        residual=_p(residual), ldr=(residual.stride(0) if residual is not None else 0) if ldr is None else ldr,
+        geglu=int(geglu), out_act=out_act,
+    )
+    lib.call("hv_gemm", C.byref(p), stream)
+
+
+def conv3x3(lib, stream, x, w, y, *, x2=None, mode=A.CONV_S1, pro_scale=None, pro_shift=None, pro_act=A.ACT_NONE,
+            bias=None, rowvec=None, images_per_rowvec=1, residual=None, out_act=A.ACT_NONE):
+    """x [n,Hs,Ws,C1] (+x2 [n,Hs,Ws,C2]); w packed [Cout, 9, C1+C2]; y [n,Ho,Wo,Cout]."""
+    n, Hs, Ws, C1 = x.shape
+    _, Ho, Wo, Cout = y.shape
+    p = A.Conv3x3Params(
+        X=_p(x), C1=C1, X2=_p(x2), C2=0 if x2 is None else x2.shape[3], W=_p(w), Y=_p(y),
+        n_images=n, Hs=Hs, Ws=Ws, Ho=Ho, Wo=Wo, Cout=Cout, mode=mode,
+        pro_scale=_p(pro_scale), pro_shift=_p(pro_shift), pro_act=pro_act, bias=_p(bias),
+        rowvec=_p(rowvec), images_per_rowvec=images_per_rowvec, residual=_p(residual),
+        residual_images=0 if residual is None else residual.shape[0], out_act=out_act,
+    )
+    lib.call("hv_conv3x3", C.byref(p), stream)
+
+
+def groupnorm_affine(lib, stream, x, gamma, beta, groups, eps, partial, scale, shift, *, x2=None, splits=None):
+    n, pixels, C1 = x.shape[0], x.shape[1] * x.shape[2], x.shape[3]
+    if splits is None:
+        splits = max(1, min(64, pixels // 64))
+    assert partial.numel() >= n * splits * groups * 2
+    p = A.GroupNormParams(
+        X=_p(x), C1=C1, X2=_p(x2), C2=0 if x2 is None else x2.shape[3], n_images=n, pixels=pixels,
+        groups=groups, eps=eps, gamma=_p(gamma), beta=_p(beta), partial=_p(partial), splits=splits,
+        scale=_p(scale), shift=_p(shift),
+    )
+    lib.call("hv_groupnorm_affine", C.byref(p), stream)
+
+
+def layernorm_stats(lib, stream, x, mean, rstd, eps=1e-5, M=None):
+    M = x.shape[0] if M is None else M
+    lib.call("hv_layernorm_stats", x.data_ptr(), x.stride(0), M, x.shape[1], eps, mean.data_ptr(), rstd.data_ptr(),
+             stream)
+
+
+def attention(lib, stream, q, k, vt, o, *, n_images, heads, D, Lq, L1, ldq, ldk, ldvt, ldo, k2=None, vt2=None,
+              ldk2=0, ldvt2=0, L2=0, bank_sel=None):
+    p = A.AttentionParams(
+        Q=_p(q), ldq=ldq, K=_p(k), ldk=ldk, Vt=_p(vt), ldvt=ldvt, K2=_p(k2), ldk2=ldk2, Vt2=_p(vt2), ldvt2=ldvt2,
+        bank_sel=_p(bank_sel), O=_p(o), ldo=ldo, n_images=n_images, heads=heads, D=D, Lq=Lq, L1=L1, L2=L2,
+        scale=1.0 / math.sqrt(D),
+    )
+    lib.call("hv_attention", C.byref(p), stream)
+
+
+def temporal_attention(lib, stream, qkv, o, *, B, F, P, heads, D, ld=None, ldo=None):
+    p = A.TemporalAttentionParams(
+        QKV=_p(qkv), ld=qkv.stride(0) if ld is None else ld, O=_p(o), ldo=o.stride(0) if ldo is None else ldo,
+        B=B, F=F, P=P, heads=heads, D=D, scale=1.0 / math.sqrt(D),
+    )
+    lib.call("hv_temporal_attention", C.byref(p), stream)
+
+
+def pack_ncfhw(lib, stream, src, dst, rep=1):
+    """src [B,C,F,H,W] fp32|bf16 -> dst [(rep B) F, H, W, Cpad] bf16."""
+    B, Cc, Fr, H, W = src.shape
+    lib.call("hv_pack_ncfhw", src.data_ptr(), int(src.dtype == BF16), B, Cc, Fr, H, W, rep, dst.data_ptr(),
+             dst.shape[-1], stream)
+
+
+def unpack_nhwc(lib, stream, src, dst):
+    """src [(B F), H, W, ldc] bf16 -> dst [B,C,F,H,W] fp32|bf16."""
+    B, Cc, Fr, H, W = dst.shape
+    lib.call("hv_unpack_nhwc", src.data_ptr(), src.shape[-1], B, Cc, Fr, H, W, dst.data_ptr(),
+             int(dst.dtype == BF16), stream)
+
+
+def pixel_unshuffle(lib, stream, src, dst, r):
+    B, Cc, Fr, H, W = src.shape
+    lib.call("hv_pixel_unshuffle", src.data_ptr(), B, Cc, Fr, H, W, r, dst.data_ptr(), stream)
+
+
+def timestep_embedding(lib, stream, t, dst):
+    lib.call("hv_timestep_embedding", t.data_ptr(), dst.shape[0], dst.shape[1], dst.data_ptr(), stream)
+
+
+def accumulate_window(lib, stream, pred, rep, Cc, frames, acc, counter):
+    f_win, H, W, ldc = pred.shape[0] // rep, pred.shape[1], pred.shape[2], pred.shape[3]
+    lib.call("hv_accumulate_window", pred.data_ptr(), ldc, rep, Cc, f_win, H, W, frames.data_ptr(), acc.shape[2],
+             acc.data_ptr(), counter.data_ptr(), stream)
+
+
+def cfg_ddim_step(lib, stream, latents, acc, counter, rep, guidance, sqrt_a, sqrt_1ma, sqrt_ap, sqrt_1map):
+    _, Cc, Fr, H, W = latents.shape
+    lib.call("hv_cfg_ddim_step", latents.data_ptr(), acc.data_ptr(), counter.data_ptr(), rep, Cc, Fr, H, W,
+             guidance, sqrt_a, sqrt_1ma, sqrt_ap, sqrt_1map, stream)

@@ -1,0 +1,208 @@
+/* humanvid_hip.h -- C ABI of libhumanvid_hip.so: the MI355X (gfx950) kernels of the CamAnimate
+ * denoising path.
+ *
+ * The reference (zhenzhiwang/HumanVid) is pure Python and has no FFI / operator registry; its
+ * boundary for this path is the Python class surface, which the `src.*` /
+ * `humanvid_amd.*` host code reproduces.  This header is the native layer underneath it: every
+ * entry point replaces a group of ATen / diffusers ops the reference dispatches, cited below as
+ * /root/reference file:line.  Conventions:
+ *   - plain C: raw device pointers, sizes, strides; the caller owns every buffer (including
+ *     workspaces); the library keeps no state besides captured graphs.
+ *   - activations: bfloat16 bits (uint16_t), channels-last  [image][y][x][channel]
+ *     == [image][token][channel]; image index = batch * frames + frame.
+ *   - `stream` is a hipStream_t passed as void*; all work is enqueued asynchronously on it.
+ *   - return value: 0 on success, negative HV_E* code otherwise; hv_last_error() returns a
+ *     thread-local description of the last failure.
+ */
+#ifndef HUMANVID_HIP_H
+#define HUMANVID_HIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HV_OK 0
+#define HV_EINVAL (-1)  /* shape / alignment / dtype violation */
+#define HV_ENOTSUP (-2) /* e.g. head dim not in {40, 80, 160} */
+#define HV_EHIP (-3)    /* HIP runtime error, see hv_last_error() */
+
+#define HV_ACT_NONE 0
+#define HV_ACT_SILU 1
+#define HV_ACT_RELU 2
+
+const char* hv_last_error(void);
+int hv_abi_version(void);
+/* sizeof() of every parameter struct, in declaration order -- lets a binding verify its mirror */
+int hv_struct_sizes(int* out, int capacity);
+
+/* ---- dense contraction --------------------------------------------------------------------
+ * Y[M,N] = epi( pro(X)[M,K] . W[N,K]^T ).  Replaces nn.Linear / 1x1 nn.Conv2d call sites:
+ * Transformer3DModel proj_in/out (src/models/transformer_3d.py:125-166), motion-module
+ * proj_in/out (src/models/motion_module.py:157-175), diffusers Attention to_q/k/v/to_out,
+ * FeedForward/GEGLU, TimestepEmbedding (src/models/unet_3d.py:461-467), time_emb_proj
+ * (src/models/resnet.py:224), conv_shortcut (src/models/resnet.py:211-213).               */
+typedef struct hv_gemm_params {
+    const uint16_t* X;
+    long ldx;
+    const uint16_t* X2; /* optional: columns k >= K1 come from X2[m][k-K1] (skip concat) */
+    long ldx2;
+    int K1;
+    const uint16_t* W; /* [N][K] */
+    void* Y;           /* bf16, or float when out_f32 */
+    long ldy;
+    int out_f32;
+    uint16_t* Yt; /* columns n >= n_split are stored transposed: Yt[(n-n_split)*ldyt + m] */
+    long ldyt;
+    int n_split;
+    int M, N, K;
+    const float* pro_scale; /* [M/rows_per_image][K]: x' = act(x*scale + shift) (GroupNorm apply) */
+    const float* pro_shift;
+    int rows_per_image;
+    int pro_act;
+    const float* bias;     /* [N] */
+    const float* row_mean; /* LayerNorm fold: y = rstd[m]*(acc - mean[m]*colsum[n]) + bias[n] */
+    const float* row_rstd;
+    const float* colsum;
+    const float* pe; /* [pe_frames][N], row m uses frame (m / pe_period) % pe_frames */
+    int pe_period;
+    int pe_frames;
+    const float* rowvec; /* [M/rowvec_period][N] (time embedding, folded cross-attention) */
+    int rowvec_period;
+    const uint16_t* residual;
+    long ldr;
+    int geglu; /* W rows packed as [16 h | 16 g] blocks; Y has N/2 columns: h * gelu(g) */
+    int out_act;
+} hv_gemm_params;
+int hv_gemm(const hv_gemm_params* p, void* stream);
+
+/* ---- 3x3 convolution (implicit GEMM, LDS halo tile) ---------------------------------------
+ * Replaces InflatedConv3d 3x3 (src/models/resnet.py:9-15) incl. ResnetBlock3D conv1/conv2 with the
+ * preceding InflatedGroupNorm+SiLU applied on load (src/models/resnet.py:215-245), Downsample3D
+ * (stride 2, :110-118), Upsample3D (nearest 2x folded into addressing, :51-88), the skip
+ * torch.cat (src/models/unet_3d_blocks.py:698,828: two-source channel loop), PoseGuider convs
+ * (src/models/pose_guider.py:51-61) and the camera encoder convs (src/cameractrl/pose_adaptor.py). */
+#define HV_CONV_S1 0
+#define HV_CONV_S2 1
+#define HV_CONV_UP2 2
+typedef struct hv_conv3x3_params {
+    const uint16_t* X; /* [n][Hs][Ws][C1] */
+    int C1;
+    const uint16_t* X2; /* optional second source, channels C1..C1+C2 */
+    int C2;
+    const uint16_t* W; /* packed [Cout][9][C1+C2], tap = ky*3+kx */
+    uint16_t* Y;       /* [n][Ho][Wo][Cout] */
+    int n_images, Hs, Ws, Ho, Wo, Cout;
+    int mode;
+    const float* pro_scale; /* [n][Cin] GroupNorm apply (+ pro_act) on load; padding stays zero */
+    const float* pro_shift;
+    int pro_act;
+    const float* bias;
+    const float* rowvec; /* [n/images_per_rowvec][Cout] (time embedding) */
+    int images_per_rowvec;
+    const uint16_t* residual; /* [residual_images][Ho][Wo][Cout], image index taken modulo */
+    int residual_images;
+    int out_act;
+} hv_conv3x3_params;
+int hv_conv3x3(const hv_conv3x3_params* p, void* stream);
+
+/* ---- GroupNorm statistics -> per-(image,channel) affine -----------------------------------
+ * InflatedGroupNorm (src/models/resnet.py:18-26), torch.nn.GroupNorm in Transformer3DModel
+ * (src/models/transformer_3d.py:58-60,123) and the motion module (src/models/motion_module.py:119).
+ * Produces scale/shift so that GN(x)[c] = x*scale[img][c] + shift[img][c]; the apply step is fused
+ * into the consumer (hv_conv3x3 / hv_gemm prologue).                                       */
+typedef struct hv_groupnorm_params {
+    const uint16_t* X;
+    int C1;
+    const uint16_t* X2;
+    int C2;
+    int n_images, pixels, groups;
+    float eps;
+    const float* gamma;
+    const float* beta;
+    float* partial; /* workspace: n_images * splits * groups * 2 floats */
+    int splits;
+    float* scale; /* out [n_images][C] */
+    float* shift;
+} hv_groupnorm_params;
+int hv_groupnorm_affine(const hv_groupnorm_params* p, void* stream);
+
+/* LayerNorm row statistics (nn.LayerNorm eps 1e-5; src/models/attention.py:329-360,
+ * src/models/motion_module.py:228,234); normalisation itself is folded into hv_gemm.       */
+int hv_layernorm_stats(const uint16_t* X, long ldx, int M, int C, float eps, float* mean, float* rstd,
+                       void* stream);
+
+/* ---- spatial self-attention with reference-bank keys --------------------------------------
+ * diffusers Attention/AttnProcessor2_0 SDPA as used by the patched TemporalBasicTransformerBlock
+ * (src/models/mutual_self_attention.py:147-186): per image, keys/values = own tokens, followed by
+ * the reference bank tokens for images whose bank_sel >= 0 (the CFG-unconditional half attends
+ * to its own tokens only).  Flash-style online softmax, MFMA 16x16x32.                      */
+typedef struct hv_attention_params {
+    const uint16_t* Q; /* row = img*Lq + q, head h at column h*D */
+    long ldq;
+    const uint16_t* K; /* row = img*L1 + kv */
+    long ldk;
+    const uint16_t* Vt; /* transposed values: Vt[(h*D+d)*ldvt + img*L1 + kv] */
+    long ldvt;
+    const uint16_t* K2; /* bank keys: row = sel*L2 + kv */
+    long ldk2;
+    const uint16_t* Vt2;
+    long ldvt2;
+    const int* bank_sel; /* [n_images] or NULL */
+    uint16_t* O;
+    long ldo;
+    int n_images, heads, D, Lq, L1, L2;
+    float scale;
+} hv_attention_params;
+int hv_attention(const hv_attention_params* p, void* stream);
+
+/* ---- temporal self-attention over the frame axis ------------------------------------------
+ * VersatileAttention (src/models/motion_module.py:351-388) and the camera encoder's
+ * TemporalSelfAttention (src/cameractrl/motion_module.py:323-388): for every (batch, pixel, head)
+ * attention across F frames; rows of QKV are (b*F + f)*P + p, columns [q | k | v] of width C.   */
+typedef struct hv_temporal_attention_params {
+    const uint16_t* QKV;
+    long ld;
+    uint16_t* O;
+    long ldo;
+    int B, F, P, heads, D;
+    float scale;
+} hv_temporal_attention_params;
+int hv_temporal_attention(const hv_temporal_attention_params* p, void* stream);
+
+/* ---- layout adaptors at the drop-in boundary ----------------------------------------------
+ * [b][c][f][h][w] (fp32 or bf16, the reference's layout) <-> [(rep b) f][h][w][cpad] bf16.     */
+int hv_pack_ncfhw(const void* src, int src_is_bf16, int B, int C, int F, int H, int W, int rep, uint16_t* dst,
+                  int Cpad, void* stream);
+int hv_unpack_nhwc(const uint16_t* src, int ldc, int B, int C, int F, int H, int W, void* dst, int dst_is_bf16,
+                   void* stream);
+/* nn.PixelUnshuffle(r) on [b][c][f][H][W] fp32 -> [(b f)][H/r][W/r][c*r*r] bf16
+ * (src/cameractrl/pose_adaptor.py:177,236) */
+int hv_pixel_unshuffle(const float* src, int B, int C, int F, int H, int W, int r, uint16_t* dst, void* stream);
+/* diffusers Timesteps(320, flip_sin_to_cos=True, shift 0) (src/models/unet_3d.py:93,461): [B][dim] bf16 */
+int hv_timestep_embedding(const float* t, int B, int dim, uint16_t* dst, void* stream);
+
+/* ---- window accumulation, classifier-free guidance and the DDIM v-prediction update --------
+ * src/pipelines/pipeline_pose2vid_long.py:550-563 (+ diffusers DDIMScheduler.step, eta = 0).
+ * pred: [(rep f_win)][h][w][ldc] bf16 (conv_out output); acc: fp32 [rep][C][F][h][w]; counter [F]. */
+int hv_accumulate_window(const uint16_t* pred, int ldc, int rep, int C, int f_win, int H, int W, const int* frames,
+                         int F, float* acc, float* counter, void* stream);
+int hv_cfg_ddim_step(float* latents, float* acc, float* counter, int rep, int C, int F, int H, int W,
+                     float guidance, float sqrt_a, float sqrt_1ma, float sqrt_ap, float sqrt_1map, void* stream);
+
+/* ---- HIP graph capture of a launch sequence (one denoising step) ---------------------------- */
+int hv_graph_begin(void* stream);
+int hv_graph_end(void* stream, void** graph_exec_out);
+int hv_graph_launch(void* graph_exec, void* stream);
+int hv_graph_destroy(void* graph_exec);
+
+/* timing helper used by bench.py: elapsed milliseconds between two events it records on `stream` */
+int hv_event_create(void** ev);
+int hv_event_record(void* ev, void* stream);
+int hv_event_elapsed_ms(void* start, void* stop, float* ms);
+int hv_event_destroy(void* ev);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

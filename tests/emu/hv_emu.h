@@ -1,0 +1,282 @@
+// hv_emu.h -- a tiny single-threaded emulator of the HIP execution model (workgroups of
+// 64-lane waves, LDS, barriers, wave-collective MFMA / shuffles), built on ucontext fibers.
+//
+// DEVELOPMENT / TEST INFRASTRUCTURE ONLY.  The build container has no GPU, so the kernels in
+// humanvid_amd/csrc are additionally compiled for the host against this header (-DHV_EMU) and
+// their index arithmetic (MFMA fragment layouts, LDS tiling, halo handling, online softmax)
+// is checked against the oracle on tiny shapes by tests/test_emu_kernels.py.  The product
+// library (libhumanvid_hip.so) never contains or loads any of this; nothing here is a
+// "CPU fallback".
+//
+// Fidelity notes:
+//  * MFMA C/D layouts follow /opt/skills/guides/cdna_hip_programming.md section 3:
+//      16x16:  col = lane & 15, row = (lane >> 4) * 4 + reg
+//      32x32:  col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+//    A/B operands: lane (i = lane & 15|31, g = lane >> 4|5) holds k = g * KV + 0..KV-1 where KV
+//    is the per-lane vector length (8 for the gfx950 double-K shapes, 4 for 16x16x16).
+//  * products are accumulated in fp32 in k order, inputs are bf16.
+//  * fibers run to the next barrier/collective in thread order, so a missing __syncthreads()
+//    shows up as a wrong result rather than being hidden by lock-step execution.
+#pragma once
+#include <ucontext.h>
+
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <vector>
+
+namespace hvemu {
+
+struct uint3_ {
+    unsigned x, y, z;
+};
+struct dim3 {
+    unsigned x, y, z;
+    dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
+};
+
+struct WaveState {
+    int arrived = 0;
+    int gen = 0;
+    alignas(16) unsigned char in[64][160];
+    alignas(16) unsigned char out[64][64];
+};
+
+struct Fiber {
+    ucontext_t ctx;
+    uint3_ tid;
+    int lane, wave;
+    bool done = false;
+    std::vector<char> stack;
+};
+
+struct Block {
+    std::vector<Fiber> fibers;
+    std::vector<WaveState> waves;
+    int bar_arrived = 0, bar_gen = 0, alive = 0;
+};
+
+inline Block* g_block = nullptr;
+inline Fiber* cur = nullptr;
+inline ucontext_t g_sched;
+inline uint3_ g_blockIdx, g_blockDim, g_gridDim;
+inline std::function<void()>* g_body = nullptr;
+
+inline void yield_() { swapcontext(&cur->ctx, &g_sched); }
+
+inline void fiber_entry() {
+    (*g_body)();
+    cur->done = true;
+    g_block->alive--;
+    // a thread that exits early must not dead-lock a barrier the others are waiting on
+    swapcontext(&cur->ctx, &g_sched);
+}
+
+inline void syncthreads() {
+    Block& b = *g_block;
+    int my = b.bar_gen;
+    if (++b.bar_arrived >= b.alive) {
+        b.bar_arrived = 0;
+        b.bar_gen++;
+        return;
+    }
+    while (b.bar_gen == my) yield_();
+}
+
+// run `compute(in[64], out[64])` once per wave when all 64 lanes have arrived
+template <class F>
+inline void wave_collective(const void* in, size_t in_sz, void* out, size_t out_sz, F compute) {
+    WaveState& w = g_block->waves[cur->wave];
+    if (in_sz > sizeof(w.in[0]) || out_sz > sizeof(w.out[0])) {
+        fprintf(stderr, "hvemu: collective payload too large\n");
+        abort();
+    }
+    memcpy(w.in[cur->lane], in, in_sz);
+    int my = w.gen;
+    if (++w.arrived == 64) {
+        compute(w);
+        w.arrived = 0;
+        w.gen++;
+    } else {
+        while (w.gen == my) yield_();
+    }
+    memcpy(out, w.out[cur->lane], out_sz);
+}
+
+inline void launch(dim3 grid, dim3 block, std::function<void()> body, size_t stack_bytes = 256 * 1024) {
+    const int nthreads = block.x * block.y * block.z;
+    if (nthreads % 64) {
+        fprintf(stderr, "hvemu: block size must be a multiple of 64\n");
+        abort();
+    }
+    g_body = &body;
+    g_blockDim = {block.x, block.y, block.z};
+    g_gridDim = {grid.x, grid.y, grid.z};
+    Block blk;
+    blk.fibers.resize(nthreads);
+    blk.waves.resize(nthreads / 64);
+    for (auto& f : blk.fibers) f.stack.resize(stack_bytes);
+    g_block = &blk;
+    for (unsigned bz = 0; bz < grid.z; ++bz)
+        for (unsigned by = 0; by < grid.y; ++by)
+            for (unsigned bx = 0; bx < grid.x; ++bx) {
+                g_blockIdx = {bx, by, bz};
+                blk.bar_arrived = 0;
+                blk.alive = nthreads;
+                for (auto& w : blk.waves) w.arrived = 0;
+                for (int t = 0; t < nthreads; ++t) {
+                    Fiber& f = blk.fibers[t];
+                    f.done = false;
+                    f.tid = {t % block.x, (t / block.x) % block.y, t / (block.x * block.y)};
+                    f.lane = t % 64;
+                    f.wave = t / 64;
+                    getcontext(&f.ctx);
+                    f.ctx.uc_stack.ss_sp = f.stack.data();
+                    f.ctx.uc_stack.ss_size = f.stack.size();
+                    f.ctx.uc_link = &g_sched;
+                    makecontext(&f.ctx, (void (*)())fiber_entry, 0);
+                }
+                long guard = 0;
+                while (blk.alive > 0) {
+                    for (int t = 0; t < nthreads; ++t) {
+                        Fiber& f = blk.fibers[t];
+                        if (f.done) continue;
+                        cur = &f;
+                        swapcontext(&g_sched, &f.ctx);
+                    }
+                    if (++guard > 50000000L) {
+                        fprintf(stderr, "hvemu: dead-lock (divergent barrier?)\n");
+                        abort();
+                    }
+                }
+            }
+    g_block = nullptr;
+    cur = nullptr;
+}
+
+}  // namespace hvemu
+
+// ---- the subset of the HIP device language the kernels use ---------------------------------
+using dim3 = hvemu::dim3;
+#define threadIdx (hvemu::cur->tid)
+#define blockIdx (hvemu::g_blockIdx)
+#define blockDim (hvemu::g_blockDim)
+#define gridDim (hvemu::g_gridDim)
+#define __global__
+#define __device__
+#define __host__
+#define __forceinline__ inline
+#define __shared__ static
+#define __launch_bounds__(...)
+#define __restrict__
+inline void __syncthreads() { hvemu::syncthreads(); }
+
+typedef short hv_s8 __attribute__((ext_vector_type(8)));
+typedef short hv_s4 __attribute__((ext_vector_type(4)));
+typedef float hv_f4 __attribute__((ext_vector_type(4)));
+typedef float hv_f16 __attribute__((ext_vector_type(16)));
+
+namespace hvemu {
+inline float bf2f(short s) {
+    uint32_t u = ((uint32_t)(uint16_t)s) << 16;
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+}
+
+template <int MN, int KV, int NREG, class VA, class VC>
+inline VC mfma(VA a, VA b, VC c) {
+    struct In {
+        VA a, b;
+        VC c;
+    } in{a, b, c};
+    VC out;
+    wave_collective(&in, sizeof(in), &out, sizeof(out), [](WaveState& w) {
+        constexpr int G = 64 / MN;  // lane groups along k
+        static float A[MN][G * KV], B[G * KV][MN];
+        for (int l = 0; l < 64; ++l) {
+            In li;
+            memcpy(&li, w.in[l], sizeof(In));
+            for (int j = 0; j < KV; ++j) {
+                A[l % MN][(l / MN) * KV + j] = bf2f(li.a[j]);
+                B[(l / MN) * KV + j][l % MN] = bf2f(li.b[j]);
+            }
+        }
+        for (int l = 0; l < 64; ++l) {
+            In li;
+            memcpy(&li, w.in[l], sizeof(In));
+            VC o;
+            for (int r = 0; r < NREG; ++r) {
+                int col = l % MN;
+                int row = (MN == 16) ? (l / 16) * 4 + r : (r & 3) + 8 * (r >> 2) + 4 * (l / 32);
+                float acc = li.c[r];
+                for (int k = 0; k < G * KV; ++k) acc = fmaf(A[row][k], B[k][col], acc);
+                o[r] = acc;
+            }
+            memcpy(w.out[l], &o, sizeof(VC));
+        }
+    });
+    return out;
+}
+
+template <class T>
+inline T shfl_idx(T v, int src_lane_of_me) {
+    struct In {
+        T v;
+        int src;
+    } in{v, src_lane_of_me};
+    T out;
+    wave_collective(&in, sizeof(in), &out, sizeof(out), [](WaveState& w) {
+        for (int l = 0; l < 64; ++l) {
+            In li;
+            memcpy(&li, w.in[l], sizeof(In));
+            In ls;
+            memcpy(&ls, w.in[li.src & 63], sizeof(In));
+            memcpy(w.out[l], &ls.v, sizeof(T));
+        }
+    });
+    return out;
+}
+}  // namespace hvemu
+
+inline hv_f4 __builtin_amdgcn_mfma_f32_16x16x32_bf16(hv_s8 a, hv_s8 b, hv_f4 c, int, int, int) {
+    return hvemu::mfma<16, 8, 4>(a, b, c);
+}
+inline hv_f4 __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(hv_s4 a, hv_s4 b, hv_f4 c, int, int, int) {
+    return hvemu::mfma<16, 4, 4>(a, b, c);
+}
+inline hv_f16 __builtin_amdgcn_mfma_f32_32x32x16_bf16(hv_s8 a, hv_s8 b, hv_f16 c, int, int, int) {
+    return hvemu::mfma<32, 8, 16>(a, b, c);
+}
+template <class T>
+inline T __shfl_xor(T v, int mask) {
+    return hvemu::shfl_idx(v, hvemu::cur->lane ^ mask);
+}
+template <class T>
+inline T __shfl(T v, int lane) {
+    return hvemu::shfl_idx(v, lane);
+}
+inline float __builtin_amdgcn_exp2f(float x) { return exp2f(x); }
+inline float __builtin_amdgcn_rcpf(float x) { return 1.0f / x; }
+inline float __builtin_amdgcn_rsqf(float x) { return 1.0f / sqrtf(x); }
+inline float atomicAdd(float* p, float v) {
+    float o = *p;
+    *p = o + v;
+    return o;
+}
+
+// host runtime stand-ins used by the C-ABI wrappers
+typedef void* hipStream_t;
+typedef int hipError_t;
+#define hipSuccess 0
+inline hipError_t hipGetLastError() { return 0; }
+inline const char* hipGetErrorString(hipError_t) { return "emu"; }
+inline hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t) {
+    memset(p, v, n);
+    return 0;
+}
+inline int min(int a, int b) { return a < b ? a : b; }
+inline int max(int a, int b) { return a > b ? a : b; }

@@ -1,0 +1,314 @@
+"""Kernel-level parity cases, shared by the emulator suite (CPU, tiny shapes) and the GPU suite.
+
+Every case builds seeded bf16 inputs, runs ONE C-ABI entry point through `humanvid_amd.ops`, and
+compares with a plain PyTorch fp32 CPU computation of the reference op on the same (bf16-rounded)
+inputs.  Tolerance: the kernels accumulate in fp32 and round the result to bf16 once, so the bound
+is bf16 output rounding (2^-9 relative) plus summation-order noise: NRMSE <= 4e-3 (stated per case).
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+import torch.nn.functional as F
+
+from humanvid_amd import _abi as A
+from humanvid_amd import ops, packing
+
+BF16 = torch.bfloat16
+TOL = 4e-3
+
+
+def nrmse(a: torch.Tensor, ref: torch.Tensor) -> float:
+    a, ref = a.detach().float().cpu(), ref.detach().float().cpu()
+    return float((a - ref).norm() / (ref.norm() + 1e-12))
+
+
+def rnd(g, *shape, scale=1.0):
+    return torch.randn(*shape, generator=g) * scale
+
+
+class Ctx:
+    def __init__(self, lib, device="cpu", stream=None):
+        self.lib, self.device, self.stream = lib, device, stream
+
+    def dev(self, t, dtype=None):
+        t = t.to(dtype) if dtype is not None else t
+        return t.contiguous().to(self.device)
+
+    def bf(self, t):
+        return self.dev(t, BF16)
+
+    def sync(self):
+        if self.device != "cpu":
+            torch.cuda.synchronize()
+
+
+def r(t):  # the bf16-rounded value as fp32 (what the kernel actually sees)
+    return t.to(BF16).float()
+
+
+# ----------------------------------------------------------------------------------------- GEMM
+def case_gemm(cx: Ctx, M=200, N=320, K=320, seed=0, residual=True, out_f32=False, two_source=False, transposed=False):
+    g = torch.Generator().manual_seed(seed)
+    x, w = rnd(g, M, K), rnd(g, N, K, scale=K**-0.5)
+    bias, res = rnd(g, N, scale=0.1), rnd(g, M, N)
+    ref = r(x) @ r(w).t() + bias
+    if residual:
+        ref = ref + r(res)
+    y = torch.zeros(M, N, dtype=torch.float32 if out_f32 else BF16, device=cx.device)
+    kw = {}
+    xd = cx.bf(x)
+    if two_source:
+        k1 = (K // 2) // 64 * 64
+        x1, x2 = cx.bf(x[:, :k1]), cx.bf(x[:, k1:])
+        kw.update(x2=x2, k1=k1)
+        xd = x1
+    yt = None
+    if transposed:
+        ns = (N // 2) // 16 * 16
+        yt = torch.zeros(N - ns, M, dtype=BF16, device=cx.device)
+        kw.update(yt=yt, n_split=ns)
+    ops.gemm(cx.lib, cx.stream, xd, cx.bf(w), y, bias=cx.dev(bias), residual=cx.bf(res) if residual else None, **kw)
+    cx.sync()
+    if transposed:
+        ns = kw["n_split"]
+        e = max(nrmse(y[:, :ns], ref[:, :ns]), nrmse(yt.t(), ref[:, ns:]))
+    else:
+        e = nrmse(y, ref)
+    assert e < TOL, f"gemm nrmse {e}"
+    return e
+
+
+def case_gemm_prologue(cx: Ctx, n_img=3, rows=50, N=128, K=320, seed=1):
+    """GroupNorm-apply (+SiLU) fused on the A operand: y = silu(x*scale[img]+shift[img]) @ W^T."""
+    g = torch.Generator().manual_seed(seed)
+    M = n_img * rows
+    x, w = rnd(g, M, K), rnd(g, N, K, scale=K**-0.5)
+    sc, sh = 1 + 0.3 * rnd(g, n_img, K), 0.2 * rnd(g, n_img, K)
+    a = F.silu(r(x).view(n_img, rows, K) * sc[:, None] + sh[:, None]).view(M, K)
+    ref = r(a) @ r(w).t()  # the kernel rounds the transformed operand to bf16 before the MFMA
+    y = torch.zeros(M, N, dtype=BF16, device=cx.device)
+    ops.gemm(cx.lib, cx.stream, cx.bf(x), cx.bf(w), y, pro_scale=cx.dev(sc), pro_shift=cx.dev(sh),
+             rows_per_image=rows, pro_act=A.ACT_SILU)
+    cx.sync()
+    e = nrmse(y, ref)
+    assert e < TOL, f"gemm prologue nrmse {e}"
+    return e
+
+
+def case_gemm_lnfold(cx: Ctx, B=2, Fr=3, P=20, C=320, N=192, seed=2):
+    """LayerNorm + positional encoding folded into the projection (motion-module QKV)."""
+    g = torch.Generator().manual_seed(seed)
+    M = B * Fr * P
+    x = rnd(g, M, C) + 0.5
+    gamma, beta = 1 + 0.2 * rnd(g, C), 0.1 * rnd(g, C)
+    w, bias = rnd(g, N, C, scale=C**-0.5), rnd(g, N, scale=0.1)
+    pe = rnd(g, Fr, C, scale=0.5)
+    xr = r(x)
+    ln = F.layer_norm(xr, (C,), gamma, beta, 1e-5)
+    frame = (torch.arange(M) // P) % Fr
+    ref = (ln + pe[frame]) @ w.t() + bias
+    wf, colsum, bfold = packing.fold_layernorm(w, bias, gamma, beta)
+    pet = packing.pe_table(pe, w)
+    mean = torch.zeros(M, device=cx.device)
+    rstd = torch.zeros(M, device=cx.device)
+    xd = cx.bf(x)
+    ops.layernorm_stats(cx.lib, cx.stream, xd, mean, rstd)
+    y = torch.zeros(M, N, dtype=BF16, device=cx.device)
+    ops.gemm(cx.lib, cx.stream, xd, cx.dev(wf), y, bias=cx.dev(bfold), row_mean=mean, row_rstd=rstd,
+             colsum=cx.dev(colsum), pe=cx.dev(pet), pe_period=P, pe_frames=Fr)
+    cx.sync()
+    e_stats = nrmse(mean, xr.mean(1))
+    e = nrmse(y, ref)
+    assert e_stats < 1e-5, f"ln mean {e_stats}"
+    assert e < 6e-3, f"ln-fold nrmse {e}"  # folded weights are rounded once more than the reference's
+    return e
+
+
+def case_gemm_geglu(cx: Ctx, M=70, C=64, seed=3):
+    g = torch.Generator().manual_seed(seed)
+    x = rnd(g, M, C)
+    w, b = rnd(g, 8 * C, C, scale=C**-0.5), rnd(g, 8 * C, scale=0.1)
+    res = rnd(g, M, 4 * C)
+    h, gate = (r(x) @ r(w).t() + b).chunk(2, dim=-1)
+    ref = h * F.gelu(gate) + r(res)
+    wp, bp, _ = packing.pack_geglu(w, b)
+    y = torch.zeros(M, 4 * C, dtype=BF16, device=cx.device)
+    ops.gemm(cx.lib, cx.stream, cx.bf(x), cx.bf(wp), y, bias=cx.dev(bp), geglu=True, residual=cx.bf(res))
+    cx.sync()
+    e = nrmse(y, ref)
+    assert e < TOL, f"geglu nrmse {e}"
+    return e
+
+
+# ----------------------------------------------------------------------------------------- conv
+def case_conv(cx: Ctx, n=2, H=12, W=20, C1=32, C2=0, Cout=40, mode=A.CONV_S1, pro=True, temb=True, residual=True,
+              out_act=A.ACT_NONE, seed=4):
+    g = torch.Generator().manual_seed(seed)
+    Cin = C1 + C2
+    x = rnd(g, n, Cin, H, W)
+    w, bias = rnd(g, Cout, Cin, 3, 3, scale=(9 * Cin) ** -0.5), rnd(g, Cout, scale=0.1)
+    sc, sh = 1 + 0.3 * rnd(g, n, Cin), 0.2 * rnd(g, n, Cin)
+    a = r(x)
+    if pro:
+        a = r(F.silu(a * sc[:, :, None, None] + sh[:, :, None, None]))
+    if mode == A.CONV_UP2:
+        a = F.interpolate(a, scale_factor=2.0, mode="nearest")
+    ref = F.conv2d(a, r(w), bias, stride=2 if mode == A.CONV_S2 else 1, padding=1)
+    Ho, Wo = ref.shape[2], ref.shape[3]
+    tv = rnd(g, 1, Cout, scale=0.3)
+    if temb:
+        ref = ref + tv[:, :, None, None]
+    res = rnd(g, 1, Cout, Ho, Wo)
+    if residual:
+        ref = ref + r(res)
+    if out_act == A.ACT_SILU:
+        ref = F.silu(ref)
+    xh = x.permute(0, 2, 3, 1)
+    x1 = cx.bf(xh[..., :C1])
+    x2 = cx.bf(xh[..., C1:]) if C2 else None
+    y = torch.zeros(n, Ho, Wo, Cout, dtype=BF16, device=cx.device)
+    ops.conv3x3(cx.lib, cx.stream, x1, cx.dev(packing.pack_conv3x3(w, Cin)), y, x2=x2, mode=mode,
+                pro_scale=cx.dev(sc) if pro else None, pro_shift=cx.dev(sh) if pro else None,
+                pro_act=A.ACT_SILU if pro else A.ACT_NONE, bias=cx.dev(bias),
+                rowvec=cx.dev(tv) if temb else None, images_per_rowvec=n,
+                residual=cx.bf(res.permute(0, 2, 3, 1)) if residual else None, out_act=out_act)
+    cx.sync()
+    e = nrmse(y.permute(0, 3, 1, 2), ref)
+    assert e < TOL, f"conv mode {mode} nrmse {e}"
+    return e
+
+
+# ----------------------------------------------------------------------------------------- norms
+def case_groupnorm(cx: Ctx, n=3, H=6, W=10, C1=320, C2=0, groups=32, seed=5):
+    g = torch.Generator().manual_seed(seed)
+    C = C1 + C2
+    x = rnd(g, n, C, H, W) * (1 + torch.arange(C).view(1, C, 1, 1) % 5) + 0.7
+    gamma, beta = 1 + 0.2 * rnd(g, C), 0.1 * rnd(g, C)
+    xr = r(x)
+    ref = F.group_norm(xr, groups, gamma, beta, 1e-5)
+    xh = x.permute(0, 2, 3, 1)
+    partial = torch.zeros(n * 64 * groups * 2, device=cx.device)
+    scale, shift = torch.zeros(n, C, device=cx.device), torch.zeros(n, C, device=cx.device)
+    ops.groupnorm_affine(cx.lib, cx.stream, cx.bf(xh[..., :C1]), cx.dev(gamma), cx.dev(beta), groups, 1e-5, partial,
+                         scale, shift, x2=cx.bf(xh[..., C1:]) if C2 else None, splits=3)
+    cx.sync()
+    got = xr * scale.cpu()[:, :, None, None] + shift.cpu()[:, :, None, None]
+    e = nrmse(got, ref)
+    assert e < 1e-4, f"groupnorm nrmse {e}"
+    return e
+
+
+# ----------------------------------------------------------------------------------------- attention
+def case_attention(cx: Ctx, D=40, n_img=4, Lq=72, Lb=40, seed=6):
+    """images [0, n/2) are CFG-unconditional (own keys only); the rest append bank batch 1."""
+    g = torch.Generator().manual_seed(seed)
+    H = 8
+    Cc = H * D
+    q, k, v = rnd(g, n_img, Lq, Cc), rnd(g, n_img, Lq, Cc), rnd(g, n_img, Lq, Cc)
+    kb, vb = rnd(g, 2, Lb, Cc), rnd(g, 2, Lb, Cc)
+    sel = torch.tensor([-1] * (n_img // 2) + [1] * (n_img - n_img // 2), dtype=torch.int32)
+
+    def heads(t):
+        return r(t).view(t.shape[0], t.shape[1], H, D).transpose(1, 2)
+
+    ref = torch.zeros(n_img, Lq, Cc)
+    for i in range(n_img):
+        kk, vv = heads(k[i : i + 1]), heads(v[i : i + 1])
+        if sel[i] >= 0:
+            s = int(sel[i])
+            kk = torch.cat([kk, heads(kb[s : s + 1])], dim=2)
+            vv = torch.cat([vv, heads(vb[s : s + 1])], dim=2)
+        o = F.scaled_dot_product_attention(heads(q[i : i + 1]), kk, vv)
+        ref[i] = o.transpose(1, 2).reshape(Lq, Cc)
+    qkv = cx.bf(torch.cat([q, k], dim=-1).view(n_img * Lq, 2 * Cc))  # q | k interleaved rows, ld = 2C
+    vt = cx.bf(v.reshape(n_img * Lq, Cc).t())  # [C][n*Lq]
+    k2 = cx.bf(kb.reshape(2 * Lb, Cc))
+    vt2 = cx.bf(vb.reshape(2 * Lb, Cc).t())
+    o = torch.zeros(n_img * Lq, Cc, dtype=BF16, device=cx.device)
+    ops.attention(cx.lib, cx.stream, qkv, qkv[:, Cc:], vt, o, n_images=n_img, heads=H, D=D, Lq=Lq, L1=Lq,
+                  ldq=2 * Cc, ldk=2 * Cc, ldvt=n_img * Lq, ldo=Cc, k2=k2, vt2=vt2, ldk2=Cc, ldvt2=2 * Lb, L2=Lb,
+                  bank_sel=cx.dev(sel))
+    cx.sync()
+    e = nrmse(o.view(n_img, Lq, Cc), ref)
+    assert e < 6e-3, f"attention D={D} nrmse {e}"  # P is rounded to bf16 before P.V (as SDPA kernels do)
+    return e
+
+
+def case_temporal(cx: Ctx, D=40, B=2, Fr=5, P=6, seed=7):
+    g = torch.Generator().manual_seed(seed)
+    H = 8
+    Cc = H * D
+    qkv = rnd(g, B * Fr * P, 3 * Cc)
+    t = r(qkv).view(B, Fr, P, 3, H, D)
+    q, k, v = (t[:, :, :, i].permute(0, 2, 3, 1, 4).reshape(B * P, H, Fr, D) for i in range(3))
+    o = F.scaled_dot_product_attention(q, k, v)  # [(b p), h, f, d]
+    ref = o.view(B, P, H, Fr, D).permute(0, 3, 1, 2, 4).reshape(B * Fr * P, Cc)
+    out = torch.zeros(B * Fr * P, Cc, dtype=BF16, device=cx.device)
+    ops.temporal_attention(cx.lib, cx.stream, cx.bf(qkv), out, B=B, F=Fr, P=P, heads=H, D=D)
+    cx.sync()
+    e = nrmse(out, ref)
+    assert e < TOL, f"temporal D={D} nrmse {e}"
+    return e
+
+
+# ----------------------------------------------------------------------------------------- elementwise
+def case_elementwise(cx: Ctx, seed=8):
+    g = torch.Generator().manual_seed(seed)
+    B, Cc, Fr, H, W = 1, 4, 3, 6, 5
+    lat = rnd(g, B, Cc, Fr, H, W)
+    dst = torch.zeros(2 * B * Fr, H, W, 32, dtype=BF16, device=cx.device)
+    ops.pack_ncfhw(cx.lib, cx.stream, cx.dev(lat), dst, rep=2)
+    cx.sync()
+    want = r(lat).permute(0, 2, 3, 4, 1).reshape(B * Fr, H, W, Cc)
+    got = dst.float().cpu()
+    assert torch.equal(got[: B * Fr, ..., :Cc], want) and torch.equal(got[B * Fr :, ..., :Cc], want)
+    assert float(got[..., Cc:].abs().max()) == 0.0
+    back = torch.zeros(2 * B, Cc, Fr, H, W, device=cx.device)
+    ops.unpack_nhwc(cx.lib, cx.stream, dst, back)
+    cx.sync()
+    assert torch.equal(back.cpu()[0], r(lat)[0]) and torch.equal(back.cpu()[1], r(lat)[0])
+
+    src = rnd(g, 1, 6, 2, 16, 8)
+    un = torch.zeros(2, 2, 1, 6 * 64, dtype=BF16, device=cx.device)
+    ops.pixel_unshuffle(cx.lib, cx.stream, cx.dev(src), un, 8)
+    cx.sync()
+    ref = F.pixel_unshuffle(src.permute(0, 2, 1, 3, 4).reshape(2, 6, 16, 8), 8).permute(0, 2, 3, 1)
+    assert torch.equal(un.float().cpu(), r(ref))
+
+    t = torch.tensor([601.0, 32.0])
+    te = torch.zeros(2, 320, dtype=BF16, device=cx.device)
+    ops.timestep_embedding(cx.lib, cx.stream, cx.dev(t), te)
+    cx.sync()
+    half = 160
+    freq = torch.exp(-math.log(10000.0) * torch.arange(half) / half)
+    ang = t[:, None] * freq[None]
+    ref = torch.cat([torch.cos(ang), torch.sin(ang)], dim=-1)
+    assert float((te.float().cpu() - ref).abs().max()) < 1e-2  # bf16 output, fp32 range reduction
+
+    # window accumulation + CFG + DDIM
+    pred = rnd(g, 2 * 2, H, W, 4)  # rep=2, f_win=2
+    frames = torch.tensor([2, 0], dtype=torch.int32)
+    acc = torch.zeros(2, Cc, Fr, H, W, device=cx.device)
+    cnt = torch.zeros(Fr, device=cx.device)
+    ops.accumulate_window(cx.lib, cx.stream, cx.bf(pred), 2, Cc, cx.dev(frames), acc, cnt)
+    ops.accumulate_window(cx.lib, cx.stream, cx.bf(pred), 2, Cc, cx.dev(torch.tensor([1, 2], dtype=torch.int32)), acc, cnt)
+    cx.sync()
+    pr = r(pred).view(2, 2, H, W, 4).permute(0, 4, 1, 2, 3)  # [rep][c][fw][h][w]
+    racc = torch.zeros(2, Cc, Fr, H, W)
+    racc[:, :, [2, 0]] += pr
+    racc[:, :, [1, 2]] += pr
+    assert torch.allclose(acc.cpu(), racc) and cnt.cpu().tolist() == [1.0, 1.0, 2.0]
+    latd = cx.dev(lat.clone())
+    sa, s1a, sap, s1ap, gs = 0.6, 0.8, 0.8, 0.6, 3.5
+    ops.cfg_ddim_step(cx.lib, cx.stream, latd, acc, cnt, 2, gs, sa, s1a, sap, s1ap)
+    cx.sync()
+    nz = racc / torch.tensor([1.0, 1.0, 2.0]).view(1, 1, Fr, 1, 1)
+    v = nz[0] + gs * (nz[1] - nz[0])
+    x0 = sa * lat[0] - s1a * v
+    eps = sa * v + s1a * lat[0]
+    ref = sap * x0 + s1ap * eps
+    assert torch.allclose(latd.cpu()[0], ref, atol=1e-5)
+    assert float(acc.abs().max()) == 0.0 and float(cnt.abs().max()) == 0.0
+    return 0.0

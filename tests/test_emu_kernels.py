@@ -1,0 +1,76 @@
+"""Kernel index-logic checks on the host emulator (tests/emu/hv_emu.h) -- runs without a GPU.
+
+The same kernel sources that hipcc compiles for gfx950 are compiled for the host with MFMA /
+LDS / barrier semantics emulated; tiny shapes only.  This is development infrastructure: the
+product never loads the emulated library (see tests/test_product_guard.py).
+"""
+import os
+import sys
+
+import pytest
+import torch
+
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), "emu"))
+import build_emu  # noqa: E402
+
+import kernel_cases as kc  # noqa: E402
+from humanvid_amd import _abi as A  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def cx():
+    lib = A.HvLibrary(build_emu.build())
+    return kc.Ctx(lib, "cpu", None)
+
+
+def test_gemm_plain(cx):
+    kc.case_gemm(cx, M=200, N=320, K=320)
+
+
+def test_gemm_variants(cx):
+    kc.case_gemm(cx, M=130, N=132, K=128, residual=False, out_f32=True)
+    kc.case_gemm(cx, M=64, N=160, K=256, two_source=True)
+    kc.case_gemm(cx, M=96, N=96, K=64, transposed=True)
+
+
+def test_gemm_prologue(cx):
+    kc.case_gemm_prologue(cx)
+
+
+def test_gemm_lnfold(cx):
+    kc.case_gemm_lnfold(cx)
+
+
+def test_gemm_geglu(cx):
+    kc.case_gemm_geglu(cx)
+
+
+@pytest.mark.parametrize("mode", [A.CONV_S1, A.CONV_S2, A.CONV_UP2])
+def test_conv_modes(cx, mode):
+    kc.case_conv(cx, mode=mode)
+
+
+def test_conv_two_source_narrow(cx):
+    kc.case_conv(cx, n=1, H=12, W=8, C1=32, C2=32, Cout=36, pro=True)
+    kc.case_conv(cx, n=1, H=6, W=4, C1=32, Cout=8, mode=A.CONV_UP2, pro=False, temb=False, residual=False,
+                 out_act=A.ACT_SILU)
+
+
+def test_groupnorm(cx):
+    kc.case_groupnorm(cx)
+    kc.case_groupnorm(cx, n=2, H=4, W=4, C1=1280, C2=640, seed=9)  # groups straddle the concat seam
+    kc.case_groupnorm(cx, n=1, H=3, W=3, C1=2560, seed=10)
+
+
+@pytest.mark.parametrize("D", [40, 80, 160])
+def test_attention(cx, D):
+    kc.case_attention(cx, D=D, n_img=2, Lq=72 if D == 40 else 40, Lb=40 if D == 40 else 72)
+
+
+@pytest.mark.parametrize("D", [40, 80, 160])
+def test_temporal(cx, D):
+    kc.case_temporal(cx, D=D, Fr=5 if D != 80 else 12)
+
+
+def test_elementwise(cx):
+    kc.case_elementwise(cx)

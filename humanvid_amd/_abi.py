@@ -48,7 +48,7 @@ class Conv3x3Params(_S):
         ("n_images", I), ("Hs", I), ("Ws", I), ("Ho", I), ("Wo", I), ("Cout", I),
         ("mode", I),
         ("pro_scale", P), ("pro_shift", P), ("pro_act", I),
-        ("bias", P), ("rowvec", P), ("images_per_rowvec", I),
+        ("bias", P), ("rowvec", P), ("images_per_rowvec", I), ("rowvec_ld", L),
         ("residual", P), ("residual_images", I), ("out_act", I),
     ]
 
@@ -74,8 +74,10 @@ class AttentionParams(_S):
 
 class TemporalAttentionParams(_S):
     _fields_ = [
-        ("QKV", P), ("ld", L), ("O", P), ("ldo", L),
-        ("B", I), ("F", I), ("P", I), ("heads", I), ("D", I), ("scale", F),
+        ("Q", P), ("ldq", L), ("K", P), ("V", P), ("ldkv", L),
+        ("kv_stride_b", L), ("kv_stride_chunk", L), ("kv_chunk", I),
+        ("O", P), ("ldo", L),
+        ("B", I), ("Fq", I), ("Fkv", I), ("P", I), ("heads", I), ("D", I), ("scale", F),
     ]
 
 
@@ -91,13 +93,14 @@ PROTOTYPES = {
     "hv_groupnorm_affine": (I, [C.POINTER(GroupNormParams), P]),
     "hv_layernorm_stats": (I, [P, L, I, I, F, P, P, P]),
     "hv_attention": (I, [C.POINTER(AttentionParams), P]),
+    "hv_set_tuning": (I, [I, I]),
     "hv_temporal_attention": (I, [C.POINTER(TemporalAttentionParams), P]),
     "hv_pack_ncfhw": (I, [P, I, I, I, I, I, I, I, P, I, P]),
     "hv_unpack_nhwc": (I, [P, I, I, I, I, I, I, P, I, P]),
     "hv_pixel_unshuffle": (I, [P, I, I, I, I, I, I, P, P]),
     "hv_timestep_embedding": (I, [P, I, I, P, P]),
     "hv_accumulate_window": (I, [P, I, I, I, I, I, I, P, I, P, P, P]),
-    "hv_cfg_ddim_step": (I, [P, P, P, I, I, I, I, I, F, F, F, F, F, P]),
+    "hv_cfg_ddim_step": (I, [P, P, P, I, I, I, I, I, P, P]),
     "hv_graph_begin": (I, [P]),
     "hv_graph_end": (I, [P, C.POINTER(P)]),
     "hv_graph_launch": (I, [P, P]),

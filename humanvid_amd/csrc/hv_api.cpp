@@ -75,8 +75,15 @@ int hv_attention(const hv_attention_params* p, void* stream) {
     return hv_check_launch("hv_attention");
 }
 
+int hv_set_tuning(int key, int value) {
+    if (key == HV_TUNE_ATTN_QT_D40 && (value == 2 || value == 4)) hvk_attention_tune(40, value);
+    else if (key == HV_TUNE_ATTN_QT_D160 && (value == 1 || value == 2)) hvk_attention_tune(160, value);
+    else return hv_fail(HV_EINVAL, "hv_set_tuning: unknown key/value");
+    return HV_OK;
+}
+
 int hv_temporal_attention(const hv_temporal_attention_params* p, void* stream) {
-    if (!p || !p->QKV || !p->O) return hv_fail(HV_EINVAL, "hv_temporal_attention: null operand");
+    if (!p || !p->Q || !p->K || !p->V || !p->O) return hv_fail(HV_EINVAL, "hv_temporal_attention: null operand");
     int rc = hvk_temporal(*p, (hipStream_t)stream);
     if (rc == -2) return hv_fail(HV_ENOTSUP, "hv_temporal_attention: head dim must be 40, 80 or 160, F <= 32");
     if (rc != 0) return hv_fail(HV_EINVAL, "hv_temporal_attention: bad sizes");
@@ -117,10 +124,10 @@ int hv_accumulate_window(const uint16_t* pred, int ldc, int rep, int C, int f_wi
 }
 
 int hv_cfg_ddim_step(float* latents, float* acc, float* counter, int rep, int C, int F, int H, int W,
-                     float guidance, float sqrt_a, float sqrt_1ma, float sqrt_ap, float sqrt_1map, void* stream) {
-    if (!latents || !acc || !counter || (rep != 1 && rep != 2)) return hv_fail(HV_EINVAL, "hv_cfg_ddim_step: bad args");
-    hvk_cfg_ddim(latents, acc, counter, rep, C, F, H, W, guidance, sqrt_a, sqrt_1ma, sqrt_ap, sqrt_1map,
-                       (hipStream_t)stream);
+                     const float* coeffs, void* stream) {
+    if (!latents || !acc || !counter || !coeffs || (rep != 1 && rep != 2))
+        return hv_fail(HV_EINVAL, "hv_cfg_ddim_step: bad args");
+    hvk_cfg_ddim(latents, acc, counter, rep, C, F, H, W, coeffs, (hipStream_t)stream);
     return hv_check_launch("hv_cfg_ddim_step");
 }
 

@@ -267,14 +267,23 @@ static inline void hv_attention_launch_t(const hv_attention_params& p, hipStream
     hv_launch(hv_attention_kernel<D, QT>, dim3(grid), dim3(256), stream, p);
 }
 
+// tuning knobs (hv_set_tuning): queries-per-wave fragment count per head dim
+static int g_hv_attn_qt40 = 4, g_hv_attn_qt160 = 2;
+
 static inline int hv_attention_launch(const hv_attention_params& p, hipStream_t stream) {
     if (p.L1 <= 0 || p.L1 % 8 != 0 || p.L2 % 8 != 0 || p.Lq <= 0) return -1;
     if (p.ldq % 8 || p.ldk % 8 || p.ldvt % 8 || p.ldo % 4) return -1;
     if (p.L2 > 0 && p.bank_sel != nullptr && (!p.K2 || !p.Vt2 || p.ldk2 % 8 || p.ldvt2 % 8)) return -1;
     switch (p.D) {
-        case 40: hv_attention_launch_t<40, 4>(p, stream); break;
+        case 40:
+            if (g_hv_attn_qt40 == 2) hv_attention_launch_t<40, 2>(p, stream);
+            else hv_attention_launch_t<40, 4>(p, stream);
+            break;
         case 80: hv_attention_launch_t<80, 2>(p, stream); break;
-        case 160: hv_attention_launch_t<160, 2>(p, stream); break;
+        case 160:
+            if (g_hv_attn_qt160 == 1) hv_attention_launch_t<160, 1>(p, stream);
+            else hv_attention_launch_t<160, 2>(p, stream);
+            break;
         default: return -2;
     }
     return 0;

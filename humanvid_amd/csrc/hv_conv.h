@@ -199,7 +199,7 @@ __global__ __launch_bounds__(256) void hv_conv3x3_kernel(hv_conv3x3_params p) {
     }
 
     // ---- epilogue
-    const float* rv = p.rowvec ? p.rowvec + (long)(img / p.images_per_rowvec) * p.Cout : nullptr;
+    const float* rv = p.rowvec ? p.rowvec + (long)(img / p.images_per_rowvec) * p.rowvec_ld : nullptr;
     const int rimg = p.residual ? (p.residual_images > 0 ? img % p.residual_images : img) : 0;
 #pragma unroll
     for (int mf = 0; mf < 4; ++mf) {

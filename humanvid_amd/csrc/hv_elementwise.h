@@ -121,8 +121,9 @@ __global__ __launch_bounds__(256) void hv_accumulate_kernel(const bf16_t* pred, 
 // (pipeline_pose2vid_long.py:555-563; diffusers DDIMScheduler.step).
 // Also clears the accumulators for the next step.
 __global__ __launch_bounds__(256) void hv_cfg_ddim_kernel(float* latents, float* acc, float* counter, int rep, int C,
-                                                          int F, int H, int W, float guidance, float sqrt_a,
-                                                          float sqrt_1ma, float sqrt_ap, float sqrt_1map) {
+                                                          int F, int H, int W, const float* coeffs) {
+    const float guidance = coeffs[0], sqrt_a = coeffs[1], sqrt_1ma = coeffs[2], sqrt_ap = coeffs[3],
+                sqrt_1map = coeffs[4];
     const long per = (long)C * F * H * W;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < per; i += (long)gridDim.x * blockDim.x) {
         const int f = (int)((i / ((long)H * W)) % F);
@@ -174,8 +175,8 @@ static inline void hv_accumulate_launch(const bf16_t* pred, int ldc, int rep, in
               f_win, H, W, frames, F, acc, counter);
 }
 static inline void hv_cfg_ddim_launch(float* latents, float* acc, float* counter, int rep, int C, int F, int H, int W,
-                                      float guidance, float sa, float s1a, float sap, float s1ap, hipStream_t s) {
+                                      const float* coeffs, hipStream_t s) {
     hv_launch(hv_cfg_ddim_kernel, dim3(hv_ew_grid((long)C * F * H * W)), dim3(256), s, latents, acc, counter, rep, C, F,
-              H, W, guidance, sa, s1a, sap, s1ap);
+              H, W, coeffs);
     hv_launch(hv_clear_kernel, dim3((F + 255) / 256), dim3(256), s, counter, F);
 }

@@ -9,6 +9,7 @@ int hvk_conv3x3(const hv_conv3x3_params& p, hipStream_t s);
 int hvk_groupnorm(const hv_groupnorm_params& p, hipStream_t s);
 void hvk_layernorm(const bf16_t* X, long ldx, int M, int C, float eps, float* mean, float* rstd, hipStream_t s);
 int hvk_attention(const hv_attention_params& p, hipStream_t s);
+void hvk_attention_tune(int head_dim, int qt);
 int hvk_temporal(const hv_temporal_attention_params& p, hipStream_t s);
 void hvk_pack(const void* src, int src_bf16, int B, int C, int F, int H, int W, int rep, bf16_t* dst, int Cpad,
               hipStream_t s);
@@ -17,8 +18,8 @@ void hvk_unshuffle(const float* src, int B, int C, int F, int H, int W, int r, b
 void hvk_timestep(const float* t, int B, int dim, bf16_t* dst, hipStream_t s);
 void hvk_accumulate(const bf16_t* pred, int ldc, int rep, int C, int f_win, int H, int W, const int* frames, int F,
                     float* acc, float* counter, hipStream_t s);
-void hvk_cfg_ddim(float* latents, float* acc, float* counter, int rep, int C, int F, int H, int W, float guidance,
-                  float sa, float s1a, float sap, float s1ap, hipStream_t s);
+void hvk_cfg_ddim(float* latents, float* acc, float* counter, int rep, int C, int F, int H, int W,
+                  const float* coeffs, hipStream_t s);
 
 #ifdef HV_SINGLE_TU
 #include "k_gemm.hip"

@@ -24,22 +24,23 @@ __global__ __launch_bounds__(256) void hv_temporal_kernel(hv_temporal_attention_
     __shared__ __attribute__((aligned(16))) bf16_t Ksm[FMAX * C];
     __shared__ __attribute__((aligned(16))) bf16_t Vsm[FMAX * C];
     const int tid = threadIdx.x, nthr = blockDim.x;
-    const int F = p.F;
+    const int F = p.Fkv, FQ = p.Fq;
     const int b = blockIdx.x / p.P, pix = blockIdx.x % p.P;
-    const long row0 = ((long)b * F) * p.P + pix;  // row of frame f: row0 + f * P
+    const long row0 = ((long)b * FQ) * p.P + pix;  // query / output row of local frame f: row0 + f * P
 
     const int cv = C / 8;
     for (int i = tid; i < F * cv; i += nthr) {
         const int f = i / cv, c = i % cv;
-        const bf16_t* src = p.QKV + (row0 + (long)f * p.P) * p.ld + C + c * 8;
-        hv_st16(Ksm + f * C + c * 8, hv_ld16(src));
-        hv_st16(Vsm + f * C + c * 8, hv_ld16(src + C));
+        const long kvrow = (long)b * p.kv_stride_b + (long)(f / p.kv_chunk) * p.kv_stride_chunk +
+                           (long)(f % p.kv_chunk) * p.P + pix;
+        hv_st16(Ksm + f * C + c * 8, hv_ld16(p.K + kvrow * p.ldkv + c * 8));
+        hv_st16(Vsm + f * C + c * 8, hv_ld16(p.V + kvrow * p.ldkv + c * 8));
     }
     __syncthreads();
 
-    const int h = tid / F, fq = tid % F;
+    const int h = tid / FQ, fq = tid % FQ;
     if (h >= HEADS) return;
-    const bf16_t* qrow = p.QKV + (row0 + (long)fq * p.P) * p.ld + h * D;
+    const bf16_t* qrow = p.Q + (row0 + (long)fq * p.P) * p.ldq + h * D;
 
     float s[FMAX];
 #pragma unroll
@@ -93,15 +94,15 @@ __global__ __launch_bounds__(256) void hv_temporal_kernel(hv_temporal_attention_
 
 template <int D>
 static inline int hv_temporal_launch_d(const hv_temporal_attention_params& p, hipStream_t stream) {
-    const int threads = ((8 * p.F + 63) / 64) * 64;
+    const int threads = ((8 * p.Fq + 63) / 64) * 64;
     const dim3 grid(p.B * p.P), block(threads);
-    if (p.F <= 8)
+    if (p.Fkv <= 8)
         hv_launch(hv_temporal_kernel<D, 8>, grid, block, stream, p);
-    else if (p.F <= 16)
+    else if (p.Fkv <= 16)
         hv_launch(hv_temporal_kernel<D, 16>, grid, block, stream, p);
-    else if (p.F <= 24)
+    else if (p.Fkv <= 24)
         hv_launch(hv_temporal_kernel<D, 24>, grid, block, stream, p);
-    else if (p.F <= 32)
+    else if (p.Fkv <= 32)
         hv_launch(hv_temporal_kernel<D, 32>, grid, block, stream, p);
     else
         return -2;
@@ -109,8 +110,9 @@ static inline int hv_temporal_launch_d(const hv_temporal_attention_params& p, hi
 }
 
 static inline int hv_temporal_launch(const hv_temporal_attention_params& p, hipStream_t stream) {
-    if (p.heads != 8 || p.B <= 0 || p.F <= 0 || p.P <= 0) return p.heads != 8 ? -2 : -1;
-    if (p.ld % 8 || p.ldo % 8) return -1;
+    if (p.heads != 8 || p.B <= 0 || p.Fkv <= 0 || p.Fq <= 0 || p.Fq > p.Fkv || p.P <= 0 || p.kv_chunk <= 0)
+        return p.heads != 8 ? -2 : -1;
+    if (p.ldq % 8 || p.ldkv % 8 || p.ldo % 8) return -1;
     switch (p.D) {
         case 40: return hv_temporal_launch_d<40>(p, stream);
         case 80: return hv_temporal_launch_d<80>(p, stream);

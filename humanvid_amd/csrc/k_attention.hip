@@ -3,3 +3,7 @@
 #include "hv_kernels.h"
 
 int hvk_attention(const hv_attention_params& p, hipStream_t s) { return hv_attention_launch(p, s); }
+void hvk_attention_tune(int head_dim, int qt) {
+    if (head_dim == 40) g_hv_attn_qt40 = qt;
+    if (head_dim == 160) g_hv_attn_qt160 = qt;
+}

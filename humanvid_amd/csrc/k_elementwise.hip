@@ -17,7 +17,7 @@ void hvk_accumulate(const bf16_t* pred, int ldc, int rep, int C, int f_win, int 
                     float* acc, float* counter, hipStream_t s) {
     hv_accumulate_launch(pred, ldc, rep, C, f_win, H, W, frames, F, acc, counter, s);
 }
-void hvk_cfg_ddim(float* latents, float* acc, float* counter, int rep, int C, int F, int H, int W, float guidance,
-                  float sa, float s1a, float sap, float s1ap, hipStream_t s) {
-    hv_cfg_ddim_launch(latents, acc, counter, rep, C, F, H, W, guidance, sa, s1a, sap, s1ap, s);
+void hvk_cfg_ddim(float* latents, float* acc, float* counter, int rep, int C, int F, int H, int W,
+                  const float* coeffs, hipStream_t s) {
+    hv_cfg_ddim_launch(latents, acc, counter, rep, C, F, H, W, coeffs, s);
 }

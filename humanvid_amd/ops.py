@@ -49,7 +49,7 @@ def gemm(lib, stream, x, w, y, *, x2=None, k1=0, yt=None, n_split=0, pro_scale=N
 
 
 def conv3x3(lib, stream, x, w, y, *, x2=None, mode=A.CONV_S1, pro_scale=None, pro_shift=None, pro_act=A.ACT_NONE,
-            bias=None, rowvec=None, images_per_rowvec=1, residual=None, out_act=A.ACT_NONE):
+            bias=None, rowvec=None, images_per_rowvec=1, rowvec_ld=None, residual=None, out_act=A.ACT_NONE):
     """x [n,Hs,Ws,C1] (+x2 [n,Hs,Ws,C2]); w packed [Cout, 9, C1+C2]; y [n,Ho,Wo,Cout]."""
     n, Hs, Ws, C1 = x.shape
     _, Ho, Wo, Cout = y.shape
@@ -57,7 +57,8 @@ def conv3x3(lib, stream, x, w, y, *, x2=None, mode=A.CONV_S1, pro_scale=None, pr
         X=_p(x), C1=C1, X2=_p(x2), C2=0 if x2 is None else x2.shape[3], W=_p(w), Y=_p(y),
         n_images=n, Hs=Hs, Ws=Ws, Ho=Ho, Wo=Wo, Cout=Cout, mode=mode,
         pro_scale=_p(pro_scale), pro_shift=_p(pro_shift), pro_act=pro_act, bias=_p(bias),
-        rowvec=_p(rowvec), images_per_rowvec=images_per_rowvec, residual=_p(residual),
+        rowvec=_p(rowvec), images_per_rowvec=images_per_rowvec,
+        rowvec_ld=(Cout if rowvec_ld is None else rowvec_ld), residual=_p(residual),
         residual_images=0 if residual is None else residual.shape[0], out_act=out_act,
     )
     lib.call("hv_conv3x3", C.byref(p), stream)
@@ -92,10 +93,28 @@ def attention(lib, stream, q, k, vt, o, *, n_images, heads, D, Lq, L1, ldq, ldk,
     lib.call("hv_attention", C.byref(p), stream)
 
 
-def temporal_attention(lib, stream, qkv, o, *, B, F, P, heads, D, ld=None, ldo=None):
+def temporal_attention(lib, stream, qkv, o, *, B, F, P, heads, D):
+    """Single-device form: qkv [(B F P), 3C] rows (b*F + f)*P + p with columns [q | k | v]."""
+    Cc = heads * D
+    ld = qkv.stride(0)
+    eb = qkv.element_size()
     p = A.TemporalAttentionParams(
-        QKV=_p(qkv), ld=qkv.stride(0) if ld is None else ld, O=_p(o), ldo=o.stride(0) if ldo is None else ldo,
-        B=B, F=F, P=P, heads=heads, D=D, scale=1.0 / math.sqrt(D),
+        Q=qkv.data_ptr(), ldq=ld, K=qkv.data_ptr() + Cc * eb, V=qkv.data_ptr() + 2 * Cc * eb, ldkv=ld,
+        kv_stride_b=F * P, kv_stride_chunk=0, kv_chunk=F, O=_p(o), ldo=o.stride(0),
+        B=B, Fq=F, Fkv=F, P=P, heads=heads, D=D, scale=1.0 / math.sqrt(D),
+    )
+    lib.call("hv_temporal_attention", C.byref(p), stream)
+
+
+def temporal_attention_sharded(lib, stream, q, kv_gathered, o, *, B, Fq, ranks, P, heads, D):
+    """Frame-sharded form: q [(B Fq P), C] local query frames; kv_gathered [ranks, B, Fq, P, 2C]
+    (all-gathered [k | v] of every rank's frames); o like q."""
+    Cc = heads * D
+    eb = q.element_size()
+    p = A.TemporalAttentionParams(
+        Q=q.data_ptr(), ldq=q.stride(0), K=kv_gathered.data_ptr(), V=kv_gathered.data_ptr() + Cc * eb, ldkv=2 * Cc,
+        kv_stride_b=Fq * P, kv_stride_chunk=B * Fq * P, kv_chunk=Fq, O=_p(o), ldo=o.stride(0),
+        B=B, Fq=Fq, Fkv=Fq * ranks, P=P, heads=heads, D=D, scale=1.0 / math.sqrt(D),
     )
     lib.call("hv_temporal_attention", C.byref(p), stream)
 
@@ -129,7 +148,8 @@ def accumulate_window(lib, stream, pred, rep, Cc, frames, acc, counter):
              acc.data_ptr(), counter.data_ptr(), stream)
 
 
-def cfg_ddim_step(lib, stream, latents, acc, counter, rep, guidance, sqrt_a, sqrt_1ma, sqrt_ap, sqrt_1map):
+def cfg_ddim_step(lib, stream, latents, acc, counter, rep, coeffs):
+    """coeffs: device fp32 [5] = {guidance, sqrt(a_t), sqrt(1-a_t), sqrt(a_prev), sqrt(1-a_prev)}."""
     _, Cc, Fr, H, W = latents.shape
     lib.call("hv_cfg_ddim_step", latents.data_ptr(), acc.data_ptr(), counter.data_ptr(), rep, Cc, Fr, H, W,
-             guidance, sqrt_a, sqrt_1ma, sqrt_ap, sqrt_1map, stream)
+             coeffs.data_ptr(), stream)

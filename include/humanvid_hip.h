@@ -98,8 +98,9 @@ typedef struct hv_conv3x3_params {
     const float* pro_shift;
     int pro_act;
     const float* bias;
-    const float* rowvec; /* [n/images_per_rowvec][Cout] (time embedding) */
+    const float* rowvec; /* time embedding: row (n/images_per_rowvec), stride rowvec_ld floats */
     int images_per_rowvec;
+    long rowvec_ld;
     const uint16_t* residual; /* [residual_images][Ho][Wo][Cout], image index taken modulo */
     int residual_images;
     int out_act;
@@ -156,16 +157,28 @@ typedef struct hv_attention_params {
 } hv_attention_params;
 int hv_attention(const hv_attention_params* p, void* stream);
 
+/* kernel-variant selection for A/B measurements (process-global; not needed for correctness) */
+#define HV_TUNE_ATTN_QT_D40 0  /* query fragments per wave for head dim 40: 2 or 4 (default 4) */
+#define HV_TUNE_ATTN_QT_D160 1 /* for head dim 160: 1 or 2 (default 2) */
+int hv_set_tuning(int key, int value);
+
 /* ---- temporal self-attention over the frame axis ------------------------------------------
  * VersatileAttention (src/models/motion_module.py:351-388) and the camera encoder's
  * TemporalSelfAttention (src/cameractrl/motion_module.py:323-388): for every (batch, pixel, head)
- * attention across F frames; rows of QKV are (b*F + f)*P + p, columns [q | k | v] of width C.   */
+ * attention of the Fq local query frames over all Fkv frames (Fq < Fkv when the clip is sharded
+ * along the frame axis across GPUs and K/V were all-gathered).                                   */
 typedef struct hv_temporal_attention_params {
-    const uint16_t* QKV;
-    long ld;
-    uint16_t* O;
+    const uint16_t* Q; /* row (b*Fq + fq)*P + p, head h at column h*D */
+    long ldq;
+    const uint16_t* K; /* row b*kv_stride_b + (f / kv_chunk)*kv_stride_chunk + (f % kv_chunk)*P + p */
+    const uint16_t* V;
+    long ldkv;
+    long kv_stride_b;     /* in rows */
+    long kv_stride_chunk; /* in rows; frame-sharded runs gather K/V as [rank][b][F/ranks][P] */
+    int kv_chunk;
+    uint16_t* O; /* same row order as Q */
     long ldo;
-    int B, F, P, heads, D;
+    int B, Fq, Fkv, P, heads, D;
     float scale;
 } hv_temporal_attention_params;
 int hv_temporal_attention(const hv_temporal_attention_params* p, void* stream);
@@ -187,8 +200,10 @@ int hv_timestep_embedding(const float* t, int B, int dim, uint16_t* dst, void* s
  * pred: [(rep f_win)][h][w][ldc] bf16 (conv_out output); acc: fp32 [rep][C][F][h][w]; counter [F]. */
 int hv_accumulate_window(const uint16_t* pred, int ldc, int rep, int C, int f_win, int H, int W, const int* frames,
                          int F, float* acc, float* counter, void* stream);
+/* coeffs: DEVICE pointer to {guidance, sqrt(a_t), sqrt(1-a_t), sqrt(a_prev), sqrt(1-a_prev)} so that
+ * a captured step graph can be replayed for every timestep */
 int hv_cfg_ddim_step(float* latents, float* acc, float* counter, int rep, int C, int F, int H, int W,
-                     float guidance, float sqrt_a, float sqrt_1ma, float sqrt_ap, float sqrt_1map, void* stream);
+                     const float* coeffs, void* stream);
 
 /* ---- HIP graph capture of a launch sequence (one denoising step) ---------------------------- */
 int hv_graph_begin(void* stream);

@@ -250,6 +250,20 @@ def case_temporal(cx: Ctx, D=40, B=2, Fr=5, P=6, seed=7):
     cx.sync()
     e = nrmse(out, ref)
     assert e < TOL, f"temporal D={D} nrmse {e}"
+    # frame-sharded form: 'ranks' shards of Fq frames each query against the gathered K/V
+    if Fr % 2 == 0:
+        ranks, Fq = 2, Fr // 2
+        t5 = qkv.view(B, Fr, P, 3 * Cc)
+        kvg = torch.stack([t5[:, rk * Fq:(rk + 1) * Fq, :, Cc:] for rk in range(ranks)]).contiguous()  # [R,B,Fq,P,2C]
+        for rk in range(ranks):
+            ql = cx.bf(t5[:, rk * Fq:(rk + 1) * Fq, :, :Cc].reshape(B * Fq * P, Cc))
+            ol = torch.zeros(B * Fq * P, Cc, dtype=BF16, device=cx.device)
+            ops.temporal_attention_sharded(cx.lib, cx.stream, ql, cx.bf(kvg), ol, B=B, Fq=Fq, ranks=ranks, P=P,
+                                           heads=H, D=D)
+            cx.sync()
+            want = ref.view(B, Fr, P, Cc)[:, rk * Fq:(rk + 1) * Fq].reshape(B * Fq * P, Cc)
+            e2 = nrmse(ol, want)
+            assert e2 < TOL, f"temporal sharded rank {rk} nrmse {e2}"
     return e
 
 
@@ -302,7 +316,7 @@ def case_elementwise(cx: Ctx, seed=8):
     assert torch.allclose(acc.cpu(), racc) and cnt.cpu().tolist() == [1.0, 1.0, 2.0]
     latd = cx.dev(lat.clone())
     sa, s1a, sap, s1ap, gs = 0.6, 0.8, 0.8, 0.6, 3.5
-    ops.cfg_ddim_step(cx.lib, cx.stream, latd, acc, cnt, 2, gs, sa, s1a, sap, s1ap)
+    ops.cfg_ddim_step(cx.lib, cx.stream, latd, acc, cnt, 2, cx.dev(torch.tensor([gs, sa, s1a, sap, s1ap])))
     cx.sync()
     nz = racc / torch.tensor([1.0, 1.0, 2.0]).view(1, 1, Fr, 1, 1)
     v = nz[0] + gs * (nz[1] - nz[0])

@@ -1,0 +1,84 @@
+"""Kernel parity on a real MI355X through the C ABI (libhumanvid_hip.so), larger shapes than the
+emulator suite, including the config-#3 geometry of each kernel family."""
+import pytest
+import torch
+
+import kernel_cases as kc
+from humanvid_amd import _abi as A
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def cx():
+    from humanvid_amd import lib
+
+    lib.require_gpu()
+    return kc.Ctx(lib.load(), "cuda", lib.current_stream())
+
+
+def test_gemm(cx):
+    kc.case_gemm(cx, M=3000, N=960, K=320)
+    kc.case_gemm(cx, M=777, N=1284, K=1280, residual=False, out_f32=True)
+    kc.case_gemm(cx, M=1024, N=640, K=1920, two_source=True)
+    kc.case_gemm(cx, M=1536, N=1920, K=640, transposed=True)
+
+
+def test_gemm_fused(cx):
+    kc.case_gemm_prologue(cx, n_img=6, rows=384, N=1280, K=1280)
+    kc.case_gemm_lnfold(cx, B=2, Fr=24, P=96, C=1280, N=3840)
+    kc.case_gemm_geglu(cx, M=4096, C=320)
+
+
+@pytest.mark.parametrize("mode", [A.CONV_S1, A.CONV_S2, A.CONV_UP2])
+def test_conv(cx, mode):
+    kc.case_conv(cx, n=4, H=48, W=32, C1=320, Cout=320, mode=mode)
+
+
+def test_conv_shapes(cx):
+    kc.case_conv(cx, n=3, H=24, W=16, C1=1280, C2=640, Cout=1280)
+    kc.case_conv(cx, n=6, H=12, W=8, C1=1280, Cout=1280)
+    kc.case_conv(cx, n=2, H=96, W=64, C1=320, Cout=4, temb=False, residual=False)
+    kc.case_conv(cx, n=2, H=64, W=48, C1=32, Cout=16, pro=False, temb=False, residual=False, out_act=A.ACT_SILU)
+
+
+def test_groupnorm(cx):
+    kc.case_groupnorm(cx, n=4, H=96, W=64, C1=320)
+    kc.case_groupnorm(cx, n=4, H=24, W=16, C1=1280, C2=640)
+    kc.case_groupnorm(cx, n=3, H=12, W=8, C1=2560)
+
+
+@pytest.mark.parametrize("D,Lq,Lb", [(40, 1536, 1536), (40, 200, 72), (80, 384, 384), (160, 96, 96), (160, 384, 96)])
+def test_attention(cx, D, Lq, Lb):
+    kc.case_attention(cx, D=D, n_img=4, Lq=Lq, Lb=Lb)
+
+
+def test_attention_variants(cx):
+    cx.lib.call("hv_set_tuning", 0, 2)
+    kc.case_attention(cx, D=40, n_img=4, Lq=520, Lb=264)
+    cx.lib.call("hv_set_tuning", 0, 4)
+    cx.lib.call("hv_set_tuning", 1, 1)
+    kc.case_attention(cx, D=160, n_img=4, Lq=96, Lb=96)
+    cx.lib.call("hv_set_tuning", 1, 2)
+
+
+@pytest.mark.parametrize("D,Fr,P", [(40, 24, 384), (80, 16, 96), (160, 24, 24), (40, 8, 64)])
+def test_temporal(cx, D, Fr, P):
+    kc.case_temporal(cx, D=D, B=2, Fr=Fr, P=P)
+
+
+def test_elementwise(cx):
+    kc.case_elementwise(cx)
+
+
+def test_errors_are_python_exceptions(cx):
+    x = torch.zeros(8, 100, dtype=torch.bfloat16, device="cuda")
+    w = torch.zeros(16, 100, dtype=torch.bfloat16, device="cuda")
+    y = torch.zeros(8, 16, dtype=torch.bfloat16, device="cuda")
+    from humanvid_amd import ops
+
+    with pytest.raises(ValueError):
+        ops.gemm(cx.lib, cx.stream, x, w, y)  # K % 64 != 0
+    with pytest.raises(NotImplementedError):
+        ops.attention(cx.lib, cx.stream, x, x, x, y, n_images=1, heads=8, D=64, Lq=8, L1=8, ldq=512, ldk=512,
+                      ldvt=8, ldo=512)

@@ -1,0 +1,139 @@
+"""Launch sequencing helpers shared by the native executors (UNet3D, ReferenceNet, camera encoder,
+pose guider): each method is one fused block of the reference expressed as C-ABI launches.
+See engine.py for the fusion map and the reference citations."""
+from __future__ import annotations
+
+from typing import Dict, Optional
+
+import torch
+
+from . import _abi as A
+from . import lib as hvlib
+from . import ops
+
+BF16 = torch.bfloat16
+F32 = torch.float32
+
+
+class Workspace:
+    """Named persistent device buffers (stable addresses => HIP-graph friendly)."""
+
+    def __init__(self, device):
+        self.device = device
+        self.bufs: Dict[str, torch.Tensor] = {}
+
+    def get(self, name: str, shape, dtype=BF16) -> torch.Tensor:
+        shape = tuple(int(s) for s in shape)
+        n = 1
+        for s in shape:
+            n *= s
+        t = self.bufs.get(name)
+        if t is None or t.dtype != dtype or t.numel() < n:
+            t = torch.empty(max(n, 1), dtype=dtype, device=self.device)
+            self.bufs[name] = t
+        return t[:n].view(shape)
+
+    def bytes(self) -> int:
+        return sum(t.numel() * t.element_size() for t in self.bufs.values())
+
+
+class FrameShard:
+    """Frame-axis sharding of one context window over the ranks of a torch.distributed group
+    (backend "nccl" == RCCL over xGMI on the GPU box, "gloo" in the CPU tests)."""
+
+    def __init__(self, group=None):
+        import torch.distributed as dist
+
+        self.dist = dist
+        self.group = group
+        self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+
+    def all_gather(self, out: torch.Tensor, inp: torch.Tensor):
+        self.dist.all_gather_into_tensor(out, inp, group=self.group)
+
+    def frame_range(self, n_frames: int):
+        if n_frames % self.world:
+            raise ValueError(f"{n_frames} frames do not shard evenly over {self.world} ranks")
+        per = n_frames // self.world
+        return self.rank * per, per
+
+
+class Runner:
+    def __init__(self, device, w: Dict[str, torch.Tensor], ws: Optional[Workspace] = None, groups: int = 32,
+                 shard: Optional[FrameShard] = None):
+        self.lib = hvlib.load()
+        self.device = device
+        self.w = w
+        self.ws = ws or Workspace(device)
+        self.groups = groups
+        self.shard = shard
+        self._pe_split: Dict[tuple, tuple] = {}
+
+    @property
+    def st(self) -> int:
+        return hvlib.current_stream()
+
+    # ---- normalisation statistics ---------------------------------------------------------------
+    def gn_affine(self, x, prefix, eps, x2=None):
+        n = x.shape[0]
+        C = x.shape[3] + (0 if x2 is None else x2.shape[3])
+        sc = self.ws.get("gn_scale", (n, C), F32)
+        sh = self.ws.get("gn_shift", (n, C), F32)
+        pixels = x.shape[1] * x.shape[2]
+        splits = max(1, min(64, pixels // 48))
+        part = self.ws.get("gn_partial", (n * 64 * self.groups * 2,), F32)
+        ops.groupnorm_affine(self.lib, self.st, x, self.w[prefix + ".g"], self.w[prefix + ".b"], self.groups, eps, part,
+                             sc, sh, x2=x2, splits=splits)
+        return sc, sh
+
+    def ln_stats(self, h2d):
+        M = h2d.shape[0]
+        mean, rstd = self.ws.get("ln_mean", (M,), F32), self.ws.get("ln_rstd", (M,), F32)
+        ops.layernorm_stats(self.lib, self.st, h2d, mean, rstd)
+        return mean, rstd
+
+    # ---- LN -> GEGLU feed-forward -> +residual (in place) ----------------------------------------
+    def feed_forward(self, ff1, ff2, h2d):
+        w = self.w
+        M, C = h2d.shape
+        mean, rstd = self.ln_stats(h2d)
+        ffh = self.ws.get(f"ffh_{M}x{C}", (M, 4 * C))
+        ops.gemm(self.lib, self.st, h2d, w[ff1 + ".w"], ffh, bias=w[ff1 + ".bias"], row_mean=mean, row_rstd=rstd,
+                 colsum=w[ff1 + ".colsum"], geglu=True)
+        ops.gemm(self.lib, self.st, ffh, w[ff2 + ".w"], h2d, bias=w[ff2 + ".bias"], residual=h2d)
+
+    # ---- LN(+PE) -> qkv -> attention over frames -> out-proj + residual (in place) -----------------
+    def temporal_attention_block(self, ab, hid, B, F, N, sharded: bool):
+        """`ab` = weight prefix of one VersatileAttention / TemporalSelfAttention block; hid [(B F N), C]."""
+        w, L, st, ws = self.w, self.lib, self.st, self.ws
+        M, C = hid.shape
+        D = C // 8
+        mean, rstd = self.ln_stats(hid)
+        pe = w.get(ab + ".qkv.pe")
+        o = ws.get(f"tr_o_{M}x{C}", (M, C))
+        if not sharded:
+            pekw = {} if pe is None else dict(pe=pe, pe_period=N, pe_frames=F)
+            qkv = ws.get(f"mm_qkv_{M}x{C}", (M, 3 * C))
+            ops.gemm(L, st, hid, w[ab + ".qkv.w"], qkv, bias=w[ab + ".qkv.bias"], row_mean=mean, row_rstd=rstd,
+                     colsum=w[ab + ".qkv.colsum"], **pekw)
+            ops.temporal_attention(L, st, qkv, o, B=B, F=F, P=N, heads=8, D=D)
+        else:
+            R, f0 = self.shard.world, self.shard.rank * F
+            pq, pkv = {}, {}
+            if pe is not None:
+                key = (ab, f0, F)
+                if key not in self._pe_split:
+                    self._pe_split[key] = (pe[f0:f0 + F, :C].contiguous(), pe[f0:f0 + F, C:].contiguous())
+                a, b = self._pe_split[key]
+                pq, pkv = dict(pe=a, pe_period=N, pe_frames=F), dict(pe=b, pe_period=N, pe_frames=F)
+            q = ws.get(f"mm_q_{M}x{C}", (M, C))
+            kvl = ws.get(f"mm_kv_{M}x{C}", (M, 2 * C))
+            wq, bq, cs = w[ab + ".qkv.w"], w[ab + ".qkv.bias"], w[ab + ".qkv.colsum"]
+            ops.gemm(L, st, hid, wq[:C], q, bias=bq[:C], row_mean=mean, row_rstd=rstd, colsum=cs[:C], **pq)
+            ops.gemm(L, st, hid, wq[C:], kvl, bias=bq[C:], row_mean=mean, row_rstd=rstd, colsum=cs[C:], **pkv)
+            kvg = ws.get(f"mm_kvg_{M}x{C}", (R, B, F, N, 2 * C))
+            self.shard.all_gather(kvg.view(-1), kvl.view(-1))
+            ops.temporal_attention_sharded(L, st, q, kvg, o, B=B, Fq=F, ranks=R, P=N, heads=8, D=D)
+        ops.gemm(L, st, o, w[ab + ".to_out.0.w"], hid, bias=w[ab + ".to_out.0.bias"], residual=hid)
+

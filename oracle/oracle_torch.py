@@ -417,6 +417,7 @@ def spatial_transformer(
     do_cfg: bool,
     heads: int,
     groups: int,
+    bank_out: Optional[dict] = None,
 ) -> Tensor:
     """Transformer3DModel.forward (src/models/transformer_3d.py:103-169) with the read-mode
     patched block forward (src/models/mutual_self_attention.py:147-186, 187-228).
@@ -431,6 +432,8 @@ def spatial_transformer(
     t = p + ".transformer_blocks.0"
     ehs_f = ehs.repeat_interleave(video_length, dim=0)  # 'b n c -> (b f) n c'
     nh = layer_norm(sd, t + ".norm1", h)
+    if bank_out is not None:  # write mode: self.bank.append(norm_hidden_states.clone()), mutual_self_attention.py:137-138
+        bank_out[p] = nh.clone()
     if bank is not None:
         bank_f = bank.to(nh.dtype).repeat_interleave(video_length, dim=0)
         kv = torch.cat([nh, bank_f], dim=1)
@@ -571,6 +574,65 @@ def unet3d_forward(
     x = F.silu(group_norm(sd, "conv_norm_out", x, groups, eps))
     x = conv2d(sd, "conv_out", x)
     return x.view(b, f, -1, hh, ww).permute(0, 2, 1, 3, 4)
+
+
+def reference_net_cfg(cfg3d: dict) -> dict:
+    """The ReferenceNet is the same SD-1.5 geometry without motion modules."""
+    c = dict(cfg3d)
+    c.update(use_motion_module=False)
+    return c
+
+
+def make_reference_net_weights(cfg: dict, seed: int = 5) -> SD:
+    sd = make_unet3d_weights(reference_net_cfg(cfg), seed)
+    for k in ("conv_norm_out.weight", "conv_norm_out.bias", "conv_out.weight", "conv_out.bias"):
+        sd.pop(k)  # removed in the reference's ReferenceNet (src/models/unet_2d_condition.py:645-653)
+    return sd
+
+
+def reference_net_banks(sd: SD, cfg: dict, ref_latents: Tensor, encoder_hidden_states: Tensor) -> Dict[str, Tensor]:
+    """ReferenceNet write pass (src/pipelines/pipeline_pose2vid_long.py:470-480 ->
+    src/models/unet_2d_condition.py:872-1308 with mutual_self_attention.py:137-146): an SD UNet on
+    the reference latent at t = 0; returns {transformer location -> norm1 features [b, N, C]}.
+    NOTE: restated from the 3-D blocks with one frame (diffusers' ResnetBlock2D / Transformer2DModel
+    are not available here to pin against; SURVEY.md appendix C last bullet)."""
+    cfg = reference_net_cfg(cfg)
+    spec = unet3d_spec(cfg)
+    b = ref_latents.shape[0]
+    groups, eps, heads = cfg["norm_num_groups"], cfg["norm_eps"], cfg["attention_head_dim"]
+    banks: Dict[str, Tensor] = {}
+    emb = timestep_embedding(torch.zeros(b), spec["boc"][0])
+    emb = linear(sd, "time_embedding.linear_2", F.silu(linear(sd, "time_embedding.linear_1", emb)))
+    x = conv2d(sd, "conv_in", ref_latents)
+    skips = [x]
+
+    def tf(p, x):
+        return spatial_transformer(sd, p, x, encoder_hidden_states, None, 1, False, heads, groups, bank_out=banks)
+
+    for blk in spec["down"]:
+        p = blk["prefix"]
+        for j in range(len(blk["resnets"])):
+            x = resnet_block(sd, f"{p}.resnets.{j}", x, emb, groups, eps)
+            if blk["attn"]:
+                x = tf(f"{p}.attentions.{j}", x)
+            skips.append(x)
+        if blk["downsample"]:
+            x = conv2d(sd, f"{p}.downsamplers.0.conv", x, stride=2, padding=1)
+            skips.append(x)
+    x = resnet_block(sd, "mid_block.resnets.0", x, emb, groups, eps)
+    x = tf("mid_block.attentions.0", x)
+    x = resnet_block(sd, "mid_block.resnets.1", x, emb, groups, eps)
+    for blk in spec["up"]:
+        p = blk["prefix"]
+        for j in range(len(blk["resnets"])):
+            x = torch.cat([x, skips.pop()], dim=1)
+            x = resnet_block(sd, f"{p}.resnets.{j}", x, emb, groups, eps)
+            if blk["attn"]:
+                x = tf(f"{p}.attentions.{j}", x)
+        if blk["upsample"]:
+            x = F.interpolate(x, scale_factor=2.0, mode="nearest")
+            x = conv2d(sd, f"{p}.upsamplers.0.conv", x)
+    return banks
 
 
 # --------------------------------------------------------------------------------------

@@ -1,0 +1,247 @@
+#!/usr/bin/env python3
+"""Headline benchmark: denoising steps / second, 24f x 768 x 512 Pose2Video (BASELINE.json config #3),
+CFG 3.5, SD-1.5 geometry + AnimateDiff motion modules + CameraCtrl Pluecker encoder, bf16 storage /
+fp32 accumulation, random-init weights and synthetic latents/pose/camera/CLIP/bank tensors of the
+named shapes (no checkpoints or datasets are reachable).
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+A "step" = one pass of the hot path: pack latents -> UNet3D forward on both CFG halves (ReferenceNet
+banks injected, pose+camera conditioning added) -> window accumulation -> CFG + DDIM update.  With
+N > 1 the 24 frames are sharded over the ranks (RCCL all-gather of temporal K/V in every motion
+module): the total work is fixed, so scaling is "strong".  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+import torch  # noqa: E402
+
+PEAK_BF16_TFLOPS = 2500.0  # dense MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def build_models(dev):
+    from humanvid_amd.arch import SD15_INFERENCE_V2
+    from humanvid_amd.conditioning import CameraPoseEncoder, PoseGuider
+    from humanvid_amd.unet3d import UNet3DConditionModel
+
+    torch.manual_seed(0)
+    with torch.device(dev):
+        unet = UNet3DConditionModel(**SD15_INFERENCE_V2)
+        pg = PoseGuider(320, block_out_channels=(16, 32, 96, 256))
+        cam = CameraPoseEncoder(downscale_factor=8, channels=[320], nums_rb=2, cin=384, ksize=1, sk=True, use_conv=False,
+                                compression_factor=1, temporal_attention_nhead=8, attention_block_types=["Temporal_Self"],
+                                temporal_position_encoding=True, temporal_position_encoding_max_len=24)
+    with torch.no_grad():  # zero-initialised branches would make whole sub-graphs trivial: re-randomise
+        for mod in (unet, pg, cam):
+            for name, p in mod.named_parameters():
+                if p.ndim >= 2 and float(p.abs().max()) == 0.0:
+                    p.normal_(0.0, 0.02)
+    return unet, pg, cam
+
+
+def roofline_probe(unet, n_img, F, h, w, iters=5):
+    """Average duration of the dominant kernel (level-0 spatial attention with bank keys, the
+    launch the step issues 5x) measured with HIP events on the launch stream."""
+    import ctypes
+
+    from humanvid_amd import lib as hvlib
+    from humanvid_amd import ops
+
+    L, st = hvlib.load(), hvlib.current_stream()
+    C, N = 320, h * w
+    M = n_img * N
+    dev = torch.device("cuda")
+    qk = torch.randn(M, 2 * C, device=dev).to(torch.bfloat16)
+    vt = torch.randn(C, M, device=dev).to(torch.bfloat16)
+    k2 = torch.randn(2 * N, C, device=dev).to(torch.bfloat16)
+    vt2 = torch.randn(C, 2 * N, device=dev).to(torch.bfloat16)
+    o = torch.empty(M, C, dtype=torch.bfloat16, device=dev)
+    sel = torch.tensor([-1] * F + [1] * (n_img - F), dtype=torch.int32, device=dev)
+
+    def run():
+        ops.attention(L, st, qk, qk[:, C:], vt, o, n_images=n_img, heads=8, D=40, Lq=N, L1=N, ldq=2 * C, ldk=2 * C,
+                      ldvt=M, ldo=C, k2=k2, vt2=vt2, ldk2=C, ldvt2=2 * N, L2=N, bank_sel=sel)
+
+    run()
+    torch.cuda.synchronize()
+    e0, e1 = ctypes.c_void_p(), ctypes.c_void_p()
+    L.call("hv_event_create", ctypes.byref(e0))
+    L.call("hv_event_create", ctypes.byref(e1))
+    L.call("hv_event_record", e0, st)
+    for _ in range(iters):
+        run()
+    L.call("hv_event_record", e1, st)
+    ms = ctypes.c_float()
+    L.call("hv_event_elapsed_ms", e0, e1, ctypes.byref(ms))
+    L.call("hv_event_destroy", e0)
+    L.call("hv_event_destroy", e1)
+    ms = ms.value / iters
+    flops = 4.0 * N * N * C * F + 4.0 * N * 2 * N * C * (n_img - F)
+    return dict(kernel="hv_attention_kernel<40> (level-0 spatial self-attention + bank keys)", ms=ms,
+                flops=flops, tflops=flops / ms / 1e9)
+
+
+def cpu_baseline(budget_hw=(24, 16), frames=24):
+    """Time the fp32 oracle (a port of the reference's forward) on the host cores on a bounded sample:
+    one CFG UNet forward + DDIM update at F=24, full SD-1.5 widths, latent 24x16 (1/16 of the
+    config-#3 pixels); scaled to config #3 by the as-written FLOP ratio."""
+    sys.path.insert(0, os.path.join(REPO, "oracle"))
+    import oracle_torch as O  # test infrastructure: timed here as the reported CPU baseline only
+
+    from humanvid_amd.arch import DEFAULT_UNET3D_CONFIG, SD15_INFERENCE_V2
+    from humanvid_amd.workload import unet3d_flops
+
+    cfg = dict(O.SD15_UNET3D_CFG)
+    sd = O.make_unet3d_weights(cfg, seed=0)
+    h, w = budget_hw
+    g = torch.Generator().manual_seed(42)
+    lat = torch.randn(1, 4, frames, h, w, generator=g)
+    ehs = torch.cat([torch.zeros(1, 1, 768), torch.randn(1, 1, 768, generator=g)])
+    pose = torch.randn(1, 320, frames, h, w, generator=g).repeat(2, 1, 1, 1, 1)
+    banks = {p: torch.randn(2, (h >> l) * (w >> l), c, generator=g)
+             for p in O.transformer_locations(cfg)
+             for c, l in [(sd[p + ".norm.weight"].numel(), {320: 0, 640: 1, 1280: 2}[sd[p + ".norm.weight"].numel()])]}
+    sched = O.DDIM()
+    sched.set_timesteps(30)
+    t0 = time.time()
+    with torch.no_grad():
+        pred = O.unet3d_forward(sd, cfg, lat.repeat(2, 1, 1, 1, 1), 966, ehs, pose, banks, do_cfg=True)
+        u, c = pred.chunk(2)
+        sched.step(u + 3.5 * (c - u), 966, lat)
+    dt = time.time() - t0
+    full = dict(DEFAULT_UNET3D_CONFIG)
+    full.update(SD15_INFERENCE_V2)
+    ratio = unet3d_flops(full, 2, 24, 96, 64, True)["total"] / unet3d_flops(full, 2, frames, h, w, True)["total"]
+    return dict(value=1.0 / (dt * ratio), unit="steps/s", cores=torch.get_num_threads(), kind="port",
+                sample=f"fp32 oracle (port of the reference forward), 1 CFG step at F={frames}, latent {h}x{w}, SD-1.5 "
+                       f"widths: {dt:.1f} s; scaled by as-written FLOP ratio {ratio:.1f} to 24f x 768x512")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--frames", type=int, default=24)
+    ap.add_argument("--height", type=int, default=768)
+    ap.add_argument("--width", type=int, default=512)
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if args.gpus > 1:
+            raise SystemExit(f"--gpus {args.gpus} must be launched with torch.distributed.run --nproc-per-node {args.gpus}")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    import torch.distributed as dist
+
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from humanvid_amd.arch import DEFAULT_UNET3D_CONFIG, SD15_INFERENCE_V2
+    from humanvid_amd.pipeline import Pose2VideoPipeline
+    from humanvid_amd.scheduler import DDIMScheduler
+    from humanvid_amd.workload import unet3d_flops
+
+    F, H, W = args.frames, args.height, args.width
+    h, w = H // 8, W // 8
+    unet, pg, cam = build_models(dev)
+    sched = DDIMScheduler(beta_start=0.00085, beta_end=0.012, beta_schedule="linear", clip_sample=False, steps_offset=1,
+                          prediction_type="v_prediction", rescale_betas_zero_snr=True, timestep_spacing="trailing")
+    pipe = Pose2VideoPipeline(None, None, None, unet, pg, cam, sched)
+    if world > 1:
+        pipe.enable_frame_sharding()
+
+    g = torch.Generator().manual_seed(42)
+    latents = torch.randn(1, 4, F, h, w, generator=g)
+    pose = torch.rand(1, 3, F, H, W, generator=torch.Generator().manual_seed(1))
+    plucker = torch.randn(1, 6, F, H, W, generator=torch.Generator().manual_seed(3))
+    clip = torch.randn(1, 768, generator=torch.Generator().manual_seed(2))
+    from humanvid_amd.unet3d import transformer_locations
+
+    eng = unet.engine() if world == 1 else None
+    if eng is None:
+        from humanvid_amd.engine import UNet3DEngine
+
+        unet._engine = eng = UNet3DEngine(unet, shard=pipe.shard)
+    gb = torch.Generator(device=dev).manual_seed(5)
+    banks = {}
+    for loc in transformer_locations(unet):
+        C = eng.w[loc + ".proj_in.w"].shape[0]
+        lvl = {320: 0, 640: 1, 1280: 2}[C] if loc != "mid_block.attentions.0" else 3
+        banks[loc] = torch.randn(2, (h >> lvl) * (w >> lvl), C, device=dev, generator=gb).half().float()
+    eng.set_reference_banks(banks, do_cfg=True)
+    eng._banks_from_modules = lambda: None  # banks were installed explicitly (no ReferenceNet pass in the timed path)
+
+    K, Wm = args.steps, args.warmup
+    n_inf = max(30, K + Wm)
+    times = {}
+
+    def sync_barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    def hook(i):
+        if i == Wm - 1:
+            sync_barrier()
+            times["t0"] = time.perf_counter()
+        if i == Wm + K - 1:
+            sync_barrier()
+            times["t1"] = time.perf_counter()
+
+    if Wm == 0:
+        sync_barrier()
+        times["t0"] = time.perf_counter()
+    pipe.denoise(latents, pose, plucker, clip, n_inf, 3.5, use_graph=not args.no_graph, max_steps=Wm + K, step_hook=hook)
+    elapsed = times["t1"] - times["t0"]
+    if world > 1:
+        tmax = torch.tensor([elapsed], device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax)
+
+    if rank == 0:
+        cfg = dict(DEFAULT_UNET3D_CONFIG)
+        cfg.update(SD15_INFERENCE_V2)
+        fl = unet3d_flops(cfg, 2, F, h, w, False)
+        ms_step = elapsed / K * 1e3
+        probe = roofline_probe(unet, 2 * F, F, h, w) if world == 1 else None
+        out = {
+            "metric": "denoising steps/sec, 24f x 768x512 Pose2Video", "value": K / elapsed, "unit": "steps/s",
+            "n_gpus": world, "steps": K, "warmup": Wm, "ms_per_step": ms_step, "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": f"Pose2Video {F}f x {H}x{W}, CFG 3.5, CameraCtrl Pluecker embedding, SD-1.5 UNet3D + "
+                                   "motion modules, 1 window, DDIM v-pred (BASELINE.json configs[2])",
+                       "parallelism": "single GPU" if world == 1 else f"frame-sharded x{world} (RCCL all-gather of temporal K/V)",
+                       "hip_graph": not args.no_graph and world == 1},
+            "step_algorithmic_tflop": fl["total"] / 1e12,
+            "step_tflops_per_gpu": fl["total"] / 1e12 / (ms_step / 1e3) / world,
+            "step_frac_of_mfma_peak": fl["total"] / 1e12 / (ms_step / 1e3) / world / PEAK_BF16_TFLOPS,
+        }
+        if probe is not None:
+            out["roofline"] = {"bound": "mfma", "achieved": probe["tflops"], "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                               "frac": probe["tflops"] / PEAK_BF16_TFLOPS, "traffic": None,
+                               "kernel": probe["kernel"], "avg_launch_ms": probe["ms"],
+                               "flops_per_launch": probe["flops"]}
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

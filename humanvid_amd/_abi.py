@@ -95,7 +95,7 @@ PROTOTYPES = {
     "hv_attention": (I, [C.POINTER(AttentionParams), P]),
     "hv_set_tuning": (I, [I, I]),
     "hv_temporal_attention": (I, [C.POINTER(TemporalAttentionParams), P]),
-    "hv_pack_ncfhw": (I, [P, I, I, I, I, I, I, I, P, I, P]),
+    "hv_pack_ncfhw": (I, [P, I, I, I, I, I, I, P, I, I, P, I, P]),
     "hv_unpack_nhwc": (I, [P, I, I, I, I, I, I, P, I, P]),
     "hv_pixel_unshuffle": (I, [P, I, I, I, I, I, I, P, P]),
     "hv_timestep_embedding": (I, [P, I, I, P, P]),

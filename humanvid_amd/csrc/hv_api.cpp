@@ -90,10 +90,10 @@ int hv_temporal_attention(const hv_temporal_attention_params* p, void* stream) {
     return hv_check_launch("hv_temporal_attention");
 }
 
-int hv_pack_ncfhw(const void* src, int src_is_bf16, int B, int C, int F, int H, int W, int rep, uint16_t* dst,
-                  int Cpad, void* stream) {
-    if (!src || !dst || Cpad < C || Cpad % 8 != 0) return hv_fail(HV_EINVAL, "hv_pack_ncfhw: bad args");
-    hvk_pack(src, src_is_bf16, B, C, F, H, W, rep, dst, Cpad, (hipStream_t)stream);
+int hv_pack_ncfhw(const void* src, int src_is_bf16, int B, int C, int Fsrc, int H, int W, const int* frames, int F,
+                  int rep, uint16_t* dst, int Cpad, void* stream) {
+    if (!src || !dst || Cpad < C || Cpad % 8 != 0 || F <= 0) return hv_fail(HV_EINVAL, "hv_pack_ncfhw: bad args");
+    hvk_pack(src, src_is_bf16, B, C, Fsrc, H, W, frames, F, rep, dst, Cpad, (hipStream_t)stream);
     return hv_check_launch("hv_pack_ncfhw");
 }
 

@@ -8,8 +8,9 @@
 // [b][c][f][h][w] (fp32 / bf16)  ->  [(rep b) f][h][w][Cpad] bf16, zero channel padding.
 // The reference's 'b c f h w -> (b f) c h w' rearrange (src/models/resnet.py:12) plus the CFG
 // `.repeat(2, ...)` of src/pipelines/pipeline_pose2vid_long.py:516-520 in one pass.
-__global__ __launch_bounds__(256) void hv_pack_kernel(const void* src, int src_bf16, int B, int C, int F, int H, int W,
-                                                      int rep, bf16_t* dst, int Cpad) {
+__global__ __launch_bounds__(256) void hv_pack_kernel(const void* src, int src_bf16, int B, int C, int Fsrc, int H,
+                                                      int W, const int* frames, int F, int rep, bf16_t* dst,
+                                                      int Cpad) {
     const long npix = (long)B * F * H * W;
     const int cvs = Cpad / 8;
     const long total = npix * cvs;
@@ -22,13 +23,14 @@ __global__ __launch_bounds__(256) void hv_pack_kernel(const void* src, int src_b
         pix /= H;
         const int f = (int)(pix % F);
         const int b = (int)(pix / F);
+        const int fs = frames ? frames[f] : f;
         float v[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const int c = cv * 8 + e;
             float a = 0.f;
             if (c < C) {
-                const long si = ((((long)b * C + c) * F + f) * H + y) * W + x;
+                const long si = ((((long)b * C + c) * Fsrc + fs) * H + y) * W + x;
                 a = src_bf16 ? hv_bf2f(reinterpret_cast<const bf16_t*>(src)[si]) : reinterpret_cast<const float*>(src)[si];
             }
             v[e] = a;
@@ -152,10 +154,10 @@ static inline int hv_ew_grid(long total) {
     return (int)(g < 1 ? 1 : (g > 4096 ? 4096 : g));
 }
 
-static inline void hv_pack_launch(const void* src, int src_bf16, int B, int C, int F, int H, int W, int rep,
-                                  bf16_t* dst, int Cpad, hipStream_t s) {
-    hv_launch(hv_pack_kernel, dim3(hv_ew_grid((long)B * F * H * W * (Cpad / 8))), dim3(256), s, src, src_bf16, B, C, F,
-              H, W, rep, dst, Cpad);
+static inline void hv_pack_launch(const void* src, int src_bf16, int B, int C, int Fsrc, int H, int W,
+                                  const int* frames, int F, int rep, bf16_t* dst, int Cpad, hipStream_t s) {
+    hv_launch(hv_pack_kernel, dim3(hv_ew_grid((long)B * F * H * W * (Cpad / 8))), dim3(256), s, src, src_bf16, B, C,
+              Fsrc, H, W, frames, F, rep, dst, Cpad);
 }
 static inline void hv_unpack_launch(const bf16_t* src, int ldc, int B, int C, int F, int H, int W, void* dst,
                                     int dst_bf16, hipStream_t s) {

@@ -2,9 +2,9 @@
 #include "hv_elementwise.h"
 #include "hv_kernels.h"
 
-void hvk_pack(const void* src, int src_bf16, int B, int C, int F, int H, int W, int rep, bf16_t* dst, int Cpad,
-              hipStream_t s) {
-    hv_pack_launch(src, src_bf16, B, C, F, H, W, rep, dst, Cpad, s);
+void hvk_pack(const void* src, int src_bf16, int B, int C, int Fsrc, int H, int W, const int* frames, int F, int rep,
+              bf16_t* dst, int Cpad, hipStream_t s) {
+    hv_pack_launch(src, src_bf16, B, C, Fsrc, H, W, frames, F, rep, dst, Cpad, s);
 }
 void hvk_unpack(const bf16_t* src, int ldc, int B, int C, int F, int H, int W, void* dst, int dst_bf16, hipStream_t s) {
     hv_unpack_launch(src, ldc, B, C, F, H, W, dst, dst_bf16, s);

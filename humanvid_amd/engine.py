@@ -91,6 +91,7 @@ class UNet3DEngine:
 
         def lnfold(name, wcat, bias, norm, geglu=False, pe=None):
             gamma, beta = sd[norm + ".weight"].float(), sd[norm + ".bias"].float()
+            wcat = wcat.to(gamma.device)
             wf, colsum, bf = packing.fold_layernorm(wcat.float(), None if bias is None else bias.float(), gamma, beta)
             pet = packing.pe_table(pe, wcat) if pe is not None else None
             if geglu:

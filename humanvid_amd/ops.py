@@ -119,11 +119,13 @@ def temporal_attention_sharded(lib, stream, q, kv_gathered, o, *, B, Fq, ranks, 
     lib.call("hv_temporal_attention", C.byref(p), stream)
 
 
-def pack_ncfhw(lib, stream, src, dst, rep=1):
-    """src [B,C,F,H,W] fp32|bf16 -> dst [(rep B) F, H, W, Cpad] bf16."""
-    B, Cc, Fr, H, W = src.shape
-    lib.call("hv_pack_ncfhw", src.data_ptr(), int(src.dtype == BF16), B, Cc, Fr, H, W, rep, dst.data_ptr(),
-             dst.shape[-1], stream)
+def pack_ncfhw(lib, stream, src, dst, rep=1, frames=None):
+    """src [B,C,Fsrc,H,W] fp32|bf16 -> dst [(rep B) F, H, W, Cpad] bf16; `frames` (device int32 [F])
+    selects / reorders source frames (context window, frame shard)."""
+    B, Cc, Fs, H, W = src.shape
+    Fr = Fs if frames is None else frames.numel()
+    lib.call("hv_pack_ncfhw", src.data_ptr(), int(src.dtype == BF16), B, Cc, Fs, H, W, _p(frames), Fr, rep,
+             dst.data_ptr(), dst.shape[-1], stream)
 
 
 def unpack_nhwc(lib, stream, src, dst):

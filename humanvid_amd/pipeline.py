@@ -1,0 +1,302 @@
+"""Pose2VideoPipeline -- drop-in for /root/reference/src/pipelines/pipeline_pose2vid_long.py:35-588.
+
+`__call__` keeps the reference's signature and semantics (CLIP embed, ReferenceNet write pass at
+i == 0, context windows, CFG, DDIM v-prediction, per-frame VAE decode).  The denoising loop body
+(:454-571) is `denoise()`: everything timestep-independent is hoisted out of the loop (PoseGuider,
+CameraPoseEncoder, window lists, folded cross-attention constants, reference-bank K/V), one step is
+a fixed launch sequence into libhumanvid_hip.so (captured as a HIP graph and replayed), and with a
+`FrameShard` the frames of each window are split over the ranks of a node (all-gather of temporal
+K/V inside the motion modules, all-reduce of the tiny noise accumulator per step).
+
+VAE and CLIP stay stock PyTorch-ROCm modules supplied by the caller (BASELINE.json north_star).
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass
+from typing import Callable, Dict, List, Optional, Union
+
+import numpy as np
+import torch
+
+from . import lib as hvlib
+from . import ops
+from .reference_control import ReferenceAttentionControl
+from .runner import FrameShard
+from .scheduler import get_context_scheduler
+
+F32 = torch.float32
+BF16 = torch.bfloat16
+
+
+@dataclass
+class Pose2VideoPipelineOutput:
+    videos: Union[torch.Tensor, np.ndarray]
+
+
+def _pil_to_tensor(images, height, width, normalize: bool) -> torch.Tensor:
+    """VaeImageProcessor.preprocess: resize (Lanczos) to (height, width) rounded down to a multiple
+    of 8, [0,1], optionally 2x-1.  -> [n,3,H,W] fp32."""
+    from PIL import Image
+
+    if not isinstance(images, (list, tuple)):
+        images = [images]
+    height, width = height - height % 8, width - width % 8
+    out = []
+    for im in images:
+        im = im.convert("RGB").resize((width, height), resample=Image.LANCZOS)
+        a = torch.from_numpy(np.asarray(im, dtype=np.float32) / 255.0).permute(2, 0, 1)
+        out.append(2.0 * a - 1.0 if normalize else a)
+    return torch.stack(out)
+
+
+def _clip_preprocess(ref_image) -> torch.Tensor:
+    """CLIPImageProcessor() defaults on an image already resized to 224x224 (pipeline :380-382)."""
+    from PIL import Image
+
+    im = ref_image.convert("RGB").resize((224, 224), resample=Image.BICUBIC)
+    a = torch.from_numpy(np.asarray(im, dtype=np.float32) / 255.0).permute(2, 0, 1)
+    mean = torch.tensor([0.48145466, 0.4578275, 0.40821073]).view(3, 1, 1)
+    std = torch.tensor([0.26862954, 0.26130258, 0.27577711]).view(3, 1, 1)
+    return ((a - mean) / std)[None]
+
+
+class Pose2VideoPipeline:
+    def __init__(self, vae, image_encoder, reference_unet, denoising_unet, pose_guider, camera_pose_encoder,
+                 scheduler, image_proj_model=None, tokenizer=None, text_encoder=None):
+        self.vae, self.image_encoder = vae, image_encoder
+        self.reference_unet, self.denoising_unet = reference_unet, denoising_unet
+        self.pose_guider, self.camera_pose_encoder = pose_guider, camera_pose_encoder
+        self.scheduler = scheduler
+        self.image_proj_model, self.tokenizer, self.text_encoder = image_proj_model, tokenizer, text_encoder
+        self.vae_scale_factor = 8
+        if vae is not None and hasattr(vae, "config") and hasattr(vae.config, "block_out_channels"):
+            self.vae_scale_factor = 2 ** (len(vae.config.block_out_channels) - 1)
+        self.shard: Optional[FrameShard] = None
+        self._graph = None
+        self._graph_key = None
+
+    # ---- DiffusionPipeline surface ---------------------------------------------------------------
+    def to(self, device=None, dtype=None):
+        for m in (self.vae, self.image_encoder, self.reference_unet, self.denoising_unet, self.pose_guider,
+                  self.camera_pose_encoder):
+            if m is not None and hasattr(m, "to"):
+                m.to(device=device, dtype=dtype) if dtype is not None else m.to(device=device)
+        return self
+
+    def enable_frame_sharding(self, group=None):
+        """Shard every context window along the frame axis over the ranks of `group` (one process per
+        GPU, torch.distributed backend "nccl" = RCCL over xGMI)."""
+        self.shard = FrameShard(group)
+        self.denoising_unet._engine = None
+        return self
+
+    def progress_bar(self, iterable=None, total=None):
+        try:
+            from tqdm.auto import tqdm
+
+            return tqdm(iterable, total=total)
+        except Exception:  # pragma: no cover
+            class _Null:
+                def __enter__(s): return s
+                def __exit__(s, *a): return False
+                def update(s, n=1): pass
+            return _Null()
+
+    def prepare_latents(self, batch_size, num_channels_latents, width, height, video_length, dtype, device, generator,
+                        latents=None):
+        shape = (batch_size, num_channels_latents, video_length, height // self.vae_scale_factor,
+                 width // self.vae_scale_factor)
+        if isinstance(generator, list) and len(generator) != batch_size:
+            raise ValueError(
+                f"You have passed a list of generators of length {len(generator)}, but requested an effective batch"
+                f" size of {batch_size}. Make sure the batch size matches the length of the generators.")
+        if latents is None:
+            gdev = generator.device if isinstance(generator, torch.Generator) else torch.device("cpu")
+            latents = torch.randn(shape, generator=generator, device=gdev, dtype=F32).to(device)  # randn_tensor semantics
+        else:
+            latents = latents.to(device)
+        return latents * self.scheduler.init_noise_sigma
+
+    def decode_latents(self, latents):
+        """pipeline_pose2vid_long.py:114-127: per-frame VAE decode on PyTorch-ROCm."""
+        video_length = latents.shape[2]
+        latents = 1 / 0.18215 * latents
+        b = latents.shape[0]
+        flat = latents.permute(0, 2, 1, 3, 4).reshape(b * video_length, *latents.shape[1:2], *latents.shape[3:])
+        frames = [self.vae.decode(flat[i:i + 1].to(self.vae.dtype)).sample for i in range(flat.shape[0])]
+        video = torch.cat(frames)
+        video = video.view(b, video_length, *video.shape[1:]).permute(0, 2, 1, 3, 4)
+        video = (video / 2 + 0.5).clamp(0, 1)
+        return video.cpu().float().numpy()
+
+    # ---- the hot path ----------------------------------------------------------------------------
+    def build_conditioning(self, pose_cond_tensor, camera_embedding, windows: List[List[int]], f0: int, fl: int):
+        """Timestep-independent conditioning per window: PoseGuider + CameraPoseEncoder feature
+        (pipeline :526-539, hoisted).  Returns a list of [f_local, h, w, 320] bf16 tensors."""
+        out = []
+        for c in windows:
+            pose_w = pose_cond_tensor[:, :, c]
+            cam_w = camera_embedding[:, :, c]
+            pose_fea = self.pose_guider.forward_nhwc(pose_w)  # [(1 f), h, w, 320]
+            feat = self.camera_pose_encoder.forward_nhwc(cam_w.float(), add=pose_fea)
+            out.append(feat[f0:f0 + fl].clone())
+        return out
+
+    @torch.no_grad()
+    def denoise(self, latents: torch.Tensor, pose_cond_tensor: torch.Tensor, camera_embedding: torch.Tensor,
+                clip_image_embeds: torch.Tensor, num_inference_steps: int, guidance_scale: float,
+                context_schedule="uniform", context_frames=24, context_stride=1, context_overlap=4,
+                use_graph: bool = True, callback: Optional[Callable] = None, callback_steps: int = 1,
+                max_steps: Optional[int] = None, step_hook: Optional[Callable] = None) -> torch.Tensor:
+        """Denoising loop body of the reference (pipeline_pose2vid_long.py:454-571).
+
+        latents [1,4,F,h,w] fp32 (cuda); pose_cond_tensor [1,3,F,H,W] in [0,1]; camera_embedding
+        [1,6,F,H,W]; clip_image_embeds [1,768] or [1,1,768].  The reference banks must already be on
+        the denoising UNet (ReferenceAttentionControl.update, or engine.set_reference_banks)."""
+        dev = hvlib.require_gpu()
+        L = hvlib.load()
+        unet = self.denoising_unet
+        if self.shard is not None and unet._engine is None:
+            from .engine import UNet3DEngine
+
+            unet._engine = UNet3DEngine(unet, shard=self.shard)
+        eng = unet.engine()
+        do_cfg = guidance_scale > 1.0
+        rep = 2 if do_cfg else 1
+        sched = self.scheduler
+        sched.set_timesteps(num_inference_steps)
+        timesteps = [int(t) for t in sched.timesteps.tolist()]
+        latents = latents.to(device=dev, dtype=F32).contiguous()
+        _, C, F_, h, w = latents.shape
+        e = clip_image_embeds.reshape(1, 1, -1).to(dev)
+        ehs = torch.cat([torch.zeros_like(e), e], dim=0) if do_cfg else e
+        eng._banks_from_modules()
+        eng.set_encoder_hidden_states(ehs)
+
+        windows = list(get_context_scheduler(context_schedule)(0, num_inference_steps, F_, context_frames,
+                                                                context_stride, context_overlap))
+        world = 1 if self.shard is None else self.shard.world
+        rank = 0 if self.shard is None else self.shard.rank
+        plans = []  # per window: (frame index tensor of this rank, local frame count)
+        for c in windows:
+            if len(c) % world:
+                raise ValueError(f"window of {len(c)} frames does not shard over {world} ranks")
+            fl = len(c) // world
+            mine = c[rank * fl:(rank + 1) * fl]
+            plans.append((torch.tensor(mine, dtype=torch.int32, device=dev), fl, rank * fl))
+        conds = []
+        for c, (_, fl, f0) in zip(windows, plans):
+            conds.extend(self.build_conditioning(pose_cond_tensor.to(dev), camera_embedding.to(dev), [c], f0, fl))
+
+        acc = torch.zeros(rep, C, F_, h, w, dtype=F32, device=dev)
+        counter = torch.zeros(F_, dtype=F32, device=dev)
+        t_dev = torch.zeros(rep, dtype=F32, device=dev)
+        coeffs = torch.zeros(5, dtype=F32, device=dev)
+        t_table = torch.tensor(timesteps, dtype=F32, device=dev)
+        c_table = torch.tensor([[guidance_scale, *sched.step_coefficients(t)] for t in timesteps], dtype=F32, device=dev)
+        x_in = [eng.ws.get(f"pipe_x_in_{i}", (rep * fl, h, w, 32)) for i, (_, fl, _) in enumerate(plans)]
+        for x in x_in:
+            x.zero_()
+
+        def one_step():
+            st = hvlib.current_stream()
+            for (frames, fl, _), cond, xi in zip(plans, conds, x_in):
+                ops.pack_ncfhw(L, st, latents, xi, rep=rep, frames=frames)
+                y = eng.forward_nhwc(xi, t_dev, cond, B=rep, F=fl)
+                ops.accumulate_window(L, st, y, rep, C, frames, acc, counter)
+            if world > 1:
+                self.shard.dist.all_reduce(acc, group=self.shard.group)
+                self.shard.dist.all_reduce(counter, group=self.shard.group)
+            ops.cfg_ddim_step(L, st, latents, acc, counter, rep, coeffs)
+
+        graph = None
+        n_steps = len(timesteps) if max_steps is None else min(max_steps, len(timesteps))
+        for i in range(n_steps):
+            t_dev.copy_(t_table[i].expand(rep))
+            coeffs.copy_(c_table[i])
+            if use_graph and world == 1 and i >= 1:
+                if graph is None:
+                    # step 0 ran eagerly (allocates every workspace buffer); capture step 1 and replay it
+                    graph = self._capture(one_step)
+                else:
+                    L.call("hv_graph_launch", graph, hvlib.current_stream())
+            else:
+                one_step()
+            if step_hook is not None:
+                step_hook(i)
+            if callback is not None and i % callback_steps == 0:
+                callback(i, timesteps[i], latents)
+        if graph is not None:
+            torch.cuda.current_stream().synchronize()
+            L.call("hv_graph_destroy", graph)
+        return latents
+
+    def _capture(self, fn):
+        """Capture `fn`'s launches on a side stream into a HIP graph, launch it once, return the exec."""
+        import ctypes
+
+        L = hvlib.load()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            L.call("hv_graph_begin", side.cuda_stream)
+            fn()
+            gx = ctypes.c_void_p()
+            L.call("hv_graph_end", side.cuda_stream, ctypes.byref(gx))
+        torch.cuda.current_stream().wait_stream(side)
+        L.call("hv_graph_launch", gx, hvlib.current_stream())
+        return gx
+
+    # ---- reference-compatible entry point ----------------------------------------------------------
+    @torch.no_grad()
+    def __call__(self, ref_image, pose_images, camera_embedding, width, height, video_length, num_inference_steps,
+                 guidance_scale, num_images_per_prompt=1, eta: float = 0.0,
+                 generator: Optional[Union[torch.Generator, List[torch.Generator]]] = None,
+                 output_type: Optional[str] = "tensor", return_dict: bool = True,
+                 callback: Optional[Callable[[int, int, torch.FloatTensor], None]] = None,
+                 callback_steps: Optional[int] = 1, context_schedule="uniform", context_frames=24, context_stride=1,
+                 context_overlap=4, context_batch_size=1, interpolation_factor=1, **kwargs):
+        if eta != 0.0:
+            raise NotImplementedError("eta > 0 is not supported (the reference always samples with eta = 0)")
+        if interpolation_factor >= 2:
+            raise NotImplementedError("latent interpolation (interpolation_factor >= 2) is outside the denoising path")
+        device = torch.device("cuda") if torch.cuda.is_available() else torch.device("cpu")
+        if device.type != "cuda":
+            raise RuntimeError("Pose2VideoPipeline needs a ROCm GPU: the denoising path has no CPU fallback")
+        do_cfg = guidance_scale > 1.0
+        batch_size = 1
+        # CLIP image embedding (pipeline :380-392)
+        clip_image = _clip_preprocess(ref_image)
+        clip_embeds = self.image_encoder(clip_image.to(device, dtype=self.image_encoder.dtype)).image_embeds
+        ehs = clip_embeds.unsqueeze(1)
+        if do_cfg:
+            ehs = torch.cat([torch.zeros_like(ehs), ehs], dim=0)
+        writer = ReferenceAttentionControl(self.reference_unet, do_classifier_free_guidance=do_cfg, mode="write",
+                                           batch_size=batch_size, fusion_blocks="full")
+        reader = ReferenceAttentionControl(self.denoising_unet, do_classifier_free_guidance=do_cfg, mode="read",
+                                           batch_size=batch_size, fusion_blocks="full")
+        latents = self.prepare_latents(batch_size * num_images_per_prompt, self.denoising_unet.in_channels, width,
+                                       height, video_length, clip_embeds.dtype, device, generator)
+        ref_tensor = _pil_to_tensor(ref_image, height, width, normalize=True).to(device=device, dtype=self.vae.dtype)
+        ref_latents = self.vae.encode(ref_tensor).latent_dist.mean * 0.18215
+        pose_cond = _pil_to_tensor(list(pose_images), height, width, normalize=False)  # [F,3,H,W]
+        pose_cond = pose_cond.permute(1, 0, 2, 3)[None]  # [1,3,F,H,W]
+        camera_embedding = camera_embedding.to(device=device, dtype=F32)
+        assert camera_embedding.ndim == 5
+        # ReferenceNet write pass at t = 0, then banks -> reader (pipeline :470-480)
+        self.reference_unet(ref_latents.repeat(2 if do_cfg else 1, 1, 1, 1), torch.zeros((), device=device),
+                            encoder_hidden_states=ehs, return_dict=False)
+        reader.update(writer)
+        latents = self.denoise(latents, pose_cond, camera_embedding, clip_embeds, num_inference_steps, guidance_scale,
+                               context_schedule=context_schedule, context_frames=context_frames,
+                               context_stride=context_stride, context_overlap=context_overlap, callback=callback,
+                               callback_steps=callback_steps or 1)
+        reader.clear()
+        writer.clear()
+        images = self.decode_latents(latents)
+        if output_type == "tensor":
+            images = torch.from_numpy(images)
+        if not return_dict:
+            return images
+        return Pose2VideoPipelineOutput(videos=images)

@@ -1,0 +1,128 @@
+"""DDIM scheduler of the CamAnimate pipeline and the context-window scheduler.
+
+ * `DDIMScheduler`: the subset of diffusers' DDIMScheduler that configs/inference/inference_v2.yaml:
+   24-33 selects (linear betas 0.00085 -> 0.012, steps_offset 1, clip_sample False, v_prediction,
+   rescale_betas_zero_snr, timestep_spacing "trailing", set_alpha_to_one) -- SURVEY.md appendix C.
+   Only host-side scalars live here; the tensor update itself is hv_cfg_ddim_step.
+ * `uniform` / `ordered_halving` / `get_context_scheduler`:
+   /root/reference/src/pipelines/context.py:7-49 (exact integer semantics).
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass
+from typing import Callable, List, Optional
+
+import numpy as np
+import torch
+
+
+@dataclass
+class DDIMSchedulerOutput:
+    prev_sample: torch.Tensor
+
+
+class DDIMScheduler:
+    order = 1
+    init_noise_sigma = 1.0
+
+    def __init__(self, num_train_timesteps: int = 1000, beta_start: float = 0.0001, beta_end: float = 0.02,
+                 beta_schedule: str = "linear", clip_sample: bool = True, set_alpha_to_one: bool = True,
+                 steps_offset: int = 0, prediction_type: str = "epsilon", rescale_betas_zero_snr: bool = False,
+                 timestep_spacing: str = "leading", **unused):
+        if beta_schedule != "linear":
+            raise NotImplementedError(beta_schedule)
+        if prediction_type not in ("v_prediction", "epsilon"):
+            raise NotImplementedError(prediction_type)
+        if clip_sample:
+            raise NotImplementedError("clip_sample=True is not used by the CamAnimate configs")
+        self.num_train_timesteps = num_train_timesteps
+        self.prediction_type = prediction_type
+        self.timestep_spacing = timestep_spacing
+        self.steps_offset = steps_offset
+        betas = torch.linspace(beta_start, beta_end, num_train_timesteps, dtype=torch.float32)
+        if rescale_betas_zero_snr:
+            abar = torch.cumprod(1.0 - betas, dim=0)
+            s = abar.sqrt()
+            s0, sT = s[0].clone(), s[-1].clone()
+            s = (s - sT) * s0 / (s0 - sT)
+            abar = s**2
+            alphas = torch.cat([abar[0:1], abar[1:] / abar[:-1]])
+            betas = 1 - alphas
+        self.betas = betas
+        self.alphas_cumprod = torch.cumprod(1.0 - betas, dim=0)
+        self.final_alpha_cumprod = torch.tensor(1.0) if set_alpha_to_one else self.alphas_cumprod[0]
+        self.num_inference_steps: Optional[int] = None
+        self.timesteps = torch.from_numpy(np.arange(0, num_train_timesteps)[::-1].copy().astype(np.int64))
+
+    def set_timesteps(self, num_inference_steps: int, device=None):
+        self.num_inference_steps = num_inference_steps
+        T = self.num_train_timesteps
+        if self.timestep_spacing == "trailing":
+            ts = np.round(np.arange(T, 0, -T / num_inference_steps)) - 1
+        elif self.timestep_spacing == "leading":
+            ts = (np.arange(0, num_inference_steps) * (T // num_inference_steps)).round()[::-1].copy() + self.steps_offset
+        else:
+            raise NotImplementedError(self.timestep_spacing)
+        self.timesteps = torch.from_numpy(ts.astype(np.int64)).to(device) if device is not None else torch.from_numpy(
+            ts.astype(np.int64))
+
+    def scale_model_input(self, sample, timestep=None):
+        return sample
+
+    def step_coefficients(self, timestep: int):
+        """sqrt(a_t), sqrt(1-a_t), sqrt(a_prev), sqrt(1-a_prev) as python floats (fp32 arithmetic)."""
+        t = int(timestep)
+        prev = t - self.num_train_timesteps // self.num_inference_steps
+        a = self.alphas_cumprod[t]
+        ap = self.alphas_cumprod[prev] if prev >= 0 else self.final_alpha_cumprod
+        return float(a.sqrt()), float((1 - a).sqrt()), float(ap.sqrt()), float((1 - ap).sqrt())
+
+    def step(self, model_output, timestep, sample, eta: float = 0.0, **unused) -> DDIMSchedulerOutput:
+        """Tensor form (any device, plain torch elementwise math) kept for API compatibility with
+        callers outside the fused pipeline; the pipeline itself uses hv_cfg_ddim_step."""
+        if eta != 0.0:
+            raise NotImplementedError("eta > 0 (stochastic DDIM) is not used by the CamAnimate pipeline")
+        sa, s1a, sap, s1ap = self.step_coefficients(int(timestep))
+        if self.prediction_type == "v_prediction":
+            x0 = sa * sample - s1a * model_output
+            eps = sa * model_output + s1a * sample
+        else:
+            eps = model_output
+            x0 = (sample - s1a * eps) / sa
+        return DDIMSchedulerOutput(prev_sample=sap * x0 + s1ap * eps)
+
+
+# ---------------------------------------------------------------------------------- context windows
+def ordered_halving(val):
+    bin_str = f"{val:064b}"
+    return int(bin_str[::-1], 2) / (1 << 64)
+
+
+def uniform(step: int = ..., num_steps: Optional[int] = None, num_frames: int = ..., context_size: Optional[int] = None,
+            context_stride: int = 3, context_overlap: int = 4, closed_loop: bool = True):
+    if num_frames <= context_size:
+        yield list(range(num_frames))
+        return
+    context_stride = min(context_stride, int(np.ceil(np.log2(num_frames / context_size))) + 1)
+    for context_step in 1 << np.arange(context_stride):
+        pad = int(round(num_frames * ordered_halving(step)))
+        for j in range(
+            int(ordered_halving(step) * context_step) + pad,
+            num_frames + pad + (0 if closed_loop else -context_overlap),
+            (context_size * context_step - context_overlap),
+        ):
+            yield [e % num_frames for e in range(j, j + context_size * context_step, context_step)]
+
+
+def get_context_scheduler(name: str) -> Callable:
+    if name == "uniform":
+        return uniform
+    raise ValueError(f"Unknown context_overlap policy {name}")
+
+
+def get_total_steps(scheduler, timesteps: List[int], num_steps: Optional[int] = None, num_frames: int = ...,
+                    context_size: Optional[int] = None, context_stride: int = 3, context_overlap: int = 4,
+                    closed_loop: bool = True):
+    return sum(len(list(scheduler(i, num_steps, num_frames, context_size, context_stride, context_overlap)))
+               for i in range(len(timesteps)))

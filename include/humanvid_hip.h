@@ -185,8 +185,9 @@ int hv_temporal_attention(const hv_temporal_attention_params* p, void* stream);
 
 /* ---- layout adaptors at the drop-in boundary ----------------------------------------------
  * [b][c][f][h][w] (fp32 or bf16, the reference's layout) <-> [(rep b) f][h][w][cpad] bf16.     */
-int hv_pack_ncfhw(const void* src, int src_is_bf16, int B, int C, int F, int H, int W, int rep, uint16_t* dst,
-                  int Cpad, void* stream);
+/* frames: optional DEVICE int[F] of source frame indices (context window / frame shard); NULL = 0..F-1 */
+int hv_pack_ncfhw(const void* src, int src_is_bf16, int B, int C, int Fsrc, int H, int W, const int* frames, int F,
+                  int rep, uint16_t* dst, int Cpad, void* stream);
 int hv_unpack_nhwc(const uint16_t* src, int ldc, int B, int C, int F, int H, int W, void* dst, int dst_is_bf16,
                    void* stream);
 /* nn.PixelUnshuffle(r) on [b][c][f][H][W] fp32 -> [(b f)][H/r][W/r][c*r*r] bf16

@@ -74,7 +74,7 @@ def test_unet_matches_oracle(geom):
         cfg = O.tiny_unet3d_cfg(down_block_types=("CrossAttnDownBlock3D", "CrossAttnDownBlock3D", "DownBlock3D"),
                                 up_block_types=("UpBlock3D", "CrossAttnUpBlock3D", "CrossAttnUpBlock3D"),
                                 block_out_channels=(320, 640, 1280), motion_module_resolutions=(1, 2, 4, 8))
-        f, hh, ww = 3, 8, 8
+        f, hh, ww = 3, 16, 16
     elif geom == "tiny_f8":
         cfg, f, hh, ww = O.tiny_unet3d_cfg(), 8, 12, 8
     else:

@@ -268,7 +268,7 @@ static inline void hv_attention_launch_t(const hv_attention_params& p, hipStream
 }
 
 // tuning knobs (hv_set_tuning): queries-per-wave fragment count per head dim
-static int g_hv_attn_qt40 = 4, g_hv_attn_qt160 = 2;
+static int g_hv_attn_qt40 = 2, g_hv_attn_qt160 = 2;
 
 static inline int hv_attention_launch(const hv_attention_params& p, hipStream_t stream) {
     if (p.L1 <= 0 || p.L1 % 8 != 0 || p.L2 % 8 != 0 || p.Lq <= 0) return -1;

@@ -10,43 +10,56 @@
 // Design (MI355X, head dims 40 / 80 / 160 = SD-1.5 widths 320/640/1280 over 8 heads):
 //  * S^T = K.Q^T with mfma_f32_16x16x32_bf16 (A = key rows, B = query rows): a lane then holds
 //    scores of ONE query (column lane&15) for 4 keys per fragment, so the softmax row reduction is
-//    16 in-register values + two cross-quad shuffles, and the running max / sum / rescale factor of
-//    a query live in the same lane as its O^T accumulator column (no broadcast needed).
+//    16 in-register values + two cross-quad shuffles, and the running max / rescale factor of a query
+//    live in the same lane as its O^T accumulator column (no broadcast needed).
+//  * the head dim is not a multiple of 32 for d = 40 / 80: the remainder of the QK^T reduction uses
+//    the 16-deep mfma_f32_16x16x16_bf16 so d = 40 costs 48 (not 64) and d = 80 costs exactly 80.
 //  * key rows are staged into LDS in a permuted order (bits 2 and 3-4 rotated) so that the
 //    probabilities of two adjacent score fragments concatenate, in-register, into the B operand of
 //    O^T += V^T.P^T with natural key order -- no cross-lane traffic between the two matmuls.
 //  * V arrives already transposed ([channel][token], written by the QKV GEMM epilogue), so both
-//    K and V^T fragments are single 16-byte LDS reads; LDS rows are padded to an odd number of
-//    16-byte slots.
-//  * head dim is zero-padded in LDS/registers only (40->64 for the QK^T reduction, 40->48 rows of
-//    V^T); HBM traffic is unpadded.
+//    K and V^T fragments are single LDS vector reads; LDS rows are padded to an odd number of
+//    16-byte slots (conflict-free ds_read_b128).
+//  * d = 40: V^T is padded to 48 rows; the first padding row is filled with ones, so the softmax
+//    denominator falls out of the P.V MFMA (and is rescaled with it) instead of 16 VALU adds per tile.
+//  * the O^T rescale is skipped for tiles in which no query of the wave raised its running maximum
+//    (wave-uniform test); the ragged-tail masking is a separate template instance.
 //  * K/V tiles (64 keys) are double-buffered through registers, one barrier per tile; online
-//    softmax in the exp2 domain; fp32 accumulation throughout.
+//    softmax in the exp2 domain; fp32 accumulation; register budget sized for >= 2 workgroups per CU.
 #pragma once
 #include "hv_common.h"
 #include "humanvid_hip.h"
 
 template <int D, int QT>
 struct HvAttnGeom {
-    static constexpr int DS = (D + 31) / 32;   // 32-wide reduction steps of QK^T
-    static constexpr int DT = (D + 15) / 16;   // 16-row fragments of V^T / O^T
-    static constexpr int DK = 32 * DS;
+    static constexpr int NFULL = D / 32;              // 32-deep QK^T steps
+    static constexpr bool TAIL = (D % 32) != 0;       // + one 16-deep step
+    static constexpr int DT = (D + 15) / 16;          // 16-row fragments of V^T / O^T
+    static constexpr int DK = 32 * NFULL + (TAIL ? 16 : 0);
     static constexpr int DV = 16 * DT;
-    static constexpr int KRS = DK * 2 + 16;    // K row stride in LDS (bytes), odd multiple of 16
-    static constexpr int VRS = 64 * 2 + 16;    // V^T row stride (64 keys)
+    static constexpr bool ONES = DV > D;              // spare V^T row available for the denominator
+    static constexpr int KRS = DK * 2 + 16;           // K row stride in LDS (bytes), odd multiple of 16
+    static constexpr int VRS = 64 * 2 + 16;           // V^T row stride (64 keys)
     static constexpr int KBYTES = 64 * KRS;
     static constexpr int VBYTES = DV * VRS;
-    static constexpr int KCH = 64 * (D / 8);   // 16-byte chunks of a K tile
-    static constexpr int VCH = D * 8;          // 16-byte chunks of a V^T tile
+    static constexpr int KCH = 64 * (D / 8);          // 16-byte chunks of a K tile
+    static constexpr int VCH = D * 8;                 // 16-byte chunks of a V^T tile
     static constexpr int KIT = (KCH + 255) / 256;
     static constexpr int VIT = (VCH + 255) / 256;
-    static constexpr int BQ = 4 * 16 * QT;     // queries per workgroup
+    static constexpr int BQ = 4 * 16 * QT;            // queries per workgroup
 };
 
+// waves per SIMD the register allocator is asked to fit (LDS allows 5 / 3 / 1 workgroups per CU for
+// d = 40 / 80 / 160): more resident waves let one wave's softmax VALU overlap another's MFMA
 template <int D, int QT>
-__global__ __launch_bounds__(256) void hv_attention_kernel(hv_attention_params p) {
+struct HvAttnOcc {
+    static constexpr int value = (D == 40 && QT == 2) ? 4 : ((D == 80 && QT == 2) ? 2 : 1);
+};
+
+template <int D, int QT, bool MASK>
+__global__ __launch_bounds__(256, (HvAttnOcc<D, QT>::value)) void hv_attention_kernel(hv_attention_params p) {
     using G = HvAttnGeom<D, QT>;
-    constexpr int DS = G::DS, DT = G::DT;
+    constexpr int NFULL = G::NFULL, DT = G::DT;
     __shared__ __attribute__((aligned(16))) unsigned char smem[2 * (G::KBYTES + G::VBYTES)];
     unsigned char* Ks = smem;
     unsigned char* Vs = smem + 2 * G::KBYTES;
@@ -68,24 +81,44 @@ __global__ __launch_bounds__(256) void hv_attention_kernel(hv_attention_params p
     const int T2 = sel >= 0 ? (p.L2 + 63) / 64 : 0;
     const int ntiles = T1 + T2;
 
-    // zero the padding of both LDS buffers once (never overwritten by the tile stores)
+    // zero the padding of both LDS buffers once (never overwritten by the tile stores); the first
+    // spare V^T row becomes a row of ones (bf16 1.0 = 0x3F80) -> denominator via the P.V MFMA
     for (int i = tid; i < 2 * (G::KBYTES + G::VBYTES) / 16; i += 256) {
         u32x4 z = {0u, 0u, 0u, 0u};
         hv_st16(smem + i * 16, z);
     }
+    __syncthreads();
+    if (G::ONES) {
+        for (int i = tid; i < 2 * 8; i += 256) {
+            u32x4 one = {0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u};
+            hv_st16(Vs + (i >> 3) * G::VBYTES + D * G::VRS + (i & 7) * 16, one);
+        }
+    }
 
     // ---- query fragments (B operand of S^T = K.Q^T), resident for the whole kernel
-    bf16x8 qf[QT][DS];
+    bf16x8 qf[QT][NFULL > 0 ? NFULL : 1];
+    bf16x4 qtail[QT];
     const int q_wave = qb * G::BQ + wave * 16 * QT;
 #pragma unroll
     for (int qt = 0; qt < QT; ++qt) {
         const int q = q_wave + 16 * qt + r16;
+        const bf16_t* qrow = p.Q + ((long)img * p.Lq + q) * p.ldq + head * D;
 #pragma unroll
-        for (int s = 0; s < DS; ++s) {
-            const int d = 32 * s + 8 * quad;
+        for (int s = 0; s < NFULL; ++s) {
             u32x4 v = {0u, 0u, 0u, 0u};
-            if (q < p.Lq && d + 8 <= D) v = hv_ld16(p.Q + ((long)img * p.Lq + q) * p.ldq + head * D + d);
+            if (q < p.Lq) v = hv_ld16(qrow + 32 * s + 8 * quad);
             qf[qt][s] = hv_as_bf16x8(v);
+        }
+        if (G::TAIL) {
+            const int d = 32 * NFULL + 4 * quad;
+            u32x2 v = {0u, 0u};
+            if (q < p.Lq && d + 4 <= D) v = hv_ld8(qrow + d);
+            union {
+                u32x2 u;
+                bf16x4 s;
+            } c;
+            c.u = v;
+            qtail[qt] = c.s;
         }
     }
 
@@ -105,7 +138,7 @@ __global__ __launch_bounds__(256) void hv_attention_kernel(hv_attention_params p
             u32x4 v = {0u, 0u, 0u, 0u};
             if (id < G::KCH) {
                 const int r = id / (D / 8), c = id % (D / 8);
-                if (kv0 + r < L) v = hv_ld16(Kp + (rowbase + kv0 + r) * ldk + head * D + c * 8);
+                if (!MASK || kv0 + r < L) v = hv_ld16(Kp + (rowbase + kv0 + r) * ldk + head * D + c * 8);
             }
             kreg[i] = v;
         }
@@ -115,7 +148,7 @@ __global__ __launch_bounds__(256) void hv_attention_kernel(hv_attention_params p
             u32x4 v = {0u, 0u, 0u, 0u};
             if (id < G::VCH) {
                 const int d = id >> 3, c = id & 7;
-                if (kv0 + c * 8 < L) v = hv_ld16(Vp + (long)(head * D + d) * ldv + rowbase + kv0 + c * 8);
+                if (!MASK || kv0 + c * 8 < L) v = hv_ld16(Vp + (long)(head * D + d) * ldv + rowbase + kv0 + c * 8);
             }
             vreg[i] = v;
         }
@@ -150,16 +183,13 @@ __global__ __launch_bounds__(256) void hv_attention_kernel(hv_attention_params p
     const float c2 = p.scale * 1.44269504089f;
 
     load_tile(0);
-    __syncthreads();  // padding zero-fill complete before the first tile store
+    __syncthreads();  // LDS initialisation complete before the first tile store
     for (int ti = 0; ti < ntiles; ++ti) {
         const int buf = ti & 1;
         store_tile(buf);
         __syncthreads();
         if (ti + 1 < ntiles) load_tile(ti + 1);
-        const bool bank = ti >= T1;
-        const int kv0 = (bank ? ti - T1 : ti) * 64;
-        const int L = bank ? p.L2 : p.L1;
-        const unsigned char* kb = Ks + buf * G::KBYTES + r16 * G::KRS + quad * 16;
+        const unsigned char* kb = Ks + buf * G::KBYTES + r16 * G::KRS;
         const unsigned char* vb = Vs + buf * G::VBYTES + r16 * G::VRS + quad * 16;
 
         // ---- S^T fragments: sacc[kvf][qt], lane = (query r16, quad), reg r <-> key
@@ -170,53 +200,71 @@ __global__ __launch_bounds__(256) void hv_attention_kernel(hv_attention_params p
 #pragma unroll
             for (int qt = 0; qt < QT; ++qt) sacc[kvf][qt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int s = 0; s < DS; ++s) {
-                const bf16x8 kf = hv_as_bf16x8(hv_ld16(kb + (16 * kvf) * G::KRS + s * 64));
+            for (int s = 0; s < NFULL; ++s) {
+                const bf16x8 kf = hv_as_bf16x8(hv_ld16(kb + (16 * kvf) * G::KRS + s * 64 + quad * 16));
 #pragma unroll
                 for (int qt = 0; qt < QT; ++qt)
                     sacc[kvf][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[qt][s], sacc[kvf][qt], 0, 0, 0);
             }
+            if (G::TAIL) {
+                union {
+                    u32x2 u;
+                    bf16x4 s;
+                } kt;
+                kt.u = hv_ld8(kb + (16 * kvf) * G::KRS + NFULL * 64 + quad * 8);
+#pragma unroll
+                for (int qt = 0; qt < QT; ++qt)
+                    sacc[kvf][qt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(kt.s, qtail[qt], sacc[kvf][qt], 0, 0, 0);
+            }
         }
-        // ---- mask the ragged tail of this source
-        if (kv0 + 64 > L) {
+        // ---- mask the ragged tail of this source (MASK instances only)
+        if (MASK) {
+            const bool bank = ti >= T1;
+            const int kv0 = (bank ? ti - T1 : ti) * 64;
+            const int L = bank ? p.L2 : p.L1;
+            if (kv0 + 64 > L) {
 #pragma unroll
-            for (int kvf = 0; kvf < 4; ++kvf)
+                for (int kvf = 0; kvf < 4; ++kvf)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int kv = kv0 + 32 * (kvf >> 1) + 8 * quad + 4 * (kvf & 1) + r;
-                    if (kv >= L) {
+                    for (int r = 0; r < 4; ++r) {
+                        const int kv = kv0 + 32 * (kvf >> 1) + 8 * quad + 4 * (kvf & 1) + r;
+                        if (kv >= L) {
 #pragma unroll
-                        for (int qt = 0; qt < QT; ++qt) sacc[kvf][qt][r] = -INFINITY;
+                            for (int qt = 0; qt < QT; ++qt) sacc[kvf][qt][r] = -INFINITY;
+                        }
                     }
-                }
+            }
         }
         // ---- online softmax (exp2 domain) and P^T fragments
         bf16x8 pf[QT][2];
 #pragma unroll
         for (int qt = 0; qt < QT; ++qt) {
-            float mx = -INFINITY;
+            float mx = fmaxf(fmaxf(sacc[0][qt][0], sacc[0][qt][1]), fmaxf(sacc[0][qt][2], sacc[0][qt][3]));
 #pragma unroll
-            for (int kvf = 0; kvf < 4; ++kvf)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) mx = fmaxf(mx, sacc[kvf][qt][r]);
+            for (int kvf = 1; kvf < 4; ++kvf)
+                mx = fmaxf(fmaxf(fmaxf(mx, sacc[kvf][qt][0]), fmaxf(sacc[kvf][qt][1], sacc[kvf][qt][2])),
+                           sacc[kvf][qt][3]);
             mx = fmaxf(mx, __shfl_xor(mx, 16));
             mx = fmaxf(mx, __shfl_xor(mx, 32));
-            const float mnew = fmaxf(mrun[qt], mx * c2);
-            const float alpha = __builtin_amdgcn_exp2f(mrun[qt] - mnew);
+            const float mold = mrun[qt];
+            const float mnew = fmaxf(mold, mx * c2);
             mrun[qt] = mnew;
-            float psum = 0.f;
             float pv[4][4];
+            float psum = 0.f;
 #pragma unroll
             for (int kvf = 0; kvf < 4; ++kvf)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float e = __builtin_amdgcn_exp2f(sacc[kvf][qt][r] * c2 - mnew);
-                    pv[kvf][r] = e;
-                    psum += e;
+                    pv[kvf][r] = __builtin_amdgcn_exp2f(sacc[kvf][qt][r] * c2 - mnew);
+                    if (!G::ONES) psum += pv[kvf][r];
                 }
-            lrun[qt] = lrun[qt] * alpha + psum;
+            if (__any(mnew > mold)) {  // some query of this wave raised its maximum: rescale the accumulators
+                const float alpha = __builtin_amdgcn_exp2f(mold - mnew);
+                if (!G::ONES) lrun[qt] *= alpha;
 #pragma unroll
-            for (int dt = 0; dt < DT; ++dt) oacc[qt][dt] *= alpha;
+                for (int dt = 0; dt < DT; ++dt) oacc[qt][dt] *= alpha;
+            }
+            if (!G::ONES) lrun[qt] += psum;
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
                 u32x4 w = {hv_pack2(pv[2 * ks][0], pv[2 * ks][1]), hv_pack2(pv[2 * ks][2], pv[2 * ks][3]),
@@ -225,7 +273,7 @@ __global__ __launch_bounds__(256) void hv_attention_kernel(hv_attention_params p
                 pf[qt][ks] = hv_as_bf16x8(w);
             }
         }
-        // ---- O^T += V^T . P^T
+        // ---- O^T += V^T . P^T   (row D of V^T is all ones when ONES: accumulates the denominator)
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
@@ -240,9 +288,15 @@ __global__ __launch_bounds__(256) void hv_attention_kernel(hv_attention_params p
     // ---- normalise and store: lane owns query r16, channels 16*dt + 4*quad + 0..3
 #pragma unroll
     for (int qt = 0; qt < QT; ++qt) {
-        float l = lrun[qt];
-        l += __shfl_xor(l, 16);
-        l += __shfl_xor(l, 32);
+        float l;
+        if (G::ONES) {
+            // denominator = O^T row D: fragment D/16, row (D%16) = 4*quad' + r  ->  lane quad' = (D%16)/4, reg (D%4)
+            l = __shfl(oacc[qt][D / 16][D % 4], ((D % 16) / 4) * 16 + r16);
+        } else {
+            l = lrun[qt];
+            l += __shfl_xor(l, 16);
+            l += __shfl_xor(l, 32);
+        }
         const float inv = 1.0f / l;
         const int q = q_wave + 16 * qt + r16;
         if (q >= p.Lq) continue;
@@ -264,10 +318,14 @@ static inline void hv_attention_launch_t(const hv_attention_params& p, hipStream
     using G = HvAttnGeom<D, QT>;
     const int total = ((p.Lq + G::BQ - 1) / G::BQ) * p.heads * p.n_images;
     const int grid = ((total + 7) / 8) * 8;
-    hv_launch(hv_attention_kernel<D, QT>, dim3(grid), dim3(256), stream, p);
+    const bool ragged = (p.L1 % 64) != 0 || (p.L2 % 64) != 0;
+    if (ragged)
+        hv_launch(hv_attention_kernel<D, QT, true>, dim3(grid), dim3(256), stream, p);
+    else
+        hv_launch(hv_attention_kernel<D, QT, false>, dim3(grid), dim3(256), stream, p);
 }
 
-// tuning knobs (hv_set_tuning): queries-per-wave fragment count per head dim
+// tuning knobs (hv_set_tuning): query fragments per wave, per head dim
 static int g_hv_attn_qt40 = 2, g_hv_attn_qt160 = 2;
 
 static inline int hv_attention_launch(const hv_attention_params& p, hipStream_t stream) {
@@ -276,8 +334,8 @@ static inline int hv_attention_launch(const hv_attention_params& p, hipStream_t 
     if (p.L2 > 0 && p.bank_sel != nullptr && (!p.K2 || !p.Vt2 || p.ldk2 % 8 || p.ldvt2 % 8)) return -1;
     switch (p.D) {
         case 40:
-            if (g_hv_attn_qt40 == 2) hv_attention_launch_t<40, 2>(p, stream);
-            else hv_attention_launch_t<40, 4>(p, stream);
+            if (g_hv_attn_qt40 == 4) hv_attention_launch_t<40, 4>(p, stream);
+            else hv_attention_launch_t<40, 2>(p, stream);
             break;
         case 80: hv_attention_launch_t<80, 2>(p, stream); break;
         case 160:

@@ -35,8 +35,33 @@ HV_DEV int hv_swz(int row, int chunk) {
     return row * (BK * 2) + ((chunk ^ ((row / RPB) % CPR)) << 4);
 }
 
+// erf with |error| < 1.5e-7 (Abramowitz & Stegun 7.1.26): one exp2 + one rcp + 5 FMA, vs ~60
+// instructions of libm erff in every GEGLU output element
+HV_DEV float hv_erf_fast(float x) {
+    const float ax = fabsf(x);
+    const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * ax);
+    float poly = 1.061405429f;
+    poly = poly * t - 1.453152027f;
+    poly = poly * t + 1.421413741f;
+    poly = poly * t - 0.284496736f;
+    poly = poly * t + 0.254829592f;
+    const float e = 1.0f - poly * t * __builtin_amdgcn_exp2f(-1.44269504089f * ax * ax);
+    return x < 0.f ? -e : e;
+}
+HV_DEV float hv_gelu_fast(float x) { return 0.5f * x * (1.0f + hv_erf_fast(x * 0.70710678118654752f)); }
+
+template <int N>
+struct HvInt {
+    static constexpr int value = N;
+};
+
+// Persistent workgroups: each walks a strided list of output tiles of its XCD's contiguous tile
+// range; the (tile, k-step) sequence is flattened so that the register prefetch (two k-tiles in
+// flight per workgroup) runs across tile boundaries and the epilogue of tile i overlaps the loads
+// of tile i+1.  The GEMMs of this path have short K (320..1280, 5..20 k-steps): without this the
+// kernel is L2-latency bound (one 32 KiB k-tile in flight per workgroup).
 template <int BK>
-__global__ __launch_bounds__(256) void hv_gemm_kernel(HvGemmParams p) {
+__global__ __launch_bounds__(256, 2) void hv_gemm_kernel(HvGemmParams p) {
     constexpr int BM = 128, BN = 128;
     constexpr int CPR = BK / 8;
     constexpr int CH_PER_THREAD = (BM * CPR) / 256;  // chunks of one operand tile per thread
@@ -50,43 +75,55 @@ __global__ __launch_bounds__(256) void hv_gemm_kernel(HvGemmParams p) {
     const int wm = wave & 1, wn = wave >> 1;
     const int r16 = lane & 15, quad = lane >> 4;
 
-    // XCD-aware tile mapping: all N-tiles of one M-panel stay on the XCD that dispatched them
+    // XCD-aware persistent tile walk: XCD x owns tiles [x*per_xcd, (x+1)*per_xcd); its workgroups
+    // take consecutive tiles (all N-tiles of an M-panel run together and share the panel in L2)
     const int tiles_n = (p.N + BN - 1) / BN, tiles_m = (p.M + BM - 1) / BM;
     const int total = tiles_n * tiles_m;
-    const int cpx = gridDim.x / 8;
-    const int t = (blockIdx.x % 8) * cpx + blockIdx.x / 8;
-    if (t >= total) return;
-    const int m0 = (t / tiles_n) * BM, n0 = (t % tiles_n) * BN;
-
-    u32x4 xr[CH_PER_THREAD], wr[CH_PER_THREAD];
+    const int wg_per_xcd = gridDim.x / 8;
+    const int xcd = blockIdx.x % 8, wg = blockIdx.x / 8;
+    const int per_xcd = (total + 7) / 8;
+    const int t_begin = xcd * per_xcd;
+    const int t_end = min(total, t_begin + per_xcd);
+    const int first = t_begin + wg;
+    if (first >= t_end) return;
+    const int my_tiles = (t_end - first + wg_per_xcd - 1) / wg_per_xcd;
     const int nk = p.K / BK;
+    const int nsteps = my_tiles * nk;
 
-    auto load_tile = [&](int kt) {
-        const int k0 = kt * BK;
+    u32x4 xr[2][CH_PER_THREAD], wr[2][CH_PER_THREAD];
+
+    auto load_step = [&](int s, auto SET) __attribute__((always_inline)) {
+        constexpr int R = decltype(SET)::value;
+        const int ti = first + (s / nk) * wg_per_xcd;
+        const int m0 = (ti / tiles_n) * BM, n0 = (ti % tiles_n) * BN;
+        const int k0 = (s % nk) * BK;
 #pragma unroll
         for (int i = 0; i < CH_PER_THREAD; ++i) {
             const int id = tid + 256 * i;
             const int row = id / CPR, c = id % CPR;
             const int m = m0 + row, n = n0 + row, k = k0 + c * 8;
             u32x4 z = {0u, 0u, 0u, 0u};
-            xr[i] = z;
-            wr[i] = z;
+            xr[R][i] = z;
+            wr[R][i] = z;
             if (m < p.M) {
                 const bf16_t* src = (p.X2 != nullptr && k >= p.K1) ? p.X2 + (long)m * p.ldx2 + (k - p.K1)
                                                                    : p.X + (long)m * p.ldx + k;
-                xr[i] = hv_ld16(src);
+                xr[R][i] = hv_ld16(src);
             }
-            if (n < p.N) wr[i] = hv_ld16(p.W + (long)n * p.K + k);
+            if (n < p.N) wr[R][i] = hv_ld16(p.W + (long)n * p.K + k);
         }
     };
 
-    auto store_tile = [&](int kt, int buf) {
-        const int k0 = kt * BK;
+    auto store_step = [&](int s, auto SET) __attribute__((always_inline)) {
+        constexpr int R = decltype(SET)::value;  // register set == LDS buffer (s & 1)
+        const int ti = first + (s / nk) * wg_per_xcd;
+        const int m0 = (ti / tiles_n) * BM;
+        const int k0 = (s % nk) * BK;
 #pragma unroll
         for (int i = 0; i < CH_PER_THREAD; ++i) {
             const int id = tid + 256 * i;
             const int row = id / CPR, c = id % CPR;
-            u32x4 xv = xr[i];
+            u32x4 xv = xr[R][i];
             if (p.pro_scale != nullptr || p.pro_act != HV_ACT_NONE) {
                 const int m = m0 + row;
                 if (m < p.M) {
@@ -109,25 +146,23 @@ __global__ __launch_bounds__(256) void hv_gemm_kernel(HvGemmParams p) {
                     xv = hv_pack8(f);
                 }
             }
-            hv_st16(Xs + buf * TILE_BYTES + hv_swz<BK>(row, c), xv);
-            hv_st16(Ws + buf * TILE_BYTES + hv_swz<BK>(row, c), wr[i]);
+            hv_st16(Xs + R * TILE_BYTES + hv_swz<BK>(row, c), xv);
+            hv_st16(Ws + R * TILE_BYTES + hv_swz<BK>(row, c), wr[R][i]);
         }
     };
 
     f32x4 acc[4][4];  // [nf][mf]
+    auto clear_acc = [&]() __attribute__((always_inline)) {
 #pragma unroll
-    for (int a = 0; a < 4; ++a)
+        for (int a = 0; a < 4; ++a)
 #pragma unroll
-        for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    };
 
-    load_tile(0);
-    for (int kt = 0; kt < nk; ++kt) {
-        const int buf = kt & 1;
-        store_tile(kt, buf);
-        __syncthreads();
-        if (kt + 1 < nk) load_tile(kt + 1);
-        const unsigned char* xs = Xs + buf * TILE_BYTES;
-        const unsigned char* ws = Ws + buf * TILE_BYTES;
+    auto compute = [&](auto SET) __attribute__((always_inline)) {
+        constexpr int R = decltype(SET)::value;
+        const unsigned char* xs = Xs + R * TILE_BYTES;
+        const unsigned char* ws = Ws + R * TILE_BYTES;
 #pragma unroll
         for (int kk = 0; kk < BK / 32; ++kk) {
             bf16x8 wf[4], xf[4];
@@ -142,74 +177,94 @@ __global__ __launch_bounds__(256) void hv_gemm_kernel(HvGemmParams p) {
                 for (int mf = 0; mf < 4; ++mf)
                     acc[nf][mf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nf], xf[mf], acc[nf][mf], 0, 0, 0);
         }
-    }
+    };
 
-    // ---- epilogue: lane owns token m (column of the MFMA tile) and 4 consecutive channels n
+    // ---- epilogue of one tile: lane owns token m (column of the MFMA tile) and 4 consecutive channels n
+    auto epilogue = [&](int ti) __attribute__((always_inline)) {
+        const int m0 = (ti / tiles_n) * BM, n0 = (ti % tiles_n) * BN;
 #pragma unroll
-    for (int mf = 0; mf < 4; ++mf) {
-        const int m = m0 + 64 * wm + 16 * mf + r16;
-        if (m >= p.M) continue;
-        float mean = 0.f, rstd = 1.f;
-        if (p.row_rstd != nullptr) {
-            mean = p.row_mean[m];
-            rstd = p.row_rstd[m];
-        }
-        const float* pe_row = p.pe ? p.pe + (long)((m / p.pe_period) % p.pe_frames) * p.N : nullptr;
-        const float* rv_row = p.rowvec ? p.rowvec + (long)(m / p.rowvec_period) * p.N : nullptr;
-#pragma unroll
-        for (int nf = 0; nf < 4; ++nf) {
-            const int n = n0 + 64 * wn + 16 * nf + 4 * quad;
-            if (n >= p.N) continue;
-            float v[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float a = acc[nf][mf][r];
-                if (p.row_rstd != nullptr) a = rstd * (a - mean * p.colsum[n + r]);
-                if (p.bias != nullptr) a += p.bias[n + r];
-                if (pe_row != nullptr) a += pe_row[n + r];
-                if (rv_row != nullptr) a += rv_row[n + r];
-                v[r] = a;
+        for (int mf = 0; mf < 4; ++mf) {
+            const int m = m0 + 64 * wm + 16 * mf + r16;
+            if (m >= p.M) continue;
+            float mean = 0.f, rstd = 1.f;
+            if (p.row_rstd != nullptr) {
+                mean = p.row_mean[m];
+                rstd = p.row_rstd[m];
             }
-            if (p.geglu) {
-                // packed weight rows: [16 x h | 16 x g] blocks -> fragment pairs (even nf: h, odd nf: g)
-                acc[nf][mf] = f32x4{v[0], v[1], v[2], v[3]};
-                if ((nf & 1) == 0) continue;
-                const int no = ((n0 + 64 * wn + 16 * (nf - 1)) >> 1) + 4 * quad;
+            const float* pe_row = p.pe ? p.pe + (long)((m / p.pe_period) % p.pe_frames) * p.N : nullptr;
+            const float* rv_row = p.rowvec ? p.rowvec + (long)(m / p.rowvec_period) * p.N : nullptr;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = acc[nf - 1][mf][r] * hv_gelu_erf(v[r]);
+            for (int nf = 0; nf < 4; ++nf) {
+                const int n = n0 + 64 * wn + 16 * nf + 4 * quad;
+                if (n >= p.N) continue;
+                f32x4 v = acc[nf][mf];
+                if (p.row_rstd != nullptr) v = rstd * (v - mean * *reinterpret_cast<const f32x4*>(p.colsum + n));
+                if (p.bias != nullptr) v += *reinterpret_cast<const f32x4*>(p.bias + n);
+                if (pe_row != nullptr) v += *reinterpret_cast<const f32x4*>(pe_row + n);
+                if (rv_row != nullptr) v += *reinterpret_cast<const f32x4*>(rv_row + n);
+                if (p.geglu) {
+                    // packed weight rows: [16 x h | 16 x g] blocks -> fragment pairs (even nf: h, odd nf: g)
+                    acc[nf][mf] = v;
+                    if ((nf & 1) == 0) continue;
+                    const int no = ((n0 + 64 * wn + 16 * (nf - 1)) >> 1) + 4 * quad;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = acc[nf - 1][mf][r] * hv_gelu_fast(v[r]);
+                    if (p.residual != nullptr) {
+                        const u32x2 rr = hv_ld8(p.residual + (long)m * p.ldr + no);
+                        v[0] += hv_bf2f((bf16_t)(rr[0] & 0xffff));
+                        v[1] += hv_bf2f((bf16_t)(rr[0] >> 16));
+                        v[2] += hv_bf2f((bf16_t)(rr[1] & 0xffff));
+                        v[3] += hv_bf2f((bf16_t)(rr[1] >> 16));
+                    }
+                    u32x2 o = {hv_pack2(v[0], v[1]), hv_pack2(v[2], v[3])};
+                    hv_st8(reinterpret_cast<bf16_t*>(p.Y) + (long)m * p.ldy + no, o);
+                    continue;
+                }
                 if (p.residual != nullptr) {
-                    const u32x2 rr = hv_ld8(p.residual + (long)m * p.ldr + no);
+                    const u32x2 rr = hv_ld8(p.residual + (long)m * p.ldr + n);
                     v[0] += hv_bf2f((bf16_t)(rr[0] & 0xffff));
                     v[1] += hv_bf2f((bf16_t)(rr[0] >> 16));
                     v[2] += hv_bf2f((bf16_t)(rr[1] & 0xffff));
                     v[3] += hv_bf2f((bf16_t)(rr[1] >> 16));
                 }
-                u32x2 o = {hv_pack2(v[0], v[1]), hv_pack2(v[2], v[3])};
-                hv_st8(reinterpret_cast<bf16_t*>(p.Y) + (long)m * p.ldy + no, o);
-                continue;
-            }
-            if (p.residual != nullptr) {
-                const u32x2 rr = hv_ld8(p.residual + (long)m * p.ldr + n);
-                v[0] += hv_bf2f((bf16_t)(rr[0] & 0xffff));
-                v[1] += hv_bf2f((bf16_t)(rr[0] >> 16));
-                v[2] += hv_bf2f((bf16_t)(rr[1] & 0xffff));
-                v[3] += hv_bf2f((bf16_t)(rr[1] >> 16));
-            }
 #pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = hv_act(v[r], p.out_act);
-            if (p.Yt != nullptr && n >= p.n_split) {
+                for (int r = 0; r < 4; ++r) v[r] = hv_act(v[r], p.out_act);
+                if (p.Yt != nullptr && n >= p.n_split) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) p.Yt[(long)(n - p.n_split + r) * p.ldyt + m] = hv_f2bf(v[r]);
-            } else if (p.out_f32) {
-                *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.Y) + (long)m * p.ldy + n) =
-                    f32x4{v[0], v[1], v[2], v[3]};
-            } else {
-                u32x2 o = {hv_pack2(v[0], v[1]), hv_pack2(v[2], v[3])};
-                hv_st8(reinterpret_cast<bf16_t*>(p.Y) + (long)m * p.ldy + n, o);
+                    for (int r = 0; r < 4; ++r) p.Yt[(long)(n - p.n_split + r) * p.ldyt + m] = hv_f2bf(v[r]);
+                } else if (p.out_f32) {
+                    *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.Y) + (long)m * p.ldy + n) = v;
+                } else {
+                    u32x2 o = {hv_pack2(v[0], v[1]), hv_pack2(v[2], v[3])};
+                    hv_st8(reinterpret_cast<bf16_t*>(p.Y) + (long)m * p.ldy + n, o);
+                }
             }
         }
+    };
+
+    // one flattened step: park k-tile s in LDS, refill its registers with k-tile s+2, multiply,
+    // and finish the tile when its last k-tile has been consumed
+    auto step = [&](int s, auto SET) __attribute__((always_inline)) {
+        store_step(s, SET);
+        __syncthreads();
+        if (s + 2 < nsteps) load_step(s + 2, SET);
+        compute(SET);
+        if ((s + 1) % nk == 0) {
+            epilogue(first + (s / nk) * wg_per_xcd);
+            clear_acc();
+        }
+    };
+
+    clear_acc();
+    load_step(0, HvInt<0>());
+    if (nsteps > 1) load_step(1, HvInt<1>());
+    for (int s = 0; s < nsteps; s += 2) {
+        step(s, HvInt<0>());
+        if (s + 1 < nsteps) step(s + 1, HvInt<1>());
     }
 }
+
+static int g_hv_gemm_max_grid = 512;  // tuning knob (hv_set_tuning): persistent workgroups
 
 static inline int hv_gemm_launch(const HvGemmParams& p, hipStream_t stream) {
     if (p.M <= 0 || p.N <= 0 || p.K <= 0) return -1;
@@ -218,7 +273,9 @@ static inline int hv_gemm_launch(const HvGemmParams& p, hipStream_t stream) {
     if (p.geglu && (p.N % 32 != 0 || p.Yt != nullptr || p.out_f32)) return -1;
     if (p.Yt != nullptr && (p.n_split % 16 != 0)) return -1;
     const int tiles = ((p.N + 127) / 128) * ((p.M + 127) / 128);
-    const int grid = ((tiles + 7) / 8) * 8;
+    // persistent grid: 2 workgroups per CU (64 KiB LDS each), 256 CUs, fewer when the problem is small
+    int grid = ((tiles + 7) / 8) * 8;
+    if (grid > g_hv_gemm_max_grid) grid = g_hv_gemm_max_grid;
     hv_launch(hv_gemm_kernel<64>, dim3(grid), dim3(256), stream, p);
     return 0;
 }

@@ -3,3 +3,4 @@
 #include "hv_kernels.h"
 
 int hvk_gemm(const hv_gemm_params& p, hipStream_t s) { return hv_gemm_launch(p, s); }
+void hvk_gemm_tune(int max_grid) { g_hv_gemm_max_grid = max_grid; }

@@ -259,6 +259,19 @@ template <class T>
 inline T __shfl(T v, int lane) {
     return hvemu::shfl_idx(v, lane);
 }
+inline int __any(int pred) {
+    int out;
+    hvemu::wave_collective(&pred, sizeof(pred), &out, sizeof(out), [](hvemu::WaveState& w) {
+        int any = 0;
+        for (int l = 0; l < 64; ++l) {
+            int v;
+            memcpy(&v, w.in[l], sizeof(int));
+            any |= (v != 0);
+        }
+        for (int l = 0; l < 64; ++l) memcpy(w.out[l], &any, sizeof(int));
+    });
+    return out;
+}
 inline float __builtin_amdgcn_exp2f(float x) { return exp2f(x); }
 inline float __builtin_amdgcn_rcpf(float x) { return 1.0f / x; }
 inline float __builtin_amdgcn_rsqf(float x) { return 1.0f / sqrtf(x); }

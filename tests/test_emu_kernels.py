@@ -33,6 +33,17 @@ def test_gemm_variants(cx):
     kc.case_gemm(cx, M=96, N=96, K=64, transposed=True)
 
 
+def test_gemm_persistent_multi_tile(cx):
+    """force 8 persistent workgroups so that each walks several tiles (cross-tile prefetch path)"""
+    cx.lib.call("hv_set_tuning", 2, 8)
+    try:
+        kc.case_gemm(cx, M=600, N=320, K=128, seed=12)                 # 15 tiles, 1 or 2 per workgroup
+        kc.case_gemm(cx, M=300, N=520, K=64, seed=13, residual=False)  # single k-step per tile
+        kc.case_gemm_geglu(cx, M=300, C=64, seed=14)
+    finally:
+        cx.lib.call("hv_set_tuning", 2, 512)
+
+
 def test_gemm_prologue(cx):
     kc.case_gemm_prologue(cx)
 
@@ -65,6 +76,11 @@ def test_groupnorm(cx):
 @pytest.mark.parametrize("D", [40, 80, 160])
 def test_attention(cx, D):
     kc.case_attention(cx, D=D, n_img=2, Lq=72 if D == 40 else 40, Lb=40 if D == 40 else 72)
+
+
+def test_attention_unmasked_instances(cx):
+    kc.case_attention(cx, D=40, n_img=2, Lq=64, Lb=64)   # tile-aligned lengths: the MASK=false kernels
+    kc.case_attention(cx, D=80, n_img=2, Lq=64, Lb=64)
 
 
 @pytest.mark.parametrize("D", [40, 80, 160])

@@ -20,8 +20,6 @@
 //  * V arrives already transposed ([channel][token], written by the QKV GEMM epilogue), so both
 //    K and V^T fragments are single LDS vector reads; LDS rows are padded to an odd number of
 //    16-byte slots (conflict-free ds_read_b128).
-//  * d = 40: V^T is padded to 48 rows; the first padding row is filled with ones, so the softmax
-//    denominator falls out of the P.V MFMA (and is rescaled with it) instead of 16 VALU adds per tile.
 //  * the O^T rescale is skipped for tiles in which no query of the wave raised its running maximum
 //    (wave-uniform test); the ragged-tail masking is a separate template instance.
 //  * K/V tiles (64 keys) are double-buffered through registers, one barrier per tile; online
@@ -30,6 +28,19 @@
 #include "hv_common.h"
 #include "humanvid_hip.h"
 
+#ifndef HV_ATTN_OCC40
+#define HV_ATTN_OCC40 4
+#endif
+#ifndef HV_ATTN_ONES
+// Denominator-through-the-MFMA variant (a row of ones in the spare V^T rows of d = 40).  Correct on
+// the host emulator but produced wrong / non-deterministic sums on MI355X in round 1 (A/B in
+// tools/diag_attn.py); kept behind this switch until the hardware behaviour is understood.
+#define HV_ATTN_ONES 0
+#endif
+#ifndef HV_ATTN_LAZY
+#define HV_ATTN_LAZY 1
+#endif
+
 template <int D, int QT>
 struct HvAttnGeom {
     static constexpr int NFULL = D / 32;              // 32-deep QK^T steps
@@ -37,7 +48,7 @@ struct HvAttnGeom {
     static constexpr int DT = (D + 15) / 16;          // 16-row fragments of V^T / O^T
     static constexpr int DK = 32 * NFULL + (TAIL ? 16 : 0);
     static constexpr int DV = 16 * DT;
-    static constexpr bool ONES = DV > D;              // spare V^T row available for the denominator
+    static constexpr bool ONES = HV_ATTN_ONES && DV > D;              // spare V^T row available for the denominator
     static constexpr int KRS = DK * 2 + 16;           // K row stride in LDS (bytes), odd multiple of 16
     static constexpr int VRS = 64 * 2 + 16;           // V^T row stride (64 keys)
     static constexpr int KBYTES = 64 * KRS;
@@ -53,7 +64,7 @@ struct HvAttnGeom {
 // d = 40 / 80 / 160): more resident waves let one wave's softmax VALU overlap another's MFMA
 template <int D, int QT>
 struct HvAttnOcc {
-    static constexpr int value = (D == 40 && QT == 2) ? 4 : ((D == 80 && QT == 2) ? 2 : 1);
+    static constexpr int value = (D == 40 && QT == 2) ? HV_ATTN_OCC40 : ((D == 80 && QT == 2) ? 2 : 1);
 };
 
 template <int D, int QT, bool MASK>
@@ -258,7 +269,7 @@ __global__ __launch_bounds__(256, (HvAttnOcc<D, QT>::value)) void hv_attention_k
                     pv[kvf][r] = __builtin_amdgcn_exp2f(sacc[kvf][qt][r] * c2 - mnew);
                     if (!G::ONES) psum += pv[kvf][r];
                 }
-            if (__any(mnew > mold)) {  // some query of this wave raised its maximum: rescale the accumulators
+            if (!HV_ATTN_LAZY || __any(mnew > mold)) {  // some query of this wave raised its maximum: rescale the accumulators
                 const float alpha = __builtin_amdgcn_exp2f(mold - mnew);
                 if (!G::ONES) lrun[qt] *= alpha;
 #pragma unroll

@@ -206,8 +206,8 @@ class Pose2VideoPipeline:
                 y = eng.forward_nhwc(xi, t_dev, cond, B=rep, F=fl)
                 ops.accumulate_window(L, st, y, rep, C, frames, acc, counter)
             if world > 1:
-                self.shard.dist.all_reduce(acc, group=self.shard.group)
-                self.shard.dist.all_reduce(counter, group=self.shard.group)
+                self.shard.all_reduce(acc)
+                self.shard.all_reduce(counter)
             ops.cfg_ddim_step(L, st, latents, acc, counter, rep, coeffs)
 
         graph = None

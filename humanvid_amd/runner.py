@@ -49,8 +49,25 @@ class FrameShard:
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
 
+        # gloo (CPU tests, or several ranks sharing one GPU in the 1-GPU parity test) has no device
+        # collectives: stage through host memory.  nccl (= RCCL over xGMI) runs on device buffers.
+        self.staged = dist.get_backend(group) != "nccl"
+
     def all_gather(self, out: torch.Tensor, inp: torch.Tensor):
+        if self.staged and inp.device.type != "cpu":
+            host_out = torch.empty(out.numel(), dtype=inp.dtype)
+            self.dist.all_gather_into_tensor(host_out, inp.cpu(), group=self.group)
+            out.copy_(host_out)
+            return
         self.dist.all_gather_into_tensor(out, inp, group=self.group)
+
+    def all_reduce(self, t: torch.Tensor):
+        if self.staged and t.device.type != "cpu":
+            h = t.cpu()
+            self.dist.all_reduce(h, group=self.group)
+            t.copy_(h)
+            return
+        self.dist.all_reduce(t, group=self.group)
 
     def frame_range(self, n_frames: int):
         if n_frames % self.world:

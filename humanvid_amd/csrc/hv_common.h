@@ -94,6 +94,31 @@ HV_DEV float hv_act(float x, int act) {
     return x;
 }
 
+// ---- asynchronous global -> LDS copies (LDS-DMA) --------------------------------------------
+// One wave-instruction moves 64 x 16 B: every lane supplies its own global address, the LDS
+// destination is wave-uniform base + lane * 16 (so any LDS swizzle is applied on the SOURCE side).
+// Completion is tracked by vmcnt; hv_vm_wait<N>() leaves at most N such loads in flight.
+#ifndef HV_EMU
+HV_DEV void hv_glds16(const void* gsrc, void* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds(gsrc, (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+template <int N>
+HV_DEV void hv_vm_wait() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+HV_DEV void hv_barrier_raw() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+}
+#else
+HV_DEV void hv_glds16(const void* gsrc, void* lds_wave_base) {
+    memcpy((char*)lds_wave_base + (threadIdx.x & 63) * 16, gsrc, 16);  // emulator: synchronous
+}
+template <int N>
+HV_DEV void hv_vm_wait() {}
+HV_DEV void hv_barrier_raw() { __syncthreads(); }
+#endif
+
 // ---- launch plumbing ----------------------------------------------------------------------
 // One launch helper for both builds: the real one uses the HIP triple-chevron launch on the
 // caller's stream, the emulator (tests only) runs the workgroups on host fibers.

@@ -50,6 +50,69 @@ HV_DEV float hv_erf_fast(float x) {
 }
 HV_DEV float hv_gelu_fast(float x) { return 0.5f * x * (1.0f + hv_erf_fast(x * 0.70710678118654752f)); }
 
+// ---- epilogue of one wave's 64x64 sub-tile: lane owns token m (column of the MFMA tile) and 4
+//      consecutive channels n; m_base / n_base are the sub-tile origin
+HV_DEV void hv_gemm_epilogue(const HvGemmParams& p, f32x4 (&acc)[4][4], int m_base, int n_base, int r16, int quad) {
+#pragma unroll
+    for (int mf = 0; mf < 4; ++mf) {
+        const int m = m_base + 16 * mf + r16;
+        if (m >= p.M) continue;
+        float mean = 0.f, rstd = 1.f;
+        if (p.row_rstd != nullptr) {
+            mean = p.row_mean[m];
+            rstd = p.row_rstd[m];
+        }
+        const float* pe_row = p.pe ? p.pe + (long)((m / p.pe_period) % p.pe_frames) * p.N : nullptr;
+        const float* rv_row = p.rowvec ? p.rowvec + (long)(m / p.rowvec_period) * p.N : nullptr;
+#pragma unroll
+        for (int nf = 0; nf < 4; ++nf) {
+            const int n = n_base + 16 * nf + 4 * quad;
+            if (n >= p.N) continue;
+            f32x4 v = acc[nf][mf];
+            if (p.row_rstd != nullptr) v = rstd * (v - mean * *reinterpret_cast<const f32x4*>(p.colsum + n));
+            if (p.bias != nullptr) v += *reinterpret_cast<const f32x4*>(p.bias + n);
+            if (pe_row != nullptr) v += *reinterpret_cast<const f32x4*>(pe_row + n);
+            if (rv_row != nullptr) v += *reinterpret_cast<const f32x4*>(rv_row + n);
+            if (p.geglu) {
+                // packed weight rows: [16 x h | 16 x g] blocks -> fragment pairs (even nf: h, odd nf: g)
+                acc[nf][mf] = v;
+                if ((nf & 1) == 0) continue;
+                const int no = ((n_base + 16 * (nf - 1)) >> 1) + 4 * quad;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = acc[nf - 1][mf][r] * hv_gelu_fast(v[r]);
+                if (p.residual != nullptr) {
+                    const u32x2 rr = hv_ld8(p.residual + (long)m * p.ldr + no);
+                    v[0] += hv_bf2f((bf16_t)(rr[0] & 0xffff));
+                    v[1] += hv_bf2f((bf16_t)(rr[0] >> 16));
+                    v[2] += hv_bf2f((bf16_t)(rr[1] & 0xffff));
+                    v[3] += hv_bf2f((bf16_t)(rr[1] >> 16));
+                }
+                u32x2 o = {hv_pack2(v[0], v[1]), hv_pack2(v[2], v[3])};
+                hv_st8(reinterpret_cast<bf16_t*>(p.Y) + (long)m * p.ldy + no, o);
+                continue;
+            }
+            if (p.residual != nullptr) {
+                const u32x2 rr = hv_ld8(p.residual + (long)m * p.ldr + n);
+                v[0] += hv_bf2f((bf16_t)(rr[0] & 0xffff));
+                v[1] += hv_bf2f((bf16_t)(rr[0] >> 16));
+                v[2] += hv_bf2f((bf16_t)(rr[1] & 0xffff));
+                v[3] += hv_bf2f((bf16_t)(rr[1] >> 16));
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = hv_act(v[r], p.out_act);
+            if (p.Yt != nullptr && n >= p.n_split) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) p.Yt[(long)(n - p.n_split + r) * p.ldyt + m] = hv_f2bf(v[r]);
+            } else if (p.out_f32) {
+                *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.Y) + (long)m * p.ldy + n) = v;
+            } else {
+                u32x2 o = {hv_pack2(v[0], v[1]), hv_pack2(v[2], v[3])};
+                hv_st8(reinterpret_cast<bf16_t*>(p.Y) + (long)m * p.ldy + n, o);
+            }
+        }
+    }
+}
+
 template <int N>
 struct HvInt {
     static constexpr int value = N;
@@ -179,67 +242,8 @@ __global__ __launch_bounds__(256, 2) void hv_gemm_kernel(HvGemmParams p) {
         }
     };
 
-    // ---- epilogue of one tile: lane owns token m (column of the MFMA tile) and 4 consecutive channels n
     auto epilogue = [&](int ti) __attribute__((always_inline)) {
-        const int m0 = (ti / tiles_n) * BM, n0 = (ti % tiles_n) * BN;
-#pragma unroll
-        for (int mf = 0; mf < 4; ++mf) {
-            const int m = m0 + 64 * wm + 16 * mf + r16;
-            if (m >= p.M) continue;
-            float mean = 0.f, rstd = 1.f;
-            if (p.row_rstd != nullptr) {
-                mean = p.row_mean[m];
-                rstd = p.row_rstd[m];
-            }
-            const float* pe_row = p.pe ? p.pe + (long)((m / p.pe_period) % p.pe_frames) * p.N : nullptr;
-            const float* rv_row = p.rowvec ? p.rowvec + (long)(m / p.rowvec_period) * p.N : nullptr;
-#pragma unroll
-            for (int nf = 0; nf < 4; ++nf) {
-                const int n = n0 + 64 * wn + 16 * nf + 4 * quad;
-                if (n >= p.N) continue;
-                f32x4 v = acc[nf][mf];
-                if (p.row_rstd != nullptr) v = rstd * (v - mean * *reinterpret_cast<const f32x4*>(p.colsum + n));
-                if (p.bias != nullptr) v += *reinterpret_cast<const f32x4*>(p.bias + n);
-                if (pe_row != nullptr) v += *reinterpret_cast<const f32x4*>(pe_row + n);
-                if (rv_row != nullptr) v += *reinterpret_cast<const f32x4*>(rv_row + n);
-                if (p.geglu) {
-                    // packed weight rows: [16 x h | 16 x g] blocks -> fragment pairs (even nf: h, odd nf: g)
-                    acc[nf][mf] = v;
-                    if ((nf & 1) == 0) continue;
-                    const int no = ((n0 + 64 * wn + 16 * (nf - 1)) >> 1) + 4 * quad;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] = acc[nf - 1][mf][r] * hv_gelu_fast(v[r]);
-                    if (p.residual != nullptr) {
-                        const u32x2 rr = hv_ld8(p.residual + (long)m * p.ldr + no);
-                        v[0] += hv_bf2f((bf16_t)(rr[0] & 0xffff));
-                        v[1] += hv_bf2f((bf16_t)(rr[0] >> 16));
-                        v[2] += hv_bf2f((bf16_t)(rr[1] & 0xffff));
-                        v[3] += hv_bf2f((bf16_t)(rr[1] >> 16));
-                    }
-                    u32x2 o = {hv_pack2(v[0], v[1]), hv_pack2(v[2], v[3])};
-                    hv_st8(reinterpret_cast<bf16_t*>(p.Y) + (long)m * p.ldy + no, o);
-                    continue;
-                }
-                if (p.residual != nullptr) {
-                    const u32x2 rr = hv_ld8(p.residual + (long)m * p.ldr + n);
-                    v[0] += hv_bf2f((bf16_t)(rr[0] & 0xffff));
-                    v[1] += hv_bf2f((bf16_t)(rr[0] >> 16));
-                    v[2] += hv_bf2f((bf16_t)(rr[1] & 0xffff));
-                    v[3] += hv_bf2f((bf16_t)(rr[1] >> 16));
-                }
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = hv_act(v[r], p.out_act);
-                if (p.Yt != nullptr && n >= p.n_split) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) p.Yt[(long)(n - p.n_split + r) * p.ldyt + m] = hv_f2bf(v[r]);
-                } else if (p.out_f32) {
-                    *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.Y) + (long)m * p.ldy + n) = v;
-                } else {
-                    u32x2 o = {hv_pack2(v[0], v[1]), hv_pack2(v[2], v[3])};
-                    hv_st8(reinterpret_cast<bf16_t*>(p.Y) + (long)m * p.ldy + n, o);
-                }
-            }
-        }
+        hv_gemm_epilogue(p, acc, (ti / tiles_n) * BM + 64 * wm, (ti % tiles_n) * BN + 64 * wn, r16, quad);
     };
 
     // one flattened step: park k-tile s in LDS, refill its registers with k-tile s+2, multiply,
@@ -264,7 +268,111 @@ __global__ __launch_bounds__(256, 2) void hv_gemm_kernel(HvGemmParams p) {
     }
 }
 
+// ---- LDS-DMA variant (no operand prologue): 256 x 128 x 64 tiles, 8 waves (4 along M x 2 along N,
+// 64x64 each), 3-slot LDS ring (144 KiB) filled with global_load_lds (no VGPR staging, no ds_write:
+// the register-staged kernel above is bound by the LDS write path), two k-tiles in flight across the
+// barrier with counted vmcnt waits, one raw s_barrier per k-step, persistent tile walk as above.
+// The XOR swizzle of the LDS image is applied on the per-lane SOURCE address (the DMA destination is
+// lane-linear).  Rows beyond M / N are clamped on load and masked in the epilogue.
+template <int UNUSED>
+__global__ __launch_bounds__(512) void hv_gemm_glds_kernel(HvGemmParams p) {
+    constexpr int BM = 256, BN = 128, BK = 64, NS = 3;
+    constexpr int XT = BM * BK * 2, WT = BN * BK * 2, SLOT = XT + WT;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[NS * SLOT];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave & 3, wn = wave >> 2;
+    const int r16 = lane & 15, quad = lane >> 4;
+
+    const int tiles_n = (p.N + BN - 1) / BN, tiles_m = (p.M + BM - 1) / BM;
+    const int total = tiles_n * tiles_m;
+    const int wg_per_xcd = gridDim.x / 8;
+    const int xcd = blockIdx.x % 8, wg = blockIdx.x / 8;
+    const int per_xcd = (total + 7) / 8;
+    const int t_begin = xcd * per_xcd;
+    const int t_end = min(total, t_begin + per_xcd);
+    const int first = t_begin + wg;
+    if (first >= t_end) return;
+    const int my_tiles = (t_end - first + wg_per_xcd - 1) / wg_per_xcd;
+    const int nk = p.K / BK;
+    const int nsteps = my_tiles * nk;
+
+    // 48 wave-instructions per k-tile (32 for X, 16 for W), 6 per wave
+    auto issue = [&](int s) __attribute__((always_inline)) {
+        const int ti = first + (s / nk) * wg_per_xcd;
+        const int m0 = (ti / tiles_n) * BM, n0 = (ti % tiles_n) * BN;
+        const int k0 = (s % nk) * BK;
+        unsigned char* slot = smem + (s % NS) * SLOT;
+        const bool second = p.X2 != nullptr && k0 >= p.K1;
+        const bf16_t* xb = second ? p.X2 : p.X;
+        const long ldx = second ? p.ldx2 : p.ldx;
+        const int kx = second ? k0 - p.K1 : k0;
+        const int sub = lane >> 3, pc = lane & 7;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int j = wave + 8 * q;
+            const int row = 8 * j + sub;
+            const int c = pc ^ ((row >> 1) & 7);
+            const int m = min(m0 + row, p.M - 1);
+            hv_glds16(xb + (long)m * ldx + kx + c * 8, slot + j * 1024);
+        }
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int j = wave + 8 * q;
+            const int row = 8 * j + sub;
+            const int c = pc ^ ((row >> 1) & 7);
+            const int n = min(n0 + row, p.N - 1);
+            hv_glds16(p.W + (long)n * p.K + k0 + c * 8, slot + XT + j * 1024);
+        }
+    };
+
+    f32x4 acc[4][4];  // [nf][mf]
+    auto clear_acc = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    };
+
+    clear_acc();
+    issue(0);
+    if (nsteps > 1) issue(1);
+    for (int s = 0; s < nsteps; ++s) {
+        // this wave's share of k-tile s has landed (k-tile s+1 may stay in flight) ...
+        if (s + 1 < nsteps)
+            hv_vm_wait<6>();
+        else
+            hv_vm_wait<0>();
+        // ... and so has everybody else's; all waves are also done reading k-tile s-1
+        hv_barrier_raw();
+        if (s + 2 < nsteps) issue(s + 2);  // reuses the slot of k-tile s-1
+        const unsigned char* xs = smem + (s % NS) * SLOT;
+        const unsigned char* ws = xs + XT;
+#pragma unroll
+        for (int kk = 0; kk < BK / 32; ++kk) {
+            bf16x8 wf[4], xf[4];
+#pragma unroll
+            for (int f = 0; f < 4; ++f) {
+                wf[f] = hv_as_bf16x8(hv_ld16(ws + hv_swz<BK>(64 * wn + 16 * f + r16, kk * 4 + quad)));
+                xf[f] = hv_as_bf16x8(hv_ld16(xs + hv_swz<BK>(64 * wm + 16 * f + r16, kk * 4 + quad)));
+            }
+#pragma unroll
+            for (int nf = 0; nf < 4; ++nf)
+#pragma unroll
+                for (int mf = 0; mf < 4; ++mf)
+                    acc[nf][mf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nf], xf[mf], acc[nf][mf], 0, 0, 0);
+        }
+        if ((s + 1) % nk == 0) {
+            const int ti = first + (s / nk) * wg_per_xcd;
+            hv_gemm_epilogue(p, acc, (ti / tiles_n) * BM + 64 * wm, (ti % tiles_n) * BN + 64 * wn, r16, quad);
+            clear_acc();
+        }
+    }
+}
+
 static int g_hv_gemm_max_grid = 512;  // tuning knob (hv_set_tuning): persistent workgroups
+static int g_hv_gemm_glds = 1;         // tuning knob: use the LDS-DMA kernel where applicable
 
 static inline int hv_gemm_launch(const HvGemmParams& p, hipStream_t stream) {
     if (p.M <= 0 || p.N <= 0 || p.K <= 0) return -1;
@@ -272,6 +380,16 @@ static inline int hv_gemm_launch(const HvGemmParams& p, hipStream_t stream) {
     if (p.X2 != nullptr && (p.K1 % 64 != 0)) return -1;
     if (p.geglu && (p.N % 32 != 0 || p.Yt != nullptr || p.out_f32)) return -1;
     if (p.Yt != nullptr && (p.n_split % 16 != 0)) return -1;
+    const bool prologue = p.pro_scale != nullptr || p.pro_act != HV_ACT_NONE;
+    if (g_hv_gemm_glds && !prologue && p.M >= 256) {
+        // LDS-DMA kernel: one 144 KiB workgroup per CU
+        const int tiles = ((p.N + 127) / 128) * ((p.M + 255) / 256);
+        int grid = ((tiles + 7) / 8) * 8;
+        if (grid > 256) grid = 256;
+        if (grid > g_hv_gemm_max_grid) grid = g_hv_gemm_max_grid;
+        hv_launch(hv_gemm_glds_kernel<0>, dim3(grid), dim3(512), stream, p);
+        return 0;
+    }
     const int tiles = ((p.N + 127) / 128) * ((p.M + 127) / 128);
     // persistent grid: 2 workgroups per CU (64 KiB LDS each), 256 CUs, fewer when the problem is small
     int grid = ((tiles + 7) / 8) * 8;

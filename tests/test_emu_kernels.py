@@ -44,6 +44,22 @@ def test_gemm_persistent_multi_tile(cx):
         cx.lib.call("hv_set_tuning", 2, 512)
 
 
+def test_gemm_lds_dma_kernel_variants(cx):
+    """M >= 256 without an operand prologue takes the LDS-DMA (global_load_lds) kernel: 256x128 tiles,
+    ragged M / N edges (clamped loads), two-source K, transposed store, LayerNorm fold, GEGLU."""
+    kc.case_gemm(cx, M=300, N=132, K=128, seed=21, residual=True)
+    kc.case_gemm(cx, M=520, N=320, K=192, seed=22, two_source=True)
+    kc.case_gemm(cx, M=256, N=160, K=64, seed=23, transposed=True)
+    kc.case_gemm(cx, M=260, N=64, K=64, seed=24, residual=False, out_f32=True)
+    kc.case_gemm_lnfold(cx, B=2, Fr=3, P=50, C=128, N=192, seed=25)
+    kc.case_gemm_geglu(cx, M=257, C=64, seed=26)
+    cx.lib.call("hv_set_tuning", 3, 0)   # same shapes through the register-staged kernel
+    try:
+        kc.case_gemm(cx, M=300, N=132, K=128, seed=21, residual=True)
+    finally:
+        cx.lib.call("hv_set_tuning", 3, 1)
+
+
 def test_gemm_prologue(cx):
     kc.case_gemm_prologue(cx)
 

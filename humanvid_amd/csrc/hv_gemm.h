@@ -274,10 +274,14 @@ __global__ __launch_bounds__(256, 2) void hv_gemm_kernel(HvGemmParams p) {
 // barrier with counted vmcnt waits, one raw s_barrier per k-step, persistent tile walk as above.
 // The XOR swizzle of the LDS image is applied on the per-lane SOURCE address (the DMA destination is
 // lane-linear).  Rows beyond M / N are clamped on load and masked in the epilogue.
-template <int UNUSED>
+template <int BK, int NS>
 __global__ __launch_bounds__(512) void hv_gemm_glds_kernel(HvGemmParams p) {
-    constexpr int BM = 256, BN = 128, BK = 64, NS = 3;
+    constexpr int BM = 256, BN = 128;
     constexpr int XT = BM * BK * 2, WT = BN * BK * 2, SLOT = XT + WT;
+    constexpr int RPI = 1024 / (BK * 2);        // tile rows covered by one 1 KiB wave-instruction
+    constexpr int CPR = BK / 8, RPB = 16 / CPR;  // 16-byte chunks per row, rows per 256-byte bank row
+    constexpr int XQ = BM / RPI / 8, WQ = BN / RPI / 8;  // DMA instructions per wave and k-tile
+    constexpr int LPW = XQ + WQ;
     __shared__ __attribute__((aligned(16))) unsigned char smem[NS * SLOT];
 
     const int tid = threadIdx.x;
@@ -298,7 +302,7 @@ __global__ __launch_bounds__(512) void hv_gemm_glds_kernel(HvGemmParams p) {
     const int nk = p.K / BK;
     const int nsteps = my_tiles * nk;
 
-    // 48 wave-instructions per k-tile (32 for X, 16 for W), 6 per wave
+    // (BM + BN) / RPI wave-instructions per k-tile, LPW per wave
     auto issue = [&](int s) __attribute__((always_inline)) {
         const int ti = first + (s / nk) * wg_per_xcd;
         const int m0 = (ti / tiles_n) * BM, n0 = (ti % tiles_n) * BN;
@@ -308,20 +312,20 @@ __global__ __launch_bounds__(512) void hv_gemm_glds_kernel(HvGemmParams p) {
         const bf16_t* xb = second ? p.X2 : p.X;
         const long ldx = second ? p.ldx2 : p.ldx;
         const int kx = second ? k0 - p.K1 : k0;
-        const int sub = lane >> 3, pc = lane & 7;
+        const int sub = lane / CPR, pc = lane % CPR;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
+        for (int q = 0; q < XQ; ++q) {
             const int j = wave + 8 * q;
-            const int row = 8 * j + sub;
-            const int c = pc ^ ((row >> 1) & 7);
+            const int row = RPI * j + sub;
+            const int c = pc ^ ((row / RPB) % CPR);
             const int m = min(m0 + row, p.M - 1);
             hv_glds16(xb + (long)m * ldx + kx + c * 8, slot + j * 1024);
         }
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
+        for (int q = 0; q < WQ; ++q) {
             const int j = wave + 8 * q;
-            const int row = 8 * j + sub;
-            const int c = pc ^ ((row >> 1) & 7);
+            const int row = RPI * j + sub;
+            const int c = pc ^ ((row / RPB) % CPR);
             const int n = min(n0 + row, p.N - 1);
             hv_glds16(p.W + (long)n * p.K + k0 + c * 8, slot + XT + j * 1024);
         }
@@ -341,7 +345,7 @@ __global__ __launch_bounds__(512) void hv_gemm_glds_kernel(HvGemmParams p) {
     for (int s = 0; s < nsteps; ++s) {
         // this wave's share of k-tile s has landed (k-tile s+1 may stay in flight) ...
         if (s + 1 < nsteps)
-            hv_vm_wait<6>();
+            hv_vm_wait<LPW>();
         else
             hv_vm_wait<0>();
         // ... and so has everybody else's; all waves are also done reading k-tile s-1
@@ -372,7 +376,7 @@ __global__ __launch_bounds__(512) void hv_gemm_glds_kernel(HvGemmParams p) {
 }
 
 static int g_hv_gemm_max_grid = 512;  // tuning knob (hv_set_tuning): persistent workgroups
-static int g_hv_gemm_glds = 1;         // tuning knob: use the LDS-DMA kernel where applicable
+static int g_hv_gemm_glds = 2;         // tuning knob: 2 = LDS-DMA BK=32 (2 workgroups/CU), 1 = BK=64, 0 = register-staged
 
 static inline int hv_gemm_launch(const HvGemmParams& p, hipStream_t stream) {
     if (p.M <= 0 || p.N <= 0 || p.K <= 0) return -1;
@@ -387,7 +391,14 @@ static inline int hv_gemm_launch(const HvGemmParams& p, hipStream_t stream) {
         int grid = ((tiles + 7) / 8) * 8;
         if (grid > 256) grid = 256;
         if (grid > g_hv_gemm_max_grid) grid = g_hv_gemm_max_grid;
-        hv_launch(hv_gemm_glds_kernel<0>, dim3(grid), dim3(512), stream, p);
+        if (g_hv_gemm_glds == 2) {  // BK = 32, 72 KiB ring: two workgroups per CU whose epilogues interleave
+            grid = ((tiles + 7) / 8) * 8;
+            if (grid > 512) grid = 512;
+            if (grid > g_hv_gemm_max_grid) grid = g_hv_gemm_max_grid;
+            hv_launch(hv_gemm_glds_kernel<32, 3>, dim3(grid), dim3(512), stream, p);
+        } else {
+            hv_launch(hv_gemm_glds_kernel<64, 3>, dim3(grid), dim3(512), stream, p);
+        }
         return 0;
     }
     const int tiles = ((p.N + 127) / 128) * ((p.M + 127) / 128);

@@ -44,8 +44,8 @@ def main():
     dev = hvlib.require_gpu()
     L = hvlib.load()
     st = hvlib.current_stream()
-    if os.environ.get("HV_GEMM_GLDS") == "0":
-        L.call("hv_set_tuning", 3, 0)  # A/B: register-staged GEMM instead of the LDS-DMA kernel
+    if os.environ.get("HV_GEMM_GLDS"):
+        L.call("hv_set_tuning", 3, int(os.environ["HV_GEMM_GLDS"]))  # A/B of the GEMM kernel variants
     n = args.images
     out = []
 

@@ -46,11 +46,64 @@ def build_models(dev):
     return unet, pg, cam
 
 
-def roofline_probe(unet, n_img, F, h, w, iters=5):
-    """Average duration of the dominant kernel (level-0 spatial attention with bank keys, the
-    launch the step issues 5x) measured with HIP events on the launch stream."""
+def _hip_time(fn, iters):
+    """average milliseconds of `fn` measured with HIP events recorded on the launch stream"""
     import ctypes
 
+    from humanvid_amd import lib as hvlib
+
+    L, st = hvlib.load(), hvlib.current_stream()
+    fn()
+    torch.cuda.synchronize()
+    e0, e1 = ctypes.c_void_p(), ctypes.c_void_p()
+    L.call("hv_event_create", ctypes.byref(e0))
+    L.call("hv_event_create", ctypes.byref(e1))
+    L.call("hv_event_record", e0, st)
+    for _ in range(iters):
+        fn()
+    L.call("hv_event_record", e1, st)
+    ms = ctypes.c_float()
+    L.call("hv_event_elapsed_ms", e0, e1, ctypes.byref(ms))
+    L.call("hv_event_destroy", e0)
+    L.call("hv_event_destroy", e1)
+    return ms.value / iters
+
+
+def roofline_probe(n_img, F, h, w, iters=3):
+    """Dominant kernel = the LDS-DMA GEMM (hv_gemm_glds_kernel, ~40 % of the step over ~200 launches of
+    16 shapes).  Replays those launches with their per-step multiplicities and reports the aggregate
+    algorithmic TFLOP/s (= sum flops / sum launch time) and the mean launch duration."""
+    from humanvid_amd import lib as hvlib
+    from humanvid_amd import ops
+
+    L, st = hvlib.load(), hvlib.current_stream()
+    dev = torch.device("cuda")
+    levels = [(h * w, 320, 5, 5), ((h // 2) * (w // 2), 640, 5, 5), ((h // 4) * (w // 4), 1280, 5, 5),
+              ((h // 8) * (w // 8), 1280, 1, 6)]  # tokens, C, #spatial transformers, #motion modules
+    tot_ms = tot_fl = 0.0
+    launches = 0
+    for N_tok, C, T, Mm in levels:
+        M = n_img * N_tok
+        x = torch.randn(M, C, device=dev).to(torch.bfloat16)
+        x4 = torch.randn(M, 4 * C, device=dev).to(torch.bfloat16)
+        for Nn, K, geglu, count in [(3 * C, C, False, T + 2 * Mm), (C, C, False, 2 * T + 3 * Mm),
+                                    (8 * C, C, True, T + Mm), (C, 4 * C, False, T + Mm)]:
+            wgt = (torch.randn(Nn, K, device=dev) * K**-0.5).to(torch.bfloat16)
+            y = torch.empty(M, Nn // 2 if geglu else Nn, dtype=torch.bfloat16, device=dev)
+            bias = torch.zeros(Nn, device=dev)
+            xx = x if K == C else x4
+            ms = _hip_time(lambda: ops.gemm(L, st, xx, wgt, y, bias=bias, geglu=geglu), iters)
+            tot_ms += ms * count
+            tot_fl += 2.0 * M * Nn * K * count
+            launches += count
+            del wgt, y
+    return dict(kernel="hv_gemm_glds_kernel<32,3> (all Linear / 1x1-conv GEMMs of one step)", ms=tot_ms / launches,
+                flops=tot_fl / launches, tflops=tot_fl / tot_ms / 1e9, launches_per_step=launches,
+                ms_per_step=tot_ms)
+
+
+def attention_probe(n_img, F, h, w, iters=3):
+    """Second-largest kernel: level-0 spatial self-attention with bank keys (5 launches per step)."""
     from humanvid_amd import lib as hvlib
     from humanvid_amd import ops
 
@@ -64,28 +117,12 @@ def roofline_probe(unet, n_img, F, h, w, iters=5):
     vt2 = torch.randn(C, 2 * N, device=dev).to(torch.bfloat16)
     o = torch.empty(M, C, dtype=torch.bfloat16, device=dev)
     sel = torch.tensor([-1] * F + [1] * (n_img - F), dtype=torch.int32, device=dev)
-
-    def run():
-        ops.attention(L, st, qk, qk[:, C:], vt, o, n_images=n_img, heads=8, D=40, Lq=N, L1=N, ldq=2 * C, ldk=2 * C,
-                      ldvt=M, ldo=C, k2=k2, vt2=vt2, ldk2=C, ldvt2=2 * N, L2=N, bank_sel=sel)
-
-    run()
-    torch.cuda.synchronize()
-    e0, e1 = ctypes.c_void_p(), ctypes.c_void_p()
-    L.call("hv_event_create", ctypes.byref(e0))
-    L.call("hv_event_create", ctypes.byref(e1))
-    L.call("hv_event_record", e0, st)
-    for _ in range(iters):
-        run()
-    L.call("hv_event_record", e1, st)
-    ms = ctypes.c_float()
-    L.call("hv_event_elapsed_ms", e0, e1, ctypes.byref(ms))
-    L.call("hv_event_destroy", e0)
-    L.call("hv_event_destroy", e1)
-    ms = ms.value / iters
+    ms = _hip_time(lambda: ops.attention(L, st, qk, qk[:, C:], vt, o, n_images=n_img, heads=8, D=40, Lq=N, L1=N,
+                                         ldq=2 * C, ldk=2 * C, ldvt=M, ldo=C, k2=k2, vt2=vt2, ldk2=C, ldvt2=2 * N,
+                                         L2=N, bank_sel=sel), iters)
     flops = 4.0 * N * N * C * F + 4.0 * N * 2 * N * C * (n_img - F)
-    return dict(kernel="hv_attention_kernel<40> (level-0 spatial self-attention + bank keys)", ms=ms,
-                flops=flops, tflops=flops / ms / 1e9)
+    return dict(kernel="hv_attention_kernel<40,2>", avg_launch_ms=ms, flops_per_launch=flops,
+                achieved_tflops=flops / ms / 1e9, frac_of_mfma_peak=flops / ms / 1e9 / PEAK_BF16_TFLOPS)
 
 
 def cpu_baseline(budget_hw=(24, 16), frames=24):
@@ -218,7 +255,7 @@ def main():
         cfg.update(SD15_INFERENCE_V2)
         fl = unet3d_flops(cfg, 2, F, h, w, False)
         ms_step = elapsed / K * 1e3
-        probe = roofline_probe(unet, 2 * F, F, h, w) if world == 1 else None
+        probe = roofline_probe(2 * F, F, h, w) if world == 1 else None
         out = {
             "metric": "denoising steps/sec, 24f x 768x512 Pose2Video", "value": K / elapsed, "unit": "steps/s",
             "n_gpus": world, "steps": K, "warmup": Wm, "ms_per_step": ms_step, "higher_is_better": True,
@@ -235,7 +272,9 @@ def main():
             out["roofline"] = {"bound": "mfma", "achieved": probe["tflops"], "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                                "frac": probe["tflops"] / PEAK_BF16_TFLOPS, "traffic": None,
                                "kernel": probe["kernel"], "avg_launch_ms": probe["ms"],
-                               "flops_per_launch": probe["flops"]}
+                               "flops_per_launch": probe["flops"], "launches_per_step": probe["launches_per_step"],
+                               "kernel_ms_per_step": probe["ms_per_step"]}
+            out["roofline_attention"] = attention_probe(2 * F, F, h, w)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out))

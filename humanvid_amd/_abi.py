@@ -105,6 +105,12 @@ PROTOTYPES = {
     "hv_graph_end": (I, [P, C.POINTER(P)]),
     "hv_graph_launch": (I, [P, P]),
     "hv_graph_destroy": (I, [P]),
+    "hv_cmdlist_begin": (I, []),
+    "hv_cmdlist_cut": (I, [C.POINTER(P)]),
+    "hv_cmdlist_end": (I, [C.POINTER(P)]),
+    "hv_cmdlist_size": (I, [P]),
+    "hv_cmdlist_run": (I, [P, P]),
+    "hv_cmdlist_destroy": (I, [P]),
     "hv_event_create": (I, [C.POINTER(P)]),
     "hv_event_record": (I, [P, P]),
     "hv_event_elapsed_ms": (I, [P, P, C.POINTER(F)]),

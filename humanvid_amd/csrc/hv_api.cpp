@@ -9,6 +9,7 @@
 #include "hv_kernels.h"
 
 static thread_local char g_err[512] = "";
+thread_local HvCmdList* g_hv_recording = nullptr;
 
 static int hv_fail(int code, const char* what) {
     snprintf(g_err, sizeof(g_err), "%s", what);
@@ -131,6 +132,34 @@ int hv_cfg_ddim_step(float* latents, float* acc, float* counter, int rep, int C,
         return hv_fail(HV_EINVAL, "hv_cfg_ddim_step: bad args");
     hvk_cfg_ddim(latents, acc, counter, rep, C, F, H, W, coeffs, (hipStream_t)stream);
     return hv_check_launch("hv_cfg_ddim_step");
+}
+
+int hv_cmdlist_begin(void) {
+    if (g_hv_recording) return hv_fail(HV_EINVAL, "hv_cmdlist_begin: already recording");
+    g_hv_recording = new HvCmdList();
+    return HV_OK;
+}
+int hv_cmdlist_cut(void** list_out) {
+    if (!g_hv_recording || !list_out) return hv_fail(HV_EINVAL, "hv_cmdlist_cut: not recording");
+    *list_out = (void*)g_hv_recording;
+    g_hv_recording = new HvCmdList();
+    return HV_OK;
+}
+int hv_cmdlist_end(void** list_out) {
+    if (!g_hv_recording || !list_out) return hv_fail(HV_EINVAL, "hv_cmdlist_end: not recording");
+    *list_out = (void*)g_hv_recording;
+    g_hv_recording = nullptr;
+    return HV_OK;
+}
+int hv_cmdlist_size(void* list) { return list ? (int)((HvCmdList*)list)->cmds.size() : 0; }
+int hv_cmdlist_run(void* list, void* stream) {
+    if (!list) return hv_fail(HV_EINVAL, "hv_cmdlist_run: null list");
+    for (auto& c : ((HvCmdList*)list)->cmds) c((hipStream_t)stream);
+    return hv_check_launch("hv_cmdlist_run");
+}
+int hv_cmdlist_destroy(void* list) {
+    delete (HvCmdList*)list;
+    return HV_OK;
 }
 
 #ifndef HV_EMU

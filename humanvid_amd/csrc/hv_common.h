@@ -9,6 +9,9 @@
 #include <hip/hip_runtime.h>
 #endif
 #include <stdint.h>
+
+#include <functional>
+#include <vector>
 #include "humanvid_hip.h"  // HV_ACT_* and the parameter structs
 
 typedef unsigned short bf16_t;  // raw bfloat16 bits
@@ -122,12 +125,25 @@ HV_DEV void hv_barrier_raw() { __syncthreads(); }
 // ---- launch plumbing ----------------------------------------------------------------------
 // One launch helper for both builds: the real one uses the HIP triple-chevron launch on the
 // caller's stream, the emulator (tests only) runs the workgroups on host fibers.
+// Command lists: while a list is being recorded every launch is also appended to it as a closure
+// (kernel, geometry, by-value arguments); hv_cmdlist_run() re-issues the closures on a stream with
+// one native loop -- the host-side alternative to a HIP graph for launch sequences that are
+// interleaved with RCCL collectives (frame-sharded runs).
+struct HvCmdList {
+    std::vector<std::function<void(hipStream_t)>> cmds;
+};
+extern thread_local HvCmdList* g_hv_recording;  // defined in hv_api.cpp
+
 template <class... KArgs, class... Args>
 static inline void hv_launch(void (*kernel)(KArgs...), dim3 grid, dim3 block, hipStream_t stream, Args... args) {
 #ifdef HV_EMU
     (void)stream;
+    if (g_hv_recording)
+        g_hv_recording->cmds.push_back([=](hipStream_t) { hvemu::launch(grid, block, [&]() { kernel(args...); }); });
     hvemu::launch(grid, block, [&]() { kernel(args...); });
 #else
+    if (g_hv_recording)
+        g_hv_recording->cmds.push_back([=](hipStream_t s) { kernel<<<grid, block, 0, s>>>(args...); });
     kernel<<<grid, block, 0, stream>>>(args...);
 #endif
 }

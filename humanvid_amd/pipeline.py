@@ -61,6 +61,51 @@ def _clip_preprocess(ref_image) -> torch.Tensor:
     return ((a - mean) / std)[None]
 
 
+class StepRecorder:
+    """Records one denoising step as native command-list segments separated by collectives
+    (hv_cmdlist_*): replaying a step is then one ctypes call per segment plus the collectives,
+    instead of ~1000 Python-built launches -- the frame-sharded counterpart of the HIP-graph replay."""
+
+    def __init__(self, lib):
+        self.lib = lib
+        self.items = []  # ("k", list handle) | ("c", callable)
+
+    def begin(self):
+        self.lib.call("hv_cmdlist_begin")
+
+    def _close(self, fn_name):
+        import ctypes
+
+        h = ctypes.c_void_p()
+        self.lib.call(fn_name, ctypes.byref(h))
+        if self.lib.cdll.hv_cmdlist_size(h) > 0:
+            self.items.append(("k", h))
+        else:
+            self.lib.call("hv_cmdlist_destroy", h)
+
+    def collective(self, fn):
+        self._close("hv_cmdlist_cut")
+        self.items.append(("c", fn))
+        return fn()
+
+    def end(self):
+        self._close("hv_cmdlist_end")
+
+    def replay(self):
+        st = hvlib.current_stream()
+        for kind, x in self.items:
+            if kind == "k":
+                self.lib.call("hv_cmdlist_run", x, st)
+            else:
+                x()
+
+    def destroy(self):
+        for kind, x in self.items:
+            if kind == "k":
+                self.lib.call("hv_cmdlist_destroy", x)
+        self.items = []
+
+
 class Pose2VideoPipeline:
     def __init__(self, vae, image_encoder, reference_unet, denoising_unet, pose_guider, camera_pose_encoder,
                  scheduler, image_proj_model=None, tokenizer=None, text_encoder=None):
@@ -211,6 +256,7 @@ class Pose2VideoPipeline:
             ops.cfg_ddim_step(L, st, latents, acc, counter, rep, coeffs)
 
         graph = None
+        recorder = None
         n_steps = len(timesteps) if max_steps is None else min(max_steps, len(timesteps))
         for i in range(n_steps):
             t_dev.copy_(t_table[i].expand(rep))
@@ -221,6 +267,19 @@ class Pose2VideoPipeline:
                     graph = self._capture(one_step)
                 else:
                     L.call("hv_graph_launch", graph, hvlib.current_stream())
+            elif use_graph and world > 1 and i >= 1:
+                if recorder is None:
+                    # frame-sharded: record step 1 as command-list segments cut at every collective
+                    recorder = StepRecorder(L)
+                    self.shard.recorder = recorder
+                    recorder.begin()
+                    try:
+                        one_step()
+                    finally:
+                        recorder.end()
+                        self.shard.recorder = None
+                else:
+                    recorder.replay()
             else:
                 one_step()
             if step_hook is not None:
@@ -230,6 +289,9 @@ class Pose2VideoPipeline:
         if graph is not None:
             torch.cuda.current_stream().synchronize()
             L.call("hv_graph_destroy", graph)
+        if recorder is not None:
+            torch.cuda.current_stream().synchronize()
+            recorder.destroy()
         return latents
 
     def _capture(self, fn):

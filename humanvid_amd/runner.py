@@ -52,8 +52,19 @@ class FrameShard:
         # gloo (CPU tests, or several ranks sharing one GPU in the 1-GPU parity test) has no device
         # collectives: stage through host memory.  nccl (= RCCL over xGMI) runs on device buffers.
         self.staged = dist.get_backend(group) != "nccl"
+        self.recorder = None  # set by the pipeline while it records a step as command-list segments
 
     def all_gather(self, out: torch.Tensor, inp: torch.Tensor):
+        if self.recorder is not None:
+            return self.recorder.collective(lambda: self._all_gather(out, inp))
+        return self._all_gather(out, inp)
+
+    def all_reduce(self, t: torch.Tensor):
+        if self.recorder is not None:
+            return self.recorder.collective(lambda: self._all_reduce(t))
+        return self._all_reduce(t)
+
+    def _all_gather(self, out: torch.Tensor, inp: torch.Tensor):
         if self.staged and inp.device.type != "cpu":
             host_out = torch.empty(out.numel(), dtype=inp.dtype)
             self.dist.all_gather_into_tensor(host_out, inp.cpu(), group=self.group)
@@ -61,7 +72,7 @@ class FrameShard:
             return
         self.dist.all_gather_into_tensor(out, inp, group=self.group)
 
-    def all_reduce(self, t: torch.Tensor):
+    def _all_reduce(self, t: torch.Tensor):
         if self.staged and t.device.type != "cpu":
             h = t.cpu()
             self.dist.all_reduce(h, group=self.group)

@@ -214,6 +214,16 @@ int hv_graph_end(void* stream, void** graph_exec_out);
 int hv_graph_launch(void* graph_exec, void* stream);
 int hv_graph_destroy(void* graph_exec);
 
+/* ---- command lists: record a launch sequence once, re-issue it with one native loop ------------
+ * While recording, launches execute normally AND are appended to the list.  hv_cmdlist_cut() closes
+ * the current segment and opens the next (used at every RCCL collective of a frame-sharded step). */
+int hv_cmdlist_begin(void);
+int hv_cmdlist_cut(void** list_out);
+int hv_cmdlist_end(void** list_out);
+int hv_cmdlist_size(void* list);
+int hv_cmdlist_run(void* list, void* stream);
+int hv_cmdlist_destroy(void* list);
+
 /* timing helper used by bench.py: elapsed milliseconds between two events it records on `stream` */
 int hv_event_create(void** ev);
 int hv_event_record(void* ev, void* stream);

@@ -20,28 +20,36 @@
 #include "hv_gemm.h"  // hv_swz
 #include "humanvid_hip.h"
 
-template <int TW, int MODE>
+template <int TW, int MODE, int NPIX = 128>
 struct HvConvGeom {
-    static constexpr int TH = 128 / TW;
+    static constexpr int NT = 2 * NPIX;   // threads: one wave per 64 pixels x 64 channels
+    static constexpr int TH = NPIX / TW;
     static constexpr int HH = MODE == HV_CONV_S1 ? TH + 2 : (MODE == HV_CONV_S2 ? 2 * TH + 1 : TH / 2 + 2);
     static constexpr int HW = MODE == HV_CONV_S1 ? TW + 2 : (MODE == HV_CONV_S2 ? 2 * TW + 1 : TW / 2 + 2);
     static constexpr int HP = HH * HW;
     static constexpr int PS = 80;  // bytes per halo pixel in LDS
     static constexpr int HALO_BYTES = ((HP * PS + 15) / 16) * 16;
-    static constexpr int HALO_ITERS = (HP * 4 + 255) / 256;
+    static constexpr int HALO_ITERS = (HP * 4 + NT - 1) / NT;
     static constexpr int WTILE_BYTES = 128 * 64;
 };
 
-template <int TW, int MODE>
-__global__ __launch_bounds__(256) void hv_conv3x3_kernel(hv_conv3x3_params p) {
-    using G = HvConvGeom<TW, MODE>;
+// GLDS = true: the weight tiles stream HBM/L2 -> LDS with global_load_lds into a 3-slot ring (two
+// taps in flight across one raw barrier per step, counted vmcnt); only the halo tile, which needs the
+// GroupNorm/SiLU transform, is still staged through registers (once per 9 steps).
+// NPIX = 256 (8 waves): the weight tile of a tap is shared by twice as many pixels -> ~40 % fewer
+// bytes per FLOP through the per-CU load path, which bounds the 128-pixel variant (~25 GB/s per CU).
+template <int TW, int MODE, bool GLDS, int NPIX>
+__global__ __launch_bounds__(2 * NPIX) void hv_conv3x3_kernel(hv_conv3x3_params p) {
+    using G = HvConvGeom<TW, MODE, NPIX>;
     constexpr int TH = G::TH;
-    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * G::HALO_BYTES + 2 * G::WTILE_BYTES];
+    constexpr int NT = G::NT, NW = NT / 64, WM = NPIX / 64;
+    constexpr int WSLOTS = GLDS ? 3 : 2;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * G::HALO_BYTES + WSLOTS * G::WTILE_BYTES];
     unsigned char* halo = smem;
     unsigned char* wsm = smem + 2 * G::HALO_BYTES;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave & 1, wn = wave >> 1, r16 = lane & 15, quad = lane >> 4;
+    const int wm = wave % WM, wn = wave / WM, r16 = lane & 15, quad = lane >> 4;
     const int Cin = p.C1 + p.C2;
 
     const int tiles_n = (p.Cout + 127) / 128;
@@ -74,7 +82,8 @@ __global__ __launch_bounds__(256) void hv_conv3x3_kernel(hv_conv3x3_params p) {
     const int hc = tid & 3;  // this thread's 16-byte channel slot inside a chunk (constant, 256 % 4 == 0)
 
     u32x4 hreg[G::HALO_ITERS];
-    u32x4 wreg[2];
+    constexpr int WIT = 512 / NT;  // 16-byte chunks of a weight tile per thread
+    u32x4 wreg[WIT];
 
     auto load_halo = [&](int chunk) {
         const int ci = chunk * 32 + hc * 8;
@@ -84,7 +93,7 @@ __global__ __launch_bounds__(256) void hv_conv3x3_kernel(hv_conv3x3_params p) {
         const int cc = second ? ci - p.C1 : ci;
 #pragma unroll
         for (int j = 0; j < G::HALO_ITERS; ++j) {
-            const int hp = (tid + 256 * j) >> 2;
+            const int hp = (tid + NT * j) >> 2;
             u32x4 v = {0u, 0u, 0u, 0u};
             if (hp < G::HP) {
                 const int iy = in_y0 + hp / G::HW, ix = in_x0 + hp % G::HW;
@@ -108,7 +117,7 @@ __global__ __launch_bounds__(256) void hv_conv3x3_kernel(hv_conv3x3_params p) {
         }
 #pragma unroll
         for (int j = 0; j < G::HALO_ITERS; ++j) {
-            const int hp = (tid + 256 * j) >> 2;
+            const int hp = (tid + NT * j) >> 2;
             if (hp >= G::HP) continue;
             u32x4 v = hreg[j];
             if (pro || p.pro_act != HV_ACT_NONE) {
@@ -131,8 +140,8 @@ __global__ __launch_bounds__(256) void hv_conv3x3_kernel(hv_conv3x3_params p) {
     auto load_w = [&](int step) {
         const int chunk = step / 9, tap = step % 9;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int id = tid + 256 * i;
+        for (int i = 0; i < WIT; ++i) {
+            const int id = tid + NT * i;
             const int row = id >> 2, c = id & 3;
             const int n = n0 + row;
             u32x4 v = {0u, 0u, 0u, 0u};
@@ -142,9 +151,24 @@ __global__ __launch_bounds__(256) void hv_conv3x3_kernel(hv_conv3x3_params p) {
     };
     auto store_w = [&](int buf) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int id = tid + 256 * i;
+        for (int i = 0; i < WIT; ++i) {
+            const int id = tid + NT * i;
             hv_st16(wsm + buf * G::WTILE_BYTES + hv_swz<32>(id >> 2, id & 3), wreg[i]);
+        }
+    };
+    // LDS-DMA form: 8 wave-instructions of 1 KiB (16 rows x 64 B) per tap tile, 2 per wave; the
+    // swizzle of hv_swz<32> is applied on the source address; rows beyond Cout are clamped
+    auto issue_w = [&](int step) {
+        const int chunk = step / 9, tap = step % 9;
+        unsigned char* slot = wsm + (step % 3) * G::WTILE_BYTES;
+        const int sub = lane >> 2, pc = lane & 3;
+#pragma unroll
+        for (int q = 0; q < 8 / NW; ++q) {
+            const int j = wave + NW * q;
+            const int row = 16 * j + sub;
+            const int c = pc ^ ((row >> 2) & 3);
+            const int n = min(n0 + row, p.Cout - 1);
+            hv_glds16(p.W + ((long)n * 9 + tap) * Cin + chunk * 32 + c * 8, slot + j * 1024);
         }
     };
 
@@ -164,16 +188,31 @@ __global__ __launch_bounds__(256) void hv_conv3x3_kernel(hv_conv3x3_params p) {
         for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     load_halo(0);
-    load_w(0);
+    if (GLDS) {
+        issue_w(0);
+        if (nsteps > 1) issue_w(1);
+    } else {
+        load_w(0);
+    }
     for (int s = 0; s < nsteps; ++s) {
         const int chunk = s / 9, tap = s - chunk * 9;
-        const int wbuf = s & 1, hbuf = chunk & 1;
+        const int wbuf = GLDS ? s % 3 : (s & 1), hbuf = chunk & 1;
         if (tap == 0) store_halo(chunk, hbuf);
-        store_w(wbuf);
-        __syncthreads();
-        if (s + 1 < nsteps) {
-            load_w(s + 1);
-            if (tap == 8) load_halo(chunk + 1);
+        if (GLDS) {
+            if (s + 1 < nsteps)
+                hv_vm_wait<8 / NW>();  // tap tile s landed, tile s+1 may stay in flight
+            else
+                hv_vm_wait<0>();
+            hv_barrier_raw();
+            if (s + 2 < nsteps) issue_w(s + 2);  // reuses the slot read at step s-1
+            if (tap == 8 && s + 1 < nsteps) load_halo(chunk + 1);
+        } else {
+            store_w(wbuf);
+            __syncthreads();
+            if (s + 1 < nsteps) {
+                load_w(s + 1);
+                if (tap == 8) load_halo(chunk + 1);
+            }
         }
         const int dy = tap / 3, dx = tap - dy * 3;
         const unsigned char* hb = halo + hbuf * G::HALO_BYTES + quad * 16;
@@ -234,12 +273,19 @@ __global__ __launch_bounds__(256) void hv_conv3x3_kernel(hv_conv3x3_params p) {
     }
 }
 
-template <int TW, int MODE>
+static int g_hv_conv_glds = 1;  // tuning knob (hv_set_tuning): LDS-DMA weight tiles
+
+static int g_hv_conv_big = 1;  // tuning knob: 256-pixel tiles (8 waves) on images that fill them
+
+template <int TW, int MODE, int NPIX>
 static inline void hv_conv3x3_launch_t(const hv_conv3x3_params& p, hipStream_t stream) {
-    constexpr int TH = 128 / TW;
+    constexpr int TH = NPIX / TW;
     const int tiles = p.n_images * ((p.Ho + TH - 1) / TH) * ((p.Wo + TW - 1) / TW) * ((p.Cout + 127) / 128);
     const int grid = ((tiles + 7) / 8) * 8;
-    hv_launch(hv_conv3x3_kernel<TW, MODE>, dim3(grid), dim3(256), stream, p);
+    if (g_hv_conv_glds)
+        hv_launch(hv_conv3x3_kernel<TW, MODE, true, NPIX>, dim3(grid), dim3(2 * NPIX), stream, p);
+    else
+        hv_launch(hv_conv3x3_kernel<TW, MODE, false, NPIX>, dim3(grid), dim3(2 * NPIX), stream, p);
 }
 
 static inline int hv_conv3x3_launch(const hv_conv3x3_params& p, hipStream_t stream) {
@@ -248,17 +294,26 @@ static inline int hv_conv3x3_launch(const hv_conv3x3_params& p, hipStream_t stre
     if (p.mode == HV_CONV_S1 && (p.Ho != p.Hs || p.Wo != p.Ws)) return -1;
     if (p.mode == HV_CONV_S2 && (p.Ho != (p.Hs + 1) / 2 || p.Wo != (p.Ws + 1) / 2)) return -1;
     if (p.mode == HV_CONV_UP2 && (p.Ho != 2 * p.Hs || p.Wo != 2 * p.Ws)) return -1;
-    // narrow images use the tall 16x8 patch so that the patch is not mostly padding
+    // narrow images use the tall 16x8 patch so that the patch is not mostly padding; images with at
+    // least 16 output rows use the 256-pixel (16x16) patch, except for the stride-2 form whose input
+    // halo (33x33 pixels) would not fit two buffers in LDS
     const bool narrow = p.Wo <= 8;
+    // (measured on MI355X: the 8-wave tile wins for the upsample-folded conv, 0.90 -> 1.03 PF/s, and
+    //  loses for stride 1, where the per-step barrier over 8 waves costs more than the traffic saved)
+    const bool big = g_hv_conv_big && !narrow && p.Ho >= 16 && p.mode == HV_CONV_UP2;
     switch (p.mode) {
         case HV_CONV_S1:
-            narrow ? hv_conv3x3_launch_t<8, HV_CONV_S1>(p, stream) : hv_conv3x3_launch_t<16, HV_CONV_S1>(p, stream);
+            if (big) hv_conv3x3_launch_t<16, HV_CONV_S1, 256>(p, stream);
+            else if (narrow) hv_conv3x3_launch_t<8, HV_CONV_S1, 128>(p, stream);
+            else hv_conv3x3_launch_t<16, HV_CONV_S1, 128>(p, stream);
             break;
         case HV_CONV_S2:
-            narrow ? hv_conv3x3_launch_t<8, HV_CONV_S2>(p, stream) : hv_conv3x3_launch_t<16, HV_CONV_S2>(p, stream);
+            narrow ? hv_conv3x3_launch_t<8, HV_CONV_S2, 128>(p, stream) : hv_conv3x3_launch_t<16, HV_CONV_S2, 128>(p, stream);
             break;
         case HV_CONV_UP2:
-            narrow ? hv_conv3x3_launch_t<8, HV_CONV_UP2>(p, stream) : hv_conv3x3_launch_t<16, HV_CONV_UP2>(p, stream);
+            if (big) hv_conv3x3_launch_t<16, HV_CONV_UP2, 256>(p, stream);
+            else if (narrow) hv_conv3x3_launch_t<8, HV_CONV_UP2, 128>(p, stream);
+            else hv_conv3x3_launch_t<16, HV_CONV_UP2, 128>(p, stream);
             break;
         default:
             return -1;

@@ -80,6 +80,26 @@ def test_conv_modes(cx, mode):
     kc.case_conv(cx, mode=mode)
 
 
+def test_conv_big_tiles(cx):
+    """upsample-folded convs with >= 16 output rows take the 256-pixel / 8-wave tile"""
+    kc.case_conv(cx, n=1, H=10, W=12, C1=32, C2=32, Cout=36, mode=A.CONV_UP2, seed=32)
+    kc.case_conv(cx, n=2, H=8, W=10, C1=32, Cout=40, mode=A.CONV_UP2, seed=31)
+    cx.lib.call("hv_set_tuning", 4, 0)
+    try:
+        kc.case_conv(cx, n=1, H=9, W=9, C1=64, Cout=24, mode=A.CONV_UP2, seed=33)
+    finally:
+        cx.lib.call("hv_set_tuning", 4, 1)
+
+
+def test_conv_register_staged_variant(cx):
+    cx.lib.call("hv_set_tuning", 4, 0)
+    try:
+        kc.case_conv(cx, mode=A.CONV_S1)
+        kc.case_conv(cx, n=1, H=12, W=8, C1=32, C2=32, Cout=36, pro=True)
+    finally:
+        cx.lib.call("hv_set_tuning", 4, 1)
+
+
 def test_conv_two_source_narrow(cx):
     kc.case_conv(cx, n=1, H=12, W=8, C1=32, C2=32, Cout=36, pro=True)
     kc.case_conv(cx, n=1, H=6, W=4, C1=32, Cout=8, mode=A.CONV_UP2, pro=False, temb=False, residual=False,

@@ -237,34 +237,44 @@ __global__ __launch_bounds__(2 * NPIX) void hv_conv3x3_kernel(hv_conv3x3_params 
                 acc[nf][mf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nf], xf[mf], acc[nf][mf], 0, 0, 0);
     }
 
-    // ---- epilogue
+    // ---- epilogue.  Loads are batched (all bias / time-embedding vectors, then all residual fragments of
+    // a pixel row) before their first use: see the note on hv_gemm_epilogue.
     const float* rv = p.rowvec ? p.rowvec + (long)(img / p.images_per_rowvec) * p.rowvec_ld : nullptr;
     const int rimg = p.residual ? (p.residual_images > 0 ? img % p.residual_images : img) : 0;
+    f32x4 add4[4];
+#pragma unroll
+    for (int nf = 0; nf < 4; ++nf) {
+        const int n = n0 + 64 * wn + 16 * nf + 4 * quad;
+        f32x4 a = {0.f, 0.f, 0.f, 0.f};
+        if (n < p.Cout) {
+            if (p.bias) a += *reinterpret_cast<const f32x4*>(p.bias + n);
+            if (rv) a += *reinterpret_cast<const f32x4*>(rv + n);
+        }
+        add4[nf] = a;
+    }
 #pragma unroll
     for (int mf = 0; mf < 4; ++mf) {
         const int oy = y0 + py[mf], ox = x0 + px[mf];
         if (oy >= p.Ho || ox >= p.Wo) continue;
         const long opix = (long)(img * p.Ho + oy) * p.Wo + ox;
         const long rpix = (long)(rimg * p.Ho + oy) * p.Wo + ox;
+        u32x2 res2[4];
+#pragma unroll
+        for (int nf = 0; nf < 4; ++nf) {
+            const int n = n0 + 64 * wn + 16 * nf + 4 * quad;
+            u32x2 r = {0u, 0u};
+            if (p.residual && n < p.Cout) r = hv_ld8(p.residual + rpix * p.Cout + n);
+            res2[nf] = r;
+        }
 #pragma unroll
         for (int nf = 0; nf < 4; ++nf) {
             const int n = n0 + 64 * wn + 16 * nf + 4 * quad;
             if (n >= p.Cout) continue;
-            float v[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float a = acc[nf][mf][r];
-                if (p.bias) a += p.bias[n + r];
-                if (rv) a += rv[n + r];
-                v[r] = a;
-            }
-            if (p.residual) {
-                const u32x2 rr = hv_ld8(p.residual + rpix * p.Cout + n);
-                v[0] += hv_bf2f((bf16_t)(rr[0] & 0xffff));
-                v[1] += hv_bf2f((bf16_t)(rr[0] >> 16));
-                v[2] += hv_bf2f((bf16_t)(rr[1] & 0xffff));
-                v[3] += hv_bf2f((bf16_t)(rr[1] >> 16));
-            }
+            f32x4 v = acc[nf][mf] + add4[nf];
+            v[0] += hv_bf2f((bf16_t)(res2[nf][0] & 0xffff));
+            v[1] += hv_bf2f((bf16_t)(res2[nf][0] >> 16));
+            v[2] += hv_bf2f((bf16_t)(res2[nf][1] & 0xffff));
+            v[3] += hv_bf2f((bf16_t)(res2[nf][1] >> 16));
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[r] = hv_act(v[r], p.out_act);
             u32x2 o = {hv_pack2(v[0], v[1]), hv_pack2(v[2], v[3])};

@@ -50,29 +50,68 @@ HV_DEV float hv_erf_fast(float x) {
 }
 HV_DEV float hv_gelu_fast(float x) { return 0.5f * x * (1.0f + hv_erf_fast(x * 0.70710678118654752f)); }
 
-// ---- epilogue of one wave's 64x64 sub-tile: lane owns token m (column of the MFMA tile) and 4
-//      consecutive channels n; m_base / n_base are the sub-tile origin
-HV_DEV void hv_gemm_epilogue(const HvGemmParams& p, f32x4 (&acc)[4][4], int m_base, int n_base, int r16, int quad) {
+// ---- epilogue of one wave's (16*NMF) x 64 sub-tile: lane owns token m (column of the MFMA tile) and 4
+//      consecutive channels n; m_base / n_base are the sub-tile origin.
+// All global loads of a phase are issued back-to-back before the first use: with LDS-DMA loads in
+// flight hipcc drains the whole VMEM queue (vmcnt(0)) at every ordinary load's first use, so a
+// load->use->load->use epilogue serialises dozens of L2 round trips per tile (it was ~85 % of the
+// K=320 GEMMs' time in the first version of this kernel).
+template <int NMF>
+HV_DEV void hv_gemm_epilogue(const HvGemmParams& p, f32x4 (&acc)[4][NMF], int m_base, int n_base, int r16, int quad) {
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    // phase 0: per-column vectors (bias, LayerNorm column sums) and per-row LayerNorm statistics
+    f32x4 bias4[4], cs4[4];
+    float mean[NMF], rstd[NMF];
 #pragma unroll
-    for (int mf = 0; mf < 4; ++mf) {
+    for (int nf = 0; nf < 4; ++nf) {
+        const int n = n_base + 16 * nf + 4 * quad;
+        bias4[nf] = (p.bias != nullptr && n < p.N) ? *reinterpret_cast<const f32x4*>(p.bias + n) : zero4;
+        cs4[nf] = (p.row_rstd != nullptr && n < p.N) ? *reinterpret_cast<const f32x4*>(p.colsum + n) : zero4;
+    }
+#pragma unroll
+    for (int mf = 0; mf < NMF; ++mf) {
+        const int m = m_base + 16 * mf + r16;
+        const bool on = p.row_rstd != nullptr && m < p.M;
+        mean[mf] = on ? p.row_mean[m] : 0.f;
+        rstd[mf] = on ? p.row_rstd[m] : 1.f;
+    }
+#pragma unroll
+    for (int mf = 0; mf < NMF; ++mf) {
         const int m = m_base + 16 * mf + r16;
         if (m >= p.M) continue;
-        float mean = 0.f, rstd = 1.f;
-        if (p.row_rstd != nullptr) {
-            mean = p.row_mean[m];
-            rstd = p.row_rstd[m];
-        }
         const float* pe_row = p.pe ? p.pe + (long)((m / p.pe_period) % p.pe_frames) * p.N : nullptr;
         const float* rv_row = p.rowvec ? p.rowvec + (long)(m / p.rowvec_period) * p.N : nullptr;
+        // phase 1: issue every load of this row fragment
+        f32x4 add4[4];
+        u32x2 res2[4];
+#pragma unroll
+        for (int nf = 0; nf < 4; ++nf) {
+            const int n = n_base + 16 * nf + 4 * quad;
+            f32x4 a = bias4[nf];
+            if (n < p.N) {
+                if (pe_row != nullptr) a += *reinterpret_cast<const f32x4*>(pe_row + n);
+                if (rv_row != nullptr) a += *reinterpret_cast<const f32x4*>(rv_row + n);
+            }
+            add4[nf] = a;
+            u32x2 r = {0u, 0u};
+            if (p.residual != nullptr && n < p.N) {
+                if (!p.geglu)
+                    r = hv_ld8(p.residual + (long)m * p.ldr + n);
+                else if (nf & 1)
+                    r = hv_ld8(p.residual + (long)m * p.ldr + ((n_base + 16 * (nf - 1)) >> 1) + 4 * quad);
+            }
+            res2[nf] = r;
+        }
+        // phase 2: arithmetic and stores
 #pragma unroll
         for (int nf = 0; nf < 4; ++nf) {
             const int n = n_base + 16 * nf + 4 * quad;
             if (n >= p.N) continue;
             f32x4 v = acc[nf][mf];
-            if (p.row_rstd != nullptr) v = rstd * (v - mean * *reinterpret_cast<const f32x4*>(p.colsum + n));
-            if (p.bias != nullptr) v += *reinterpret_cast<const f32x4*>(p.bias + n);
-            if (pe_row != nullptr) v += *reinterpret_cast<const f32x4*>(pe_row + n);
-            if (rv_row != nullptr) v += *reinterpret_cast<const f32x4*>(rv_row + n);
+            if (p.row_rstd != nullptr) v = rstd[mf] * (v - mean[mf] * cs4[nf]);
+            v += add4[nf];
+            const f32x4 rres = {hv_bf2f((bf16_t)(res2[nf][0] & 0xffff)), hv_bf2f((bf16_t)(res2[nf][0] >> 16)),
+                                hv_bf2f((bf16_t)(res2[nf][1] & 0xffff)), hv_bf2f((bf16_t)(res2[nf][1] >> 16))};
             if (p.geglu) {
                 // packed weight rows: [16 x h | 16 x g] blocks -> fragment pairs (even nf: h, odd nf: g)
                 acc[nf][mf] = v;
@@ -80,24 +119,12 @@ HV_DEV void hv_gemm_epilogue(const HvGemmParams& p, f32x4 (&acc)[4][4], int m_ba
                 const int no = ((n_base + 16 * (nf - 1)) >> 1) + 4 * quad;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[r] = acc[nf - 1][mf][r] * hv_gelu_fast(v[r]);
-                if (p.residual != nullptr) {
-                    const u32x2 rr = hv_ld8(p.residual + (long)m * p.ldr + no);
-                    v[0] += hv_bf2f((bf16_t)(rr[0] & 0xffff));
-                    v[1] += hv_bf2f((bf16_t)(rr[0] >> 16));
-                    v[2] += hv_bf2f((bf16_t)(rr[1] & 0xffff));
-                    v[3] += hv_bf2f((bf16_t)(rr[1] >> 16));
-                }
+                v += rres;
                 u32x2 o = {hv_pack2(v[0], v[1]), hv_pack2(v[2], v[3])};
-                hv_st8(reinterpret_cast<bf16_t*>(p.Y) + (long)m * p.ldy + no, o);
+                hv_st8_stream(reinterpret_cast<bf16_t*>(p.Y) + (long)m * p.ldy + no, o);
                 continue;
             }
-            if (p.residual != nullptr) {
-                const u32x2 rr = hv_ld8(p.residual + (long)m * p.ldr + n);
-                v[0] += hv_bf2f((bf16_t)(rr[0] & 0xffff));
-                v[1] += hv_bf2f((bf16_t)(rr[0] >> 16));
-                v[2] += hv_bf2f((bf16_t)(rr[1] & 0xffff));
-                v[3] += hv_bf2f((bf16_t)(rr[1] >> 16));
-            }
+            v += rres;
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[r] = hv_act(v[r], p.out_act);
             if (p.Yt != nullptr && n >= p.n_split) {
@@ -107,7 +134,7 @@ HV_DEV void hv_gemm_epilogue(const HvGemmParams& p, f32x4 (&acc)[4][4], int m_ba
                 *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.Y) + (long)m * p.ldy + n) = v;
             } else {
                 u32x2 o = {hv_pack2(v[0], v[1]), hv_pack2(v[2], v[3])};
-                hv_st8(reinterpret_cast<bf16_t*>(p.Y) + (long)m * p.ldy + n, o);
+                hv_st8_stream(reinterpret_cast<bf16_t*>(p.Y) + (long)m * p.ldy + n, o);
             }
         }
     }
@@ -243,7 +270,7 @@ __global__ __launch_bounds__(256, 2) void hv_gemm_kernel(HvGemmParams p) {
     };
 
     auto epilogue = [&](int ti) __attribute__((always_inline)) {
-        hv_gemm_epilogue(p, acc, (ti / tiles_n) * BM + 64 * wm, (ti % tiles_n) * BN + 64 * wn, r16, quad);
+        hv_gemm_epilogue<4>(p, acc, (ti / tiles_n) * BM + 64 * wm, (ti % tiles_n) * BN + 64 * wn, r16, quad);
     };
 
     // one flattened step: park k-tile s in LDS, refill its registers with k-tile s+2, multiply,
@@ -274,19 +301,22 @@ __global__ __launch_bounds__(256, 2) void hv_gemm_kernel(HvGemmParams p) {
 // barrier with counted vmcnt waits, one raw s_barrier per k-step, persistent tile walk as above.
 // The XOR swizzle of the LDS image is applied on the per-lane SOURCE address (the DMA destination is
 // lane-linear).  Rows beyond M / N are clamped on load and masked in the epilogue.
-template <int BK, int NS>
-__global__ __launch_bounds__(512) void hv_gemm_glds_kernel(HvGemmParams p) {
-    constexpr int BM = 256, BN = 128;
+template <int BK, int NS, int BN>
+__global__ __launch_bounds__(512, 2) void hv_gemm_glds_kernel(HvGemmParams p) {
+    constexpr int BM = 256;
+    constexpr int WAVES_N = BN / 64, WAVES_M = 8 / WAVES_N;  // 4x2 waves of 64x64 (BN=128) or 2x4 of 128x64 (BN=256)
+    constexpr int WTM = BM / WAVES_M, NMF = WTM / 16;
     constexpr int XT = BM * BK * 2, WT = BN * BK * 2, SLOT = XT + WT;
     constexpr int RPI = 1024 / (BK * 2);        // tile rows covered by one 1 KiB wave-instruction
     constexpr int CPR = BK / 8, RPB = 16 / CPR;  // 16-byte chunks per row, rows per 256-byte bank row
     constexpr int XQ = BM / RPI / 8, WQ = BN / RPI / 8;  // DMA instructions per wave and k-tile
     constexpr int LPW = XQ + WQ;
+    constexpr int AHEAD = NS - 1;               // k-tiles in flight
     __shared__ __attribute__((aligned(16))) unsigned char smem[NS * SLOT];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
-    const int wm = wave & 3, wn = wave >> 2;
+    const int wm = wave % WAVES_M, wn = wave / WAVES_M;
     const int r16 = lane & 15, quad = lane >> 4;
 
     const int tiles_n = (p.N + BN - 1) / BN, tiles_m = (p.M + BM - 1) / BM;
@@ -331,45 +361,50 @@ __global__ __launch_bounds__(512) void hv_gemm_glds_kernel(HvGemmParams p) {
         }
     };
 
-    f32x4 acc[4][4];  // [nf][mf]
+    f32x4 acc[4][NMF];  // [nf][mf]
     auto clear_acc = [&]() __attribute__((always_inline)) {
 #pragma unroll
         for (int a = 0; a < 4; ++a)
 #pragma unroll
-            for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int b = 0; b < NMF; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
     };
 
     clear_acc();
-    issue(0);
-    if (nsteps > 1) issue(1);
+#pragma unroll
+    for (int a = 0; a < AHEAD; ++a)
+        if (a < nsteps) issue(a);
     for (int s = 0; s < nsteps; ++s) {
-        // this wave's share of k-tile s has landed (k-tile s+1 may stay in flight) ...
-        if (s + 1 < nsteps)
+        // this wave's share of k-tile s has landed (up to AHEAD-1 later k-tiles may stay in flight) ...
+        const int later = nsteps - 1 - s;
+        if (later >= AHEAD - 1)
+            hv_vm_wait<(AHEAD - 1) * LPW>();
+        else if (AHEAD > 2 && later == 1)
             hv_vm_wait<LPW>();
         else
             hv_vm_wait<0>();
         // ... and so has everybody else's; all waves are also done reading k-tile s-1
         hv_barrier_raw();
-        if (s + 2 < nsteps) issue(s + 2);  // reuses the slot of k-tile s-1
+        if (s + AHEAD < nsteps) issue(s + AHEAD);  // reuses the slot of k-tile s-1
         const unsigned char* xs = smem + (s % NS) * SLOT;
         const unsigned char* ws = xs + XT;
 #pragma unroll
         for (int kk = 0; kk < BK / 32; ++kk) {
-            bf16x8 wf[4], xf[4];
+            bf16x8 wf[4], xf[NMF];
 #pragma unroll
-            for (int f = 0; f < 4; ++f) {
+            for (int f = 0; f < 4; ++f)
                 wf[f] = hv_as_bf16x8(hv_ld16(ws + hv_swz<BK>(64 * wn + 16 * f + r16, kk * 4 + quad)));
-                xf[f] = hv_as_bf16x8(hv_ld16(xs + hv_swz<BK>(64 * wm + 16 * f + r16, kk * 4 + quad)));
-            }
+#pragma unroll
+            for (int f = 0; f < NMF; ++f)
+                xf[f] = hv_as_bf16x8(hv_ld16(xs + hv_swz<BK>(WTM * wm + 16 * f + r16, kk * 4 + quad)));
 #pragma unroll
             for (int nf = 0; nf < 4; ++nf)
 #pragma unroll
-                for (int mf = 0; mf < 4; ++mf)
+                for (int mf = 0; mf < NMF; ++mf)
                     acc[nf][mf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nf], xf[mf], acc[nf][mf], 0, 0, 0);
         }
         if ((s + 1) % nk == 0) {
             const int ti = first + (s / nk) * wg_per_xcd;
-            hv_gemm_epilogue(p, acc, (ti / tiles_n) * BM + 64 * wm, (ti % tiles_n) * BN + 64 * wn, r16, quad);
+            hv_gemm_epilogue<NMF>(p, acc, (ti / tiles_n) * BM + WTM * wm, (ti % tiles_n) * BN + 64 * wn, r16, quad);
             clear_acc();
         }
     }
@@ -386,18 +421,28 @@ static inline int hv_gemm_launch(const HvGemmParams& p, hipStream_t stream) {
     if (p.Yt != nullptr && (p.n_split % 16 != 0)) return -1;
     const bool prologue = p.pro_scale != nullptr || p.pro_act != HV_ACT_NONE;
     if (g_hv_gemm_glds && !prologue && p.M >= 256) {
-        // LDS-DMA kernel: one 144 KiB workgroup per CU
-        const int tiles = ((p.N + 127) / 128) * ((p.M + 255) / 256);
+        const int tm = (p.M + 255) / 256;
+        // 256x256 tiles (one 128 KiB workgroup per CU, a third fewer bytes per FLOP through the
+        // per-CU load path) when N fills them about as well as 256x128 tiles would
+        const int n128 = ((p.N + 127) / 128) * 128, n256 = ((p.N + 255) / 256) * 256;
+        if (g_hv_gemm_glds == 3 && p.N >= 512 && (n256 - n128) * 12 <= p.N) {
+            const int tiles = tm * (n256 / 256);
+            int grid = ((tiles + 7) / 8) * 8;
+            if (grid > 256) grid = 256;
+            if (grid > g_hv_gemm_max_grid) grid = g_hv_gemm_max_grid;
+            hv_launch(hv_gemm_glds_kernel<32, 4, 256>, dim3(grid), dim3(512), stream, p);
+            return 0;
+        }
+        const int tiles = tm * (n128 / 128);
         int grid = ((tiles + 7) / 8) * 8;
-        if (grid > 256) grid = 256;
-        if (grid > g_hv_gemm_max_grid) grid = g_hv_gemm_max_grid;
-        if (g_hv_gemm_glds == 2) {  // BK = 32, 72 KiB ring: two workgroups per CU whose epilogues interleave
-            grid = ((tiles + 7) / 8) * 8;
+        if (g_hv_gemm_glds == 1) {  // BK = 64, 144 KiB ring: one workgroup per CU
+            if (grid > 256) grid = 256;
+            if (grid > g_hv_gemm_max_grid) grid = g_hv_gemm_max_grid;
+            hv_launch(hv_gemm_glds_kernel<64, 3, 128>, dim3(grid), dim3(512), stream, p);
+        } else {  // BK = 32, 72 KiB ring: two workgroups per CU whose epilogues interleave
             if (grid > 512) grid = 512;
             if (grid > g_hv_gemm_max_grid) grid = g_hv_gemm_max_grid;
-            hv_launch(hv_gemm_glds_kernel<32, 3>, dim3(grid), dim3(512), stream, p);
-        } else {
-            hv_launch(hv_gemm_glds_kernel<64, 3>, dim3(grid), dim3(512), stream, p);
+            hv_launch(hv_gemm_glds_kernel<32, 3, 128>, dim3(grid), dim3(512), stream, p);
         }
         return 0;
     }

@@ -63,6 +63,22 @@ def test_gemm_lds_dma_kernel_variants(cx):
             cx.lib.call("hv_set_tuning", 3, 2)
 
 
+def test_gemm_lds_dma_256x256_tiles(cx):
+    """variant 3: 256x256 tiles, 4-slot ring (3 k-tiles in flight), waves own 128x64"""
+    cx.lib.call("hv_set_tuning", 3, 3)
+    try:
+        kc.case_gemm(cx, M=300, N=512, K=64, seed=41, residual=True)        # single k-step per tile pair
+        kc.case_gemm(cx, M=520, N=768, K=192, seed=42, two_source=True)
+        kc.case_gemm(cx, M=256, N=512, K=128, seed=43, transposed=True)
+        kc.case_gemm_lnfold(cx, B=2, Fr=3, P=50, C=128, N=512, seed=44)
+        kc.case_gemm_geglu(cx, M=257, C=64, seed=45)                        # N = 512
+        cx.lib.call("hv_set_tuning", 2, 8)                                  # several tiles per workgroup
+        kc.case_gemm(cx, M=1200, N=1024, K=96 + 32, seed=46)
+    finally:
+        cx.lib.call("hv_set_tuning", 2, 512)
+        cx.lib.call("hv_set_tuning", 3, 2)
+
+
 def test_gemm_prologue(cx):
     kc.case_gemm_prologue(cx)
 

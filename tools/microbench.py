@@ -42,7 +42,7 @@ def main():
     args = ap.parse_args()
     only = set(args.only.split(",")) if args.only else None
     dev = hvlib.require_gpu()
-    L = hvlib.load()
+    L = A.HvLibrary(os.environ["HV_LIB"]) if os.environ.get("HV_LIB") else hvlib.load()  # A/B of build variants
     st = hvlib.current_stream()
     if os.environ.get("HV_GEMM_GLDS"):
         L.call("hv_set_tuning", 3, int(os.environ["HV_GEMM_GLDS"]))  # A/B of the GEMM kernel variants

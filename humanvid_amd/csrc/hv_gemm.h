@@ -50,69 +50,109 @@ HV_DEV float hv_erf_fast(float x) {
 }
 HV_DEV float hv_gelu_fast(float x) { return 0.5f * x * (1.0f + hv_erf_fast(x * 0.70710678118654752f)); }
 
+// Optional phase timestamps (tools/gemm_trace.hip): wave 0 of workgroup HV_GEMM_TRACE logs (id, s_memtime).
+#ifdef HV_GEMM_TRACE
+__device__ unsigned long long g_hv_trace[8192];
+#define HV_TRACE_PARAM , int& hv_ti
+#define HV_TRACE_ARG , hv_ti
+#define HV_TRACE(id)                                                                                  \
+    do {                                                                                              \
+        if (blockIdx.x == HV_GEMM_TRACE && threadIdx.x == 0 && hv_ti < 8192)                          \
+            g_hv_trace[hv_ti++] = ((unsigned long long)(id) << 56) | (__builtin_amdgcn_s_memtime() & 0xffffffffffffffull); \
+    } while (0)
+#else
+#define HV_TRACE_PARAM
+#define HV_TRACE_ARG
+#define HV_TRACE(id)
+#endif
+#ifndef HV_GEMM_DBG
+#define HV_GEMM_DBG 0  // experiment mask: 1 no epilogue, 2 no epilogue stores, 4 no ds_reads, 8 no LDS-DMA, 16 X from L2
+#endif
+
 // ---- epilogue of one wave's (16*NMF) x 64 sub-tile: lane owns token m (column of the MFMA tile) and 4
 //      consecutive channels n; m_base / n_base are the sub-tile origin.
-// All global loads of a phase are issued back-to-back before the first use: with LDS-DMA loads in
-// flight hipcc drains the whole VMEM queue (vmcnt(0)) at every ordinary load's first use, so a
-// load->use->load->use epilogue serialises dozens of L2 round trips per tile (it was ~85 % of the
-// K=320 GEMMs' time in the first version of this kernel).
-template <int NMF>
-HV_DEV void hv_gemm_epilogue(const HvGemmParams& p, f32x4 (&acc)[4][NMF], int m_base, int n_base, int r16, int quad) {
+// * All global loads of a phase are issued back-to-back before the first use: with LDS-DMA loads in
+//   flight hipcc drains the whole VMEM queue (vmcnt(0)) at every ordinary load's first use, so a
+//   load->use->load->use epilogue serialises dozens of L2 round trips per tile.
+// * MODE picks a lean instantiation for the three hot output forms (1: bf16 row-major, 2: the same with
+//   a transposed tail = the QKV projection, 3: GEGLU); MODE 0 handles everything (activation, fp32
+//   output).  The fully general body is ~100 KB of code per kernel and ran out of the instruction
+//   cache once per tile (measured: 0.29 of 0.61 ms of the level-0 QKV GEMM with the stores disabled).
+template <int NMF, int MODE>
+HV_DEV void hv_gemm_epilogue_t(const HvGemmParams& p, f32x4 (&acc)[4][NMF], int m_base, int n_base, int r16, int quad HV_TRACE_PARAM) {
+    const bool geglu = MODE == 3 ? true : (MODE == 0 ? p.geglu != 0 : false);
+    const bool has_t = MODE == 2 ? true : (MODE == 0 ? p.Yt != nullptr : false);
+    const bool out_f32 = MODE == 0 ? p.out_f32 != 0 : false;
+    const int out_act = MODE == 0 ? p.out_act : HV_ACT_NONE;
+    const bool ln = p.row_rstd != nullptr;
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-    // phase 0: per-column vectors (bias, LayerNorm column sums) and per-row LayerNorm statistics
-    f32x4 bias4[4], cs4[4];
-    float mean[NMF], rstd[NMF];
+    // Loads use clamped (always valid) addresses and sit only under wave-uniform pointer tests, so that
+    // hipcc keeps each group back-to-back and waits once; ragged edges are masked at the stores.
+    int nc[4];
 #pragma unroll
-    for (int nf = 0; nf < 4; ++nf) {
-        const int n = n_base + 16 * nf + 4 * quad;
-        bias4[nf] = (p.bias != nullptr && n < p.N) ? *reinterpret_cast<const f32x4*>(p.bias + n) : zero4;
-        cs4[nf] = (p.row_rstd != nullptr && n < p.N) ? *reinterpret_cast<const f32x4*>(p.colsum + n) : zero4;
-    }
+    for (int nf = 0; nf < 4; ++nf) nc[nf] = min(n_base + 16 * nf + 4 * quad, p.N - 4);
+    const bool two_rows = p.pe != nullptr && p.rowvec != nullptr;  // both per-row tables: rare, slow path below
 #pragma unroll
     for (int mf = 0; mf < NMF; ++mf) {
         const int m = m_base + 16 * mf + r16;
-        const bool on = p.row_rstd != nullptr && m < p.M;
-        mean[mf] = on ? p.row_mean[m] : 0.f;
-        rstd[mf] = on ? p.row_rstd[m] : 1.f;
-    }
-#pragma unroll
-    for (int mf = 0; mf < NMF; ++mf) {
-        const int m = m_base + 16 * mf + r16;
-        if (m >= p.M) continue;
-        const float* pe_row = p.pe ? p.pe + (long)((m / p.pe_period) % p.pe_frames) * p.N : nullptr;
-        const float* rv_row = p.rowvec ? p.rowvec + (long)(m / p.rowvec_period) * p.N : nullptr;
-        // phase 1: issue every load of this row fragment
-        f32x4 add4[4];
+        const int mc = min(m, p.M - 1);
+        // phase 1: issue every load of this row fragment (the per-column vectors are L1 hits after the
+        // first fragment; re-loading them keeps 48 VGPRs free across the fragments)
+        f32x4 bias4[4], cs4[4], row4[4];
         u32x2 res2[4];
+        float mean = 0.f, rstd = 1.f;
 #pragma unroll
-        for (int nf = 0; nf < 4; ++nf) {
-            const int n = n_base + 16 * nf + 4 * quad;
-            f32x4 a = bias4[nf];
-            if (n < p.N) {
-                if (pe_row != nullptr) a += *reinterpret_cast<const f32x4*>(pe_row + n);
-                if (rv_row != nullptr) a += *reinterpret_cast<const f32x4*>(rv_row + n);
+        for (int nf = 0; nf < 4; ++nf) bias4[nf] = cs4[nf] = row4[nf] = zero4, res2[nf] = u32x2{0u, 0u};
+        {
+            if (p.bias != nullptr) {
+#pragma unroll
+                for (int nf = 0; nf < 4; ++nf) bias4[nf] = *reinterpret_cast<const f32x4*>(p.bias + nc[nf]);
             }
-            add4[nf] = a;
-            u32x2 r = {0u, 0u};
-            if (p.residual != nullptr && n < p.N) {
-                if (!p.geglu)
-                    r = hv_ld8(p.residual + (long)m * p.ldr + n);
-                else if (nf & 1)
-                    r = hv_ld8(p.residual + (long)m * p.ldr + ((n_base + 16 * (nf - 1)) >> 1) + 4 * quad);
+            if (ln) {
+#pragma unroll
+                for (int nf = 0; nf < 4; ++nf) cs4[nf] = *reinterpret_cast<const f32x4*>(p.colsum + nc[nf]);
+                mean = p.row_mean[mc];
+                rstd = p.row_rstd[mc];
             }
-            res2[nf] = r;
+        }
+        if (p.pe != nullptr) {
+            const float* pe_row = p.pe + (long)((mc / p.pe_period) % p.pe_frames) * p.N;
+#pragma unroll
+            for (int nf = 0; nf < 4; ++nf) row4[nf] = *reinterpret_cast<const f32x4*>(pe_row + nc[nf]);
+        } else if (p.rowvec != nullptr) {
+            const float* rv_row = p.rowvec + (long)(mc / p.rowvec_period) * p.N;
+#pragma unroll
+            for (int nf = 0; nf < 4; ++nf) row4[nf] = *reinterpret_cast<const f32x4*>(rv_row + nc[nf]);
+        }
+        if (p.residual != nullptr) {
+            const bf16_t* res_row = p.residual + (long)mc * p.ldr;
+            if (!geglu) {
+#pragma unroll
+                for (int nf = 0; nf < 4; ++nf) res2[nf] = hv_ld8(res_row + nc[nf]);
+            } else {
+#pragma unroll
+                for (int nf = 1; nf < 4; nf += 2)
+                    res2[nf] = hv_ld8(res_row + min(((n_base + 16 * (nf - 1)) >> 1) + 4 * quad, (p.N >> 1) - 4));
+            }
+        }
+        if (two_rows) {
+            const float* rv_row = p.rowvec + (long)(mc / p.rowvec_period) * p.N;
+#pragma unroll
+            for (int nf = 0; nf < 4; ++nf) row4[nf] += *reinterpret_cast<const f32x4*>(rv_row + nc[nf]);
         }
         // phase 2: arithmetic and stores
+        if (mf == 0) HV_TRACE(7);
+        char* yrow = reinterpret_cast<char*>(p.Y) + (long)m * p.ldy * (out_f32 ? 4 : 2);
 #pragma unroll
         for (int nf = 0; nf < 4; ++nf) {
             const int n = n_base + 16 * nf + 4 * quad;
-            if (n >= p.N) continue;
+            const bool valid = m < p.M && n < p.N;
             f32x4 v = acc[nf][mf];
-            if (p.row_rstd != nullptr) v = rstd[mf] * (v - mean[mf] * cs4[nf]);
-            v += add4[nf];
+            if (ln) v = rstd * (v - mean * cs4[nf]);
+            v += bias4[nf] + row4[nf];
             const f32x4 rres = {hv_bf2f((bf16_t)(res2[nf][0] & 0xffff)), hv_bf2f((bf16_t)(res2[nf][0] >> 16)),
                                 hv_bf2f((bf16_t)(res2[nf][1] & 0xffff)), hv_bf2f((bf16_t)(res2[nf][1] >> 16))};
-            if (p.geglu) {
+            if (geglu) {
                 // packed weight rows: [16 x h | 16 x g] blocks -> fragment pairs (even nf: h, odd nf: g)
                 acc[nf][mf] = v;
                 if ((nf & 1) == 0) continue;
@@ -121,23 +161,54 @@ HV_DEV void hv_gemm_epilogue(const HvGemmParams& p, f32x4 (&acc)[4][NMF], int m_
                 for (int r = 0; r < 4; ++r) v[r] = acc[nf - 1][mf][r] * hv_gelu_fast(v[r]);
                 v += rres;
                 u32x2 o = {hv_pack2(v[0], v[1]), hv_pack2(v[2], v[3])};
-                hv_st8_stream(reinterpret_cast<bf16_t*>(p.Y) + (long)m * p.ldy + no, o);
+                if (mf == 2) HV_TRACE(12);
+                if (valid) hv_st8_stream(yrow + 2 * no, o);
+                if (mf == 2) HV_TRACE(13);
+                if (mf == 0 && nf == 1) HV_TRACE(8);
+                if (mf == 0 && nf == 3) HV_TRACE(9);
+                if (mf == 1 && nf == 3) HV_TRACE(10);
                 continue;
             }
             v += rres;
+            if (out_act != HV_ACT_NONE) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = hv_act(v[r], p.out_act);
-            if (p.Yt != nullptr && n >= p.n_split) {
+                for (int r = 0; r < 4; ++r) v[r] = hv_act(v[r], out_act);
+            }
+#if HV_GEMM_DBG & 2
+            if (v[0] != 1.2345f) continue;
+#endif
+            if (!valid) continue;
+            if (has_t && n >= p.n_split) {
+                bf16_t* yt = p.Yt + (long)(n - p.n_split) * p.ldyt + m;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) p.Yt[(long)(n - p.n_split + r) * p.ldyt + m] = hv_f2bf(v[r]);
-            } else if (p.out_f32) {
-                *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.Y) + (long)m * p.ldy + n) = v;
+                for (int r = 0; r < 4; ++r) yt[(long)r * p.ldyt] = hv_f2bf(v[r]);
+            } else if (out_f32) {
+                *reinterpret_cast<f32x4*>(yrow + 4 * n) = v;
             } else {
                 u32x2 o = {hv_pack2(v[0], v[1]), hv_pack2(v[2], v[3])};
-                hv_st8_stream(reinterpret_cast<bf16_t*>(p.Y) + (long)m * p.ldy + n, o);
+                if (mf == 2) HV_TRACE(12);
+                hv_st8_stream(yrow + 2 * n, o);
+                if (mf == 2) HV_TRACE(13);
+                if (mf == 0 && nf == 0) HV_TRACE(8);
+                if (mf == 0 && nf == 3) HV_TRACE(9);
+                if (mf == 1 && nf == 3) HV_TRACE(10);
             }
         }
     }
+    HV_TRACE(11);
+}
+
+template <int NMF>
+HV_DEV void hv_gemm_epilogue(const HvGemmParams& p, f32x4 (&acc)[4][NMF], int m_base, int n_base, int r16, int quad HV_TRACE_PARAM) {
+    const bool lean = p.out_act == HV_ACT_NONE && !p.out_f32;
+    if (lean && p.geglu)
+        hv_gemm_epilogue_t<NMF, 3>(p, acc, m_base, n_base, r16, quad HV_TRACE_ARG);
+    else if (lean && p.Yt != nullptr)
+        hv_gemm_epilogue_t<NMF, 2>(p, acc, m_base, n_base, r16, quad HV_TRACE_ARG);
+    else if (lean)
+        hv_gemm_epilogue_t<NMF, 1>(p, acc, m_base, n_base, r16, quad HV_TRACE_ARG);
+    else
+        hv_gemm_epilogue_t<NMF, 0>(p, acc, m_base, n_base, r16, quad HV_TRACE_ARG);
 }
 
 template <int N>
@@ -270,7 +341,10 @@ __global__ __launch_bounds__(256, 2) void hv_gemm_kernel(HvGemmParams p) {
     };
 
     auto epilogue = [&](int ti) __attribute__((always_inline)) {
-        hv_gemm_epilogue<4>(p, acc, (ti / tiles_n) * BM + 64 * wm, (ti % tiles_n) * BN + 64 * wn, r16, quad);
+#ifdef HV_GEMM_TRACE
+        int hv_ti = 8192;
+#endif
+        hv_gemm_epilogue<4>(p, acc, (ti / tiles_n) * BM + 64 * wm, (ti % tiles_n) * BN + 64 * wn, r16, quad HV_TRACE_ARG);
     };
 
     // one flattened step: park k-tile s in LDS, refill its registers with k-tile s+2, multiply,
@@ -295,21 +369,24 @@ __global__ __launch_bounds__(256, 2) void hv_gemm_kernel(HvGemmParams p) {
     }
 }
 
-// ---- LDS-DMA variant (no operand prologue): 256 x 128 x 64 tiles, 8 waves (4 along M x 2 along N,
-// 64x64 each), 3-slot LDS ring (144 KiB) filled with global_load_lds (no VGPR staging, no ds_write:
-// the register-staged kernel above is bound by the LDS write path), two k-tiles in flight across the
-// barrier with counted vmcnt waits, one raw s_barrier per k-step, persistent tile walk as above.
-// The XOR swizzle of the LDS image is applied on the per-lane SOURCE address (the DMA destination is
-// lane-linear).  Rows beyond M / N are clamped on load and masked in the epilogue.
-template <int BK, int NS, int BN>
-__global__ __launch_bounds__(512, 2) void hv_gemm_glds_kernel(HvGemmParams p) {
+// ---- LDS-DMA variant (no operand prologue): 256 x BN x BK tiles on an NS-slot LDS ring filled with
+// global_load_lds (no VGPR staging, no ds_write: the register-staged kernel above is bound by the LDS
+// write path), NS-1 k-tiles in flight across the barrier with counted vmcnt waits, one raw s_barrier per
+// k-step, persistent tile walk as above.  NW waves per workgroup:
+//   NW = 4, BN = 128 (default): 2 x 2 waves of 128x64 (32 MFMA per 12 ds_read_b128), 72 KiB ring, TWO
+//       workgroups per CU -> every SIMD hosts one wave of each, so one workgroup's loads / barrier /
+//       epilogue run under the other one's MFMAs (measured: in a single resident workgroup the MFMA,
+//       ds_read, LDS-DMA-issue and epilogue times simply add up);
+//   NW = 8: 4 x 2 waves of 64x64 (BN = 128) or 2 x 4 of 128x64 (BN = 256), one workgroup per CU.
+template <int BK, int NS, int BN, int NW>
+__global__ __launch_bounds__(NW * 64, 2) void hv_gemm_glds_kernel(HvGemmParams p) {
     constexpr int BM = 256;
-    constexpr int WAVES_N = BN / 64, WAVES_M = 8 / WAVES_N;  // 4x2 waves of 64x64 (BN=128) or 2x4 of 128x64 (BN=256)
+    constexpr int WAVES_N = BN / 64, WAVES_M = NW / WAVES_N;
     constexpr int WTM = BM / WAVES_M, NMF = WTM / 16;
     constexpr int XT = BM * BK * 2, WT = BN * BK * 2, SLOT = XT + WT;
     constexpr int RPI = 1024 / (BK * 2);        // tile rows covered by one 1 KiB wave-instruction
     constexpr int CPR = BK / 8, RPB = 16 / CPR;  // 16-byte chunks per row, rows per 256-byte bank row
-    constexpr int XQ = BM / RPI / 8, WQ = BN / RPI / 8;  // DMA instructions per wave and k-tile
+    constexpr int XQ = BM / RPI / NW, WQ = BN / RPI / NW;  // DMA instructions per wave and k-tile
     constexpr int LPW = XQ + WQ;
     constexpr int AHEAD = NS - 1;               // k-tiles in flight
     __shared__ __attribute__((aligned(16))) unsigned char smem[NS * SLOT];
@@ -332,32 +409,41 @@ __global__ __launch_bounds__(512, 2) void hv_gemm_glds_kernel(HvGemmParams p) {
     const int nk = p.K / BK;
     const int nsteps = my_tiles * nk;
 
-    // (BM + BN) / RPI wave-instructions per k-tile, LPW per wave
-    auto issue = [&](int s) __attribute__((always_inline)) {
-        const int ti = first + (s / nk) * wg_per_xcd;
-        const int m0 = (ti / tiles_n) * BM, n0 = (ti % tiles_n) * BN;
-        const int k0 = (s % nk) * BK;
-        unsigned char* slot = smem + (s % NS) * SLOT;
+    // LDS-DMA issue state, advanced one k-tile per call (no divisions in the loop): tile origin, k index,
+    // ring slot.  The row -> bank-row swizzle only depends on (row / RPB) % CPR: a lane's chunk column is
+    // the same for every wave-instruction when these start at multiples of 16 rows (BK = 32).
+    const int sub = lane / CPR;
+    auto chunk_ofs = [&](int j) __attribute__((always_inline)) {
+        const int row = (RPI % 16 == 0) ? sub : RPI * j + sub;
+        return ((lane % CPR) ^ ((row / RPB) % CPR)) * 8;
+    };
+    int i_tile = first, i_k = 0, i_slot = 0;
+    int i_m0 = (first / tiles_n) * BM, i_n0 = (first % tiles_n) * BN;
+    auto issue = [&]() __attribute__((always_inline)) {
+        const int k0 = i_k * BK;
+        unsigned char* slot = smem + i_slot * SLOT;
         const bool second = p.X2 != nullptr && k0 >= p.K1;
-        const bf16_t* xb = second ? p.X2 : p.X;
+        const bf16_t* xb = second ? p.X2 + (k0 - p.K1) : p.X + k0;
         const long ldx = second ? p.ldx2 : p.ldx;
-        const int kx = second ? k0 - p.K1 : k0;
-        const int sub = lane / CPR, pc = lane % CPR;
+        const bf16_t* wb = p.W + k0;
 #pragma unroll
         for (int q = 0; q < XQ; ++q) {
-            const int j = wave + 8 * q;
-            const int row = RPI * j + sub;
-            const int c = pc ^ ((row / RPB) % CPR);
-            const int m = min(m0 + row, p.M - 1);
-            hv_glds16(xb + (long)m * ldx + kx + c * 8, slot + j * 1024);
+            const int j = wave + NW * q;
+            const int m = min(((HV_GEMM_DBG & 16) ? 0 : i_m0) + RPI * j + sub, p.M - 1);
+            hv_glds16(xb + (long)m * ldx + chunk_ofs(j), slot + j * 1024);
         }
 #pragma unroll
         for (int q = 0; q < WQ; ++q) {
-            const int j = wave + 8 * q;
-            const int row = RPI * j + sub;
-            const int c = pc ^ ((row / RPB) % CPR);
-            const int n = min(n0 + row, p.N - 1);
-            hv_glds16(p.W + (long)n * p.K + k0 + c * 8, slot + XT + j * 1024);
+            const int j = wave + NW * q;
+            const int n = min(i_n0 + RPI * j + sub, p.N - 1);
+            hv_glds16(wb + (long)n * p.K + chunk_ofs(j), slot + XT + j * 1024);
+        }
+        if (++i_slot == NS) i_slot = 0;
+        if (++i_k == nk) {
+            i_k = 0;
+            i_tile += wg_per_xcd;
+            i_m0 = (i_tile / tiles_n) * BM;
+            i_n0 = (i_tile % tiles_n) * BN;
         }
     };
 
@@ -370,10 +456,15 @@ __global__ __launch_bounds__(512, 2) void hv_gemm_glds_kernel(HvGemmParams p) {
     };
 
     clear_acc();
+#ifdef HV_GEMM_TRACE
+    int hv_ti = 0;
+#endif
 #pragma unroll
     for (int a = 0; a < AHEAD; ++a)
-        if (a < nsteps) issue(a);
+        if (a < nsteps) issue();
+    int c_tile = first, c_k = 0, c_slot = 0;  // consumer state
     for (int s = 0; s < nsteps; ++s) {
+        HV_TRACE(1);
         // this wave's share of k-tile s has landed (up to AHEAD-1 later k-tiles may stay in flight) ...
         const int later = nsteps - 1 - s;
         if (later >= AHEAD - 1)
@@ -383,29 +474,39 @@ __global__ __launch_bounds__(512, 2) void hv_gemm_glds_kernel(HvGemmParams p) {
         else
             hv_vm_wait<0>();
         // ... and so has everybody else's; all waves are also done reading k-tile s-1
+        HV_TRACE(2);
         hv_barrier_raw();
-        if (s + AHEAD < nsteps) issue(s + AHEAD);  // reuses the slot of k-tile s-1
-        const unsigned char* xs = smem + (s % NS) * SLOT;
+        HV_TRACE(3);
+        if (!(HV_GEMM_DBG & 8) && s + AHEAD < nsteps) issue();  // reuses the slot of k-tile s-1
+        HV_TRACE(4);
+        const unsigned char* xs = smem + c_slot * SLOT;
         const unsigned char* ws = xs + XT;
+        if (++c_slot == NS) c_slot = 0;
 #pragma unroll
         for (int kk = 0; kk < BK / 32; ++kk) {
             bf16x8 wf[4], xf[NMF];
 #pragma unroll
             for (int f = 0; f < 4; ++f)
-                wf[f] = hv_as_bf16x8(hv_ld16(ws + hv_swz<BK>(64 * wn + 16 * f + r16, kk * 4 + quad)));
+                wf[f] = (HV_GEMM_DBG & 4) ? hv_as_bf16x8(u32x4{(unsigned)s, (unsigned)lane, (unsigned)f, 1u})
+                                          : hv_as_bf16x8(hv_ld16(ws + hv_swz<BK>(64 * wn + 16 * f + r16, kk * 4 + quad)));
 #pragma unroll
             for (int f = 0; f < NMF; ++f)
-                xf[f] = hv_as_bf16x8(hv_ld16(xs + hv_swz<BK>(WTM * wm + 16 * f + r16, kk * 4 + quad)));
+                xf[f] = (HV_GEMM_DBG & 4) ? hv_as_bf16x8(u32x4{(unsigned)s, (unsigned)lane, (unsigned)f, 2u})
+                                          : hv_as_bf16x8(hv_ld16(xs + hv_swz<BK>(WTM * wm + 16 * f + r16, kk * 4 + quad)));
 #pragma unroll
             for (int nf = 0; nf < 4; ++nf)
 #pragma unroll
                 for (int mf = 0; mf < NMF; ++mf)
                     acc[nf][mf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nf], xf[mf], acc[nf][mf], 0, 0, 0);
         }
-        if ((s + 1) % nk == 0) {
-            const int ti = first + (s / nk) * wg_per_xcd;
-            hv_gemm_epilogue<NMF>(p, acc, (ti / tiles_n) * BM + WTM * wm, (ti % tiles_n) * BN + 64 * wn, r16, quad);
+        HV_TRACE(5);
+        if (++c_k == nk) {
+            c_k = 0;
+            if (!(HV_GEMM_DBG & 1) || acc[0][0][0] == 1.2345f)
+                hv_gemm_epilogue<NMF>(p, acc, (c_tile / tiles_n) * BM + WTM * wm, (c_tile % tiles_n) * BN + 64 * wn, r16, quad HV_TRACE_ARG);
+            c_tile += wg_per_xcd;
             clear_acc();
+            HV_TRACE(6);
         }
     }
 }
@@ -430,7 +531,7 @@ static inline int hv_gemm_launch(const HvGemmParams& p, hipStream_t stream) {
             int grid = ((tiles + 7) / 8) * 8;
             if (grid > 256) grid = 256;
             if (grid > g_hv_gemm_max_grid) grid = g_hv_gemm_max_grid;
-            hv_launch(hv_gemm_glds_kernel<32, 4, 256>, dim3(grid), dim3(512), stream, p);
+            hv_launch(hv_gemm_glds_kernel<32, 4, 256, 8>, dim3(grid), dim3(512), stream, p);
             return 0;
         }
         const int tiles = tm * (n128 / 128);
@@ -438,11 +539,14 @@ static inline int hv_gemm_launch(const HvGemmParams& p, hipStream_t stream) {
         if (g_hv_gemm_glds == 1) {  // BK = 64, 144 KiB ring: one workgroup per CU
             if (grid > 256) grid = 256;
             if (grid > g_hv_gemm_max_grid) grid = g_hv_gemm_max_grid;
-            hv_launch(hv_gemm_glds_kernel<64, 3, 128>, dim3(grid), dim3(512), stream, p);
+            hv_launch(hv_gemm_glds_kernel<64, 3, 128, 8>, dim3(grid), dim3(512), stream, p);
         } else {  // BK = 32, 72 KiB ring: two workgroups per CU whose epilogues interleave
             if (grid > 512) grid = 512;
             if (grid > g_hv_gemm_max_grid) grid = g_hv_gemm_max_grid;
-            hv_launch(hv_gemm_glds_kernel<32, 3, 128>, dim3(grid), dim3(512), stream, p);
+            if (g_hv_gemm_glds == 4)
+                hv_launch(hv_gemm_glds_kernel<32, 3, 128, 8>, dim3(grid), dim3(512), stream, p);
+            else
+                hv_launch(hv_gemm_glds_kernel<32, 3, 128, 4>, dim3(grid), dim3(256), stream, p);
         }
         return 0;
     }

@@ -13,6 +13,10 @@ LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libh
 def load() -> HvLibrary:
     global _LIB
     if _LIB is None:
+        override = os.environ.get("HUMANVID_HIP_LIB")  # A/B of build variants (tools/build_variant.sh); same C ABI
+        if override:
+            _LIB = HvLibrary(override)
+            return _LIB
         if not os.path.exists(LIB_PATH):
             raise RuntimeError(
                 f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "

@@ -133,7 +133,8 @@ class Pose2VideoPipeline:
         """Shard every context window along the frame axis over the ranks of `group` (one process per
         GPU, torch.distributed backend "nccl" = RCCL over xGMI)."""
         self.shard = FrameShard(group)
-        self.denoising_unet._engine = None
+        if self.denoising_unet is not None:
+            self.denoising_unet._engine = None  # rebuilt with the shard on first use
         return self
 
     def progress_bar(self, iterable=None, total=None):
@@ -163,14 +164,29 @@ class Pose2VideoPipeline:
             latents = latents.to(device)
         return latents * self.scheduler.init_noise_sigma
 
-    def decode_latents(self, latents):
-        """pipeline_pose2vid_long.py:114-127: per-frame VAE decode on PyTorch-ROCm."""
+    @torch.no_grad()
+    def decode_latents(self, latents, frames_per_batch: int = 8):
+        """pipeline_pose2vid_long.py:114-127 decodes one frame per `vae.decode` call, serially, and copies each
+        result to the host.  Same arithmetic here (the VAE stays on PyTorch-ROCm and treats frames as independent
+        batch items), scheduled differently: `frames_per_batch` frames per call,
+        one host copy at the end, and -- when frame sharding is on -- every rank decodes only its own frames and
+        the pixels are all-gathered."""
         video_length = latents.shape[2]
         latents = 1 / 0.18215 * latents
         b = latents.shape[0]
         flat = latents.permute(0, 2, 1, 3, 4).reshape(b * video_length, *latents.shape[1:2], *latents.shape[3:])
-        frames = [self.vae.decode(flat[i:i + 1].to(self.vae.dtype)).sample for i in range(flat.shape[0])]
+        world = 1 if self.shard is None else self.shard.world
+        lo, n = 0, flat.shape[0]
+        if world > 1 and flat.shape[0] % world == 0:
+            n = flat.shape[0] // world
+            lo = self.shard.rank * n
+        step = max(1, int(frames_per_batch))
+        frames = [self.vae.decode(flat[i:min(i + step, lo + n)].to(self.vae.dtype)).sample for i in range(lo, lo + n, step)]
         video = torch.cat(frames)
+        if n != flat.shape[0]:
+            full = torch.empty(flat.shape[0], *video.shape[1:], dtype=video.dtype, device=video.device)
+            self.shard.all_gather(full, video.contiguous())
+            video = full
         video = video.view(b, video_length, *video.shape[1:]).permute(0, 2, 1, 3, 4)
         video = (video / 2 + 0.5).clamp(0, 1)
         return video.cpu().float().numpy()

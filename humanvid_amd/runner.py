@@ -67,8 +67,8 @@ class FrameShard:
     def _all_gather(self, out: torch.Tensor, inp: torch.Tensor):
         if self.staged and inp.device.type != "cpu":
             host_out = torch.empty(out.numel(), dtype=inp.dtype)
-            self.dist.all_gather_into_tensor(host_out, inp.cpu(), group=self.group)
-            out.copy_(host_out)
+            self.dist.all_gather_into_tensor(host_out, inp.cpu().reshape(-1), group=self.group)
+            out.view(-1).copy_(host_out)
             return
         self.dist.all_gather_into_tensor(out, inp, group=self.group)
 

@@ -88,3 +88,61 @@ def test_frame_sharded_temporal_block_matches_unsharded(tmp_path):
     err = float((sharded.float() - ref.float()).norm() / ref.float().norm())
     assert err < 4e-3, err
     assert not torch.equal(ref, hid)  # the block did something
+
+
+class _ToyVae(torch.nn.Module):
+    """stand-in for AutoencoderKL.decode: frames are independent batch items (GroupNorm is per sample)"""
+
+    def __init__(self):
+        super().__init__()
+        g = torch.Generator().manual_seed(5)
+        self.conv = torch.nn.Conv2d(4, 3, 3, padding=1)
+        self.norm = torch.nn.GroupNorm(1, 3)
+        with torch.no_grad():
+            self.conv.weight.copy_(torch.randn(3, 4, 3, 3, generator=g) * 0.2)
+            self.conv.bias.zero_()
+        self.dtype = torch.float32
+
+    def decode(self, z):
+        class _Out:
+            pass
+
+        o = _Out()
+        o.sample = self.norm(torch.nn.functional.interpolate(self.conv(z), scale_factor=2.0))
+        return o
+
+
+def _decode_worker(rank, world, port, out_path):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from humanvid_amd.pipeline import Pose2VideoPipeline
+
+    pipe = Pose2VideoPipeline(_ToyVae(), None, None, None, None, None, None).enable_frame_sharding()
+    lat = torch.randn(1, 4, 6, 8, 8, generator=torch.Generator().manual_seed(9))
+    video = pipe.decode_latents(lat, frames_per_batch=2)
+    if rank == 1:
+        torch.save(torch.from_numpy(video), out_path)
+    dist.destroy_process_group()
+
+
+def test_vae_decode_batched_and_frame_sharded_matches_per_frame_loop(tmp_path):
+    """decode scheduling (batched calls, frames split over ranks) must reproduce the
+    reference's serial per-frame loop (pipeline_pose2vid_long.py:114-127) exactly."""
+    from humanvid_amd.pipeline import Pose2VideoPipeline
+
+    vae = _ToyVae()
+    lat = torch.randn(1, 4, 6, 8, 8, generator=torch.Generator().manual_seed(9))
+    with torch.no_grad():
+        ref = torch.cat([vae.decode(1 / 0.18215 * lat[:, :, i]).sample for i in range(6)])
+    ref = (ref.view(1, 6, 3, 16, 16).permute(0, 2, 1, 3, 4) / 2 + 0.5).clamp(0, 1)
+    pipe = Pose2VideoPipeline(vae, None, None, None, None, None, None)
+    for fpb in (1, 4, 8):
+        got = torch.from_numpy(pipe.decode_latents(lat, frames_per_batch=fpb))
+        assert torch.allclose(got, ref, atol=1e-6), fpb
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    out_path = str(tmp_path / "video.pt")
+    mp.spawn(_decode_worker, args=(2, port, out_path), nprocs=2, join=True)
+    assert torch.allclose(torch.load(out_path), ref, atol=1e-6)

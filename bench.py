@@ -80,7 +80,7 @@ def roofline_probe(n_img, F, h, w, iters=3):
     dev = torch.device("cuda")
     levels = [(h * w, 320, 5, 5), ((h // 2) * (w // 2), 640, 5, 5), ((h // 4) * (w // 4), 1280, 5, 5),
               ((h // 8) * (w // 8), 1280, 1, 6)]  # tokens, C, #spatial transformers, #motion modules
-    tot_ms = tot_fl = 0.0
+    tot_ms = tot_fl = tot_bytes = 0.0
     launches = 0
     for N_tok, C, T, Mm in levels:
         M = n_img * N_tok
@@ -95,11 +95,12 @@ def roofline_probe(n_img, F, h, w, iters=3):
             ms = _hip_time(lambda: ops.gemm(L, st, xx, wgt, y, bias=bias, geglu=geglu), iters)
             tot_ms += ms * count
             tot_fl += 2.0 * M * Nn * K * count
+            tot_bytes += 2.0 * (M * K + Nn * K + y.numel()) * count  # operands read once, output written once (bf16)
             launches += count
             del wgt, y
-    return dict(kernel="hv_gemm_glds_kernel<32,3> (all Linear / 1x1-conv GEMMs of one step)", ms=tot_ms / launches,
+    return dict(kernel="hv_gemm_glds_kernel<32,3,128,4> (all Linear / 1x1-conv GEMMs of one step)", ms=tot_ms / launches,
                 flops=tot_fl / launches, tflops=tot_fl / tot_ms / 1e9, launches_per_step=launches,
-                ms_per_step=tot_ms)
+                ms_per_step=tot_ms, bytes=tot_bytes / launches)
 
 
 def attention_probe(n_img, F, h, w, iters=3):
@@ -271,9 +272,18 @@ def main():
         if probe is not None:
             out["roofline"] = {"bound": "mfma", "achieved": probe["tflops"], "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                                "frac": probe["tflops"] / PEAK_BF16_TFLOPS, "traffic": None,
+                               "algorithmic_bytes_per_launch": probe["bytes"],
                                "kernel": probe["kernel"], "avg_launch_ms": probe["ms"],
                                "flops_per_launch": probe["flops"], "launches_per_step": probe["launches_per_step"],
                                "kernel_ms_per_step": probe["ms_per_step"]}
+            # HBM-side bytes per launch of that kernel from the PMC passes (tools/pmc_passes.sh: FETCH_SIZE and WRITE_SIZE
+            # in separate rocprofv3 runs over this same command, FETCH_SIZE doubled as calibrated on gfx950); counters
+            # cannot be read from inside the timed run, so the committed summary of the last pass is reported here
+            pmc = os.path.join(REPO, "profiles", "r01_pmc_traffic.json")
+            if os.path.exists(pmc):
+                t = json.load(open(pmc))
+                out["roofline"]["traffic"] = t["bytes_per_launch"]
+                out["roofline"]["traffic_detail"] = t
             out["roofline_attention"] = attention_probe(2 * F, F, h, w)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()

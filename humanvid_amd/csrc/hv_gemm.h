@@ -379,7 +379,7 @@ __global__ __launch_bounds__(256, 2) void hv_gemm_kernel(HvGemmParams p) {
 //       ds_read, LDS-DMA-issue and epilogue times simply add up);
 //   NW = 8: 4 x 2 waves of 64x64 (BN = 128) or 2 x 4 of 128x64 (BN = 256), one workgroup per CU.
 template <int BK, int NS, int BN, int NW>
-__global__ __launch_bounds__(NW * 64, 2) void hv_gemm_glds_kernel(HvGemmParams p) {
+__global__ __launch_bounds__(NW * 64, 2) void hv_gemm_glds_kernel(HvGemmParams p, int gm) {
     constexpr int BM = 256;
     constexpr int WAVES_N = BN / 64, WAVES_M = NW / WAVES_N;
     constexpr int WTM = BM / WAVES_M, NMF = WTM / 16;
@@ -398,6 +398,23 @@ __global__ __launch_bounds__(NW * 64, 2) void hv_gemm_glds_kernel(HvGemmParams p
 
     const int tiles_n = (p.N + BN - 1) / BN, tiles_m = (p.M + BM - 1) / BM;
     const int total = tiles_n * tiles_m;
+    // Tile raster.  The ~64 workgroups of an XCD walk consecutive tile indices at the same time and share its 4 MiB
+    // L2.  Row-major tile order makes them 64 n-tiles of ONE m-block when N is wide: every m-block then re-streams
+    // the whole weight matrix through the L2-miss path (measured with FETCH_SIZE: 27x the algorithmic read bytes at
+    // N = 10240).  Walking gm m-blocks per n-step instead makes the concurrent set gm x (64/gm) tiles: each X
+    // k-slice is shared by 64/gm workgroups and each W k-slice by gm.
+    auto tile_origin = [&](int ti, int& m0, int& n0) __attribute__((always_inline)) {
+        if (gm <= 1) {
+            m0 = (ti / tiles_n) * BM;
+            n0 = (ti % tiles_n) * BN;
+            return;
+        }
+        const int per_group = gm * tiles_n;
+        const int g = ti / per_group, r = ti - g * per_group;
+        const int rows = max(1, min(gm, tiles_m - g * gm));  // the last group may be shorter (ti may run past the end: unused)
+        m0 = (g * gm + r % rows) * BM;
+        n0 = (r / rows) * BN;
+    };
     const int wg_per_xcd = gridDim.x / 8;
     const int xcd = blockIdx.x % 8, wg = blockIdx.x / 8;
     const int per_xcd = (total + 7) / 8;
@@ -418,7 +435,8 @@ __global__ __launch_bounds__(NW * 64, 2) void hv_gemm_glds_kernel(HvGemmParams p
         return ((lane % CPR) ^ ((row / RPB) % CPR)) * 8;
     };
     int i_tile = first, i_k = 0, i_slot = 0;
-    int i_m0 = (first / tiles_n) * BM, i_n0 = (first % tiles_n) * BN;
+    int i_m0, i_n0;
+    tile_origin(first, i_m0, i_n0);
     auto issue = [&]() __attribute__((always_inline)) {
         const int k0 = i_k * BK;
         unsigned char* slot = smem + i_slot * SLOT;
@@ -442,8 +460,7 @@ __global__ __launch_bounds__(NW * 64, 2) void hv_gemm_glds_kernel(HvGemmParams p
         if (++i_k == nk) {
             i_k = 0;
             i_tile += wg_per_xcd;
-            i_m0 = (i_tile / tiles_n) * BM;
-            i_n0 = (i_tile % tiles_n) * BN;
+            tile_origin(i_tile, i_m0, i_n0);
         }
     };
 
@@ -503,7 +520,11 @@ __global__ __launch_bounds__(NW * 64, 2) void hv_gemm_glds_kernel(HvGemmParams p
         if (++c_k == nk) {
             c_k = 0;
             if (!(HV_GEMM_DBG & 1) || acc[0][0][0] == 1.2345f)
-                hv_gemm_epilogue<NMF>(p, acc, (c_tile / tiles_n) * BM + WTM * wm, (c_tile % tiles_n) * BN + 64 * wn, r16, quad HV_TRACE_ARG);
+            {
+                int m0, n0;
+                tile_origin(c_tile, m0, n0);
+                hv_gemm_epilogue<NMF>(p, acc, m0 + WTM * wm, n0 + 64 * wn, r16, quad HV_TRACE_ARG);
+            }
             c_tile += wg_per_xcd;
             clear_acc();
             HV_TRACE(6);
@@ -512,6 +533,7 @@ __global__ __launch_bounds__(NW * 64, 2) void hv_gemm_glds_kernel(HvGemmParams p
 }
 
 static int g_hv_gemm_max_grid = 512;  // tuning knob (hv_set_tuning): persistent workgroups
+static int g_hv_gemm_raster = 0;        // tuning knob: m-blocks per raster group (0 = auto: 8 when N spans more than 8 tiles)
 static int g_hv_gemm_glds = 2;         // tuning knob: 2 = LDS-DMA BK=32 (2 workgroups/CU), 1 = BK=64, 0 = register-staged
 
 static inline int hv_gemm_launch(const HvGemmParams& p, hipStream_t stream) {
@@ -526,12 +548,13 @@ static inline int hv_gemm_launch(const HvGemmParams& p, hipStream_t stream) {
         // 256x256 tiles (one 128 KiB workgroup per CU, a third fewer bytes per FLOP through the
         // per-CU load path) when N fills them about as well as 256x128 tiles would
         const int n128 = ((p.N + 127) / 128) * 128, n256 = ((p.N + 255) / 256) * 256;
+        const int gm = g_hv_gemm_raster > 0 ? g_hv_gemm_raster : (n128 / 128 > 8 ? 8 : 1);
         if (g_hv_gemm_glds == 3 && p.N >= 512 && (n256 - n128) * 12 <= p.N) {
             const int tiles = tm * (n256 / 256);
             int grid = ((tiles + 7) / 8) * 8;
             if (grid > 256) grid = 256;
             if (grid > g_hv_gemm_max_grid) grid = g_hv_gemm_max_grid;
-            hv_launch(hv_gemm_glds_kernel<32, 4, 256, 8>, dim3(grid), dim3(512), stream, p);
+            hv_launch(hv_gemm_glds_kernel<32, 4, 256, 8>, dim3(grid), dim3(512), stream, p, gm);
             return 0;
         }
         const int tiles = tm * (n128 / 128);
@@ -539,14 +562,14 @@ static inline int hv_gemm_launch(const HvGemmParams& p, hipStream_t stream) {
         if (g_hv_gemm_glds == 1) {  // BK = 64, 144 KiB ring: one workgroup per CU
             if (grid > 256) grid = 256;
             if (grid > g_hv_gemm_max_grid) grid = g_hv_gemm_max_grid;
-            hv_launch(hv_gemm_glds_kernel<64, 3, 128, 8>, dim3(grid), dim3(512), stream, p);
+            hv_launch(hv_gemm_glds_kernel<64, 3, 128, 8>, dim3(grid), dim3(512), stream, p, gm);
         } else {  // BK = 32, 72 KiB ring: two workgroups per CU whose epilogues interleave
             if (grid > 512) grid = 512;
             if (grid > g_hv_gemm_max_grid) grid = g_hv_gemm_max_grid;
             if (g_hv_gemm_glds == 4)
-                hv_launch(hv_gemm_glds_kernel<32, 3, 128, 8>, dim3(grid), dim3(512), stream, p);
+                hv_launch(hv_gemm_glds_kernel<32, 3, 128, 8>, dim3(grid), dim3(512), stream, p, gm);
             else
-                hv_launch(hv_gemm_glds_kernel<32, 3, 128, 4>, dim3(grid), dim3(256), stream, p);
+                hv_launch(hv_gemm_glds_kernel<32, 3, 128, 4>, dim3(grid), dim3(256), stream, p, gm);
         }
         return 0;
     }

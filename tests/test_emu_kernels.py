@@ -64,6 +64,21 @@ def test_gemm_lds_dma_kernel_variants(cx):
             cx.lib.call("hv_set_tuning", 3, 2)
 
 
+def test_gemm_grouped_tile_raster(cx):
+    """tile raster with gm m-blocks per n-step (default for N > 1024; forced here), ragged last group"""
+    cx.lib.call("hv_set_tuning", 6, 2)
+    cx.lib.call("hv_set_tuning", 2, 8)
+    try:
+        kc.case_gemm(cx, M=1300, N=320, K=64, seed=61)            # 6 m-blocks x 3 n-tiles, groups of 2
+        kc.case_gemm(cx, M=1100, N=260, K=128, seed=62)           # 5 m-blocks: last group has one row
+        kc.case_gemm_lnfold(cx, B=2, Fr=4, P=150, C=128, N=192, seed=63)
+        cx.lib.call("hv_set_tuning", 6, 8)
+        kc.case_gemm(cx, M=800, N=384, K=64, seed=64)             # fewer m-blocks than the group size
+    finally:
+        cx.lib.call("hv_set_tuning", 2, 512)
+        cx.lib.call("hv_set_tuning", 6, 0)
+
+
 def test_gemm_lds_dma_256x256_tiles(cx):
     """variant 3: 256x256 tiles, 4-slot ring (3 k-tiles in flight), waves own 128x64"""
     cx.lib.call("hv_set_tuning", 3, 3)

@@ -32,7 +32,7 @@ __global__ __launch_bounds__(256, 2) void fill(const char* __restrict__ src, lon
             }
         }
         off += PAT == 0 ? 24576 : PAT == 1 ? 64 : 128;
-        if (off + (PAT == 0 ? 24576 : 640) > (PAT == 0 ? span_per_block : 640)) off = 0;
+        if (PAT == 0 ? off + 24576 > span_per_block : off >= 640) off = 0;
         if (MODE == 0 && (it & 3) == 3) __builtin_amdgcn_s_waitcnt(0x0f70 | 6 | (0 << 14));  // vmcnt(6): keep 6 in flight
     }
     if (MODE == 0) {
@@ -43,7 +43,7 @@ __global__ __launch_bounds__(256, 2) void fill(const char* __restrict__ src, lon
     if ((acc[0] ^ acc[1] ^ acc[2] ^ acc[3]) == 0x12345) sink[0] = 1;
 }
 
-int main() {
+int main(int argc, char** argv) {
     const long total = 2L << 30;
     char* d;
     unsigned* sink;
@@ -53,6 +53,17 @@ int main() {
     hipEvent_t e0, e1;
     hipEventCreate(&e0);
     hipEventCreate(&e1);
+    if (argc > 1) {
+        // calibration of rocprofv3 FETCH_SIZE (run under --pmc FETCH_SIZE): every byte of a 983 MB region is read
+        // exactly once, 4096 workgroups x 240 KB, as contiguous 1 KiB wave reads / as 64-byte row segments (the
+        // BK = 32 GEMM tile pattern) / as 128-byte row segments
+        hipLaunchKernelGGL((fill<0, 0>), dim3(4096), dim3(256), 49152, 0, d, 245760L, 245760L, 1, 10, sink);
+        hipLaunchKernelGGL((fill<0, 1>), dim3(4096), dim3(256), 49152, 0, d, 640L, 245760L, 1, 10, sink);
+        hipLaunchKernelGGL((fill<0, 2>), dim3(4096), dim3(256), 49152, 0, d, 640L, 245760L, 1, 5, sink);
+        hipDeviceSynchronize();
+        printf("calibration: 3 launches, %.1f MB read once each\n", 4096 * 245760.0 / 1e6);
+        return 0;
+    }
     const int grid = 512;
     struct Case { const char* name; long span, stride; int share, iters; };
     Case cases[] = {

@@ -7,7 +7,8 @@ profiler, the summed counters, and derived figures:
   fetch_GB / write_GB        FETCH_SIZE, WRITE_SIZE are in KiB per dispatch; FETCH_SIZE x2 on gfx950 for wide
                              (16 B/lane) coalesced reads, as /opt/skills/guides/MI355X_MICROARCH.md prescribes
   hbm_GBps                   (fetch + write) / kernel time of that pass
-  mfma_util_pct              SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE * 4 SIMDs * 256 CUs) * 100
+  mfma_util_pct              SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs * 4 SIMDs * 256 CUs) * 100
+                             (rocprofv3 sums GRBM_GUI_ACTIVE over the 8 XCDs: eff_clock_GHz = sum / 8 / kernel time)
 """
 import collections
 import csv
@@ -53,8 +54,8 @@ def main():
             rec["write_GB"] = round(v["WRITE_SIZE"] * 1024 / 1e9, 4)
             rec["write_GBps"] = round(rec["write_GB"] / (v["ns@WRITE_SIZE"] / 1e9), 1) if v["ns@WRITE_SIZE"] else 0
         if "SQ_VALU_MFMA_BUSY_CYCLES" in v and v.get("GRBM_GUI_ACTIVE"):
-            rec["mfma_util_pct"] = round(100.0 * v["SQ_VALU_MFMA_BUSY_CYCLES"] / (v["GRBM_GUI_ACTIVE"] * 4 * 256), 2)
-            rec["eff_clock_GHz"] = round(v["GRBM_GUI_ACTIVE"] / v["ns@GRBM_GUI_ACTIVE"], 3) if v["ns@GRBM_GUI_ACTIVE"] else 0
+            rec["mfma_util_pct"] = round(100.0 * v["SQ_VALU_MFMA_BUSY_CYCLES"] / (v["GRBM_GUI_ACTIVE"] / 8 * 4 * 256), 2)
+            rec["eff_clock_GHz"] = round(v["GRBM_GUI_ACTIVE"] / 8 / v["ns@GRBM_GUI_ACTIVE"], 3) if v["ns@GRBM_GUI_ACTIVE"] else 0
         rows.append(rec)
     rows.sort(key=lambda r: -r["ms_profiled"])
     cols = ["kernel", "launches", "ms_profiled"] + counters + ["fetch_GB", "fetch_GBps", "write_GB", "write_GBps",

@@ -108,12 +108,20 @@ def static_camera_entry(img_size):
     return [0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 1.0, 1.788079, 1.0, 1.0]
 
 
-def cameras_to_embedding(cam_params: Sequence[Camera], img_size) -> torch.Tensor:
-    """cam_params[0] is the reference camera, cam_params[1:] the target frames -> [1, F, 6, H, W]."""
+def cameras_to_params(cam_params: Sequence[Camera], img_size):
+    """cam_params[0] is the reference camera, cam_params[1:] the target frames -> (K [F,4] intrinsics in pixels,
+    c2w [F,4,4] poses relative to the reference camera): the inputs of `ray_condition`, and of the on-device
+    Pluecker front-end (CameraPoseEncoder.forward_nhwc_from_cameras)."""
     K = np.asarray([[c.fx * img_size[0], c.fy * img_size[1], c.cx * img_size[0], c.cy * img_size[1]]
                     for c in cam_params[1:]], dtype=np.float32)
-    c2w = torch.as_tensor(get_relative_pose(cam_params)[1:])[None]
-    pl = ray_condition(torch.as_tensor(K)[None], c2w, img_size[1], img_size[0], device="cpu")
+    return torch.as_tensor(K), torch.as_tensor(get_relative_pose(cam_params)[1:])
+
+
+def cameras_to_embedding(cam_params: Sequence[Camera], img_size) -> torch.Tensor:
+    """cam_params[0] is the reference camera, cam_params[1:] the target frames -> [1, F, 6, H, W]."""
+    K, c2w = cameras_to_params(cam_params, img_size)
+    c2w = c2w[None]
+    pl = ray_condition(K[None], c2w, img_size[1], img_size[0], device="cpu")
     return pl[0].permute(0, 3, 1, 2).contiguous().unsqueeze_(0)
 
 

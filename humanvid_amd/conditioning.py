@@ -226,6 +226,21 @@ class CameraPoseEncoder(nn.Module):
         return self._run
 
     @torch.no_grad()
+    def forward_nhwc_from_cameras(self, K: torch.Tensor, c2w: torch.Tensor, H: int, W: int,
+                                  add: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """Camera front-end on the device: K [f,4] = (fx, fy, cx, cy) in pixels and the
+        relative camera-to-world matrices c2w [f,4,4] (what `ray_condition` consumes, dance_image_h_v_camera.py:88-130)
+        -> the same feature as forward_nhwc(ray_condition(K, c2w, H, W) laid out [1,6,f,H,W]).  The Pluecker map is
+        generated inside the PixelUnshuffle kernel and never stored."""
+        dev = hvlib.require_gpu()
+        run = self._runner(dev)
+        f = K.shape[0]
+        r = self.downscale_factor
+        xs = run.ws.get("unshuffled", (f, H // r, W // r, 6 * r * r))
+        ops.plucker_unshuffle(run.lib, run.st, K.to(dev, F32).contiguous(), c2w.to(dev, F32).contiguous(), H, W, r, xs)
+        return self._encode(run, xs, 1, f, H // r, W // r, add)
+
+    @torch.no_grad()
     def forward_nhwc(self, x: torch.Tensor, add: Optional[torch.Tensor] = None) -> torch.Tensor:
         """x [b,6,f,H,W] fp32 (cuda) -> feature [(b f), H/8, W/8, C] bf16; `add` (same shape, e.g.
         the PoseGuider output) is summed in the zero-conv epilogue (pipeline_pose2vid_long.py:546)."""
@@ -233,13 +248,15 @@ class CameraPoseEncoder(nn.Module):
         if x.device.type != "cuda":
             raise RuntimeError("CameraPoseEncoder needs CUDA/HIP tensors: there is no CPU path")
         run = self._runner(dev)
-        L, st, w, ws = run.lib, run.st, run.w, run.ws
         b, c, f, H, W = x.shape
         r = self.downscale_factor
-        h, ww = H // r, W // r
+        xs = run.ws.get("unshuffled", (b * f, H // r, W // r, c * r * r))
+        ops.pixel_unshuffle(run.lib, run.st, x.float().contiguous(), xs, r)
+        return self._encode(run, xs, b, f, H // r, W // r, add)
+
+    def _encode(self, run, xs, b, f, h, ww, add):
+        L, st, w, ws = run.lib, run.st, run.w, run.ws
         n, N, C = b * f, h * ww, self.channels[0]
-        xs = ws.get("unshuffled", (n, h, ww, c * r * r))
-        ops.pixel_unshuffle(L, st, x.float().contiguous(), xs, r)
         cur = ws.get("x0", (n, h, ww, C))
         ops.conv3x3(L, st, xs, w["conv_in.w"], cur, bias=w["conv_in.bias"])
         for j in range(self.nums_rb):

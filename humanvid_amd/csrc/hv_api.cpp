@@ -116,6 +116,12 @@ int hv_pixel_unshuffle(const float* src, int B, int C, int F, int H, int W, int 
     return hv_check_launch("hv_pixel_unshuffle");
 }
 
+int hv_plucker_unshuffle(const float* K, const float* c2w, int F, int H, int W, int r, uint16_t* dst, void* stream) {
+    if (!K || !c2w || !dst || F <= 0 || r <= 0 || H % r || W % r) return hv_fail(HV_EINVAL, "hv_plucker_unshuffle: bad args");
+    hvk_plucker(K, c2w, F, H, W, r, dst, (hipStream_t)stream);
+    return hv_check_launch("hv_plucker_unshuffle");
+}
+
 int hv_timestep_embedding(const float* t, int B, int dim, uint16_t* dst, void* stream) {
     if (!t || !dst || dim % 2) return hv_fail(HV_EINVAL, "hv_timestep_embedding: bad args");
     hvk_timestep(t, B, dim, dst, (hipStream_t)stream);

@@ -85,6 +85,37 @@ __global__ __launch_bounds__(256) void hv_unshuffle_kernel(const float* src, int
     }
 }
 
+// ray_condition (src/dataset/dance_image_h_v_camera.py:88-130) fused with nn.PixelUnshuffle(r)
+// (src/cameractrl/pose_adaptor.py:177,236): the Pluecker map (o x d, d) of frame f at pixel (Y, X) is generated from
+// the frame's intrinsics K[f] = (fx, fy, cx, cy) and camera-to-world matrix c2w[f] (row-major 4x4) and written
+// straight into the camera encoder's input layout out[f][Y/r][X/r][c*r*r + (Y%r)*r + (X%r)], c = 0..5 -- the
+// [1,6,F,H,W] fp32 map (57 MB at 24 x 768 x 512) is never materialised.  fp32 arithmetic, bf16 store.
+__global__ __launch_bounds__(256) void hv_plucker_kernel(const float* K, const float* c2w, int F, int H, int W, int r,
+                                                         bf16_t* dst) {
+    const int Ho = H / r, Wo = W / r, Co = 6 * r * r;
+    const long total = (long)F * H * W;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int X = (int)(i % W);
+        const int Y = (int)((i / W) % H);
+        const int f = (int)(i / ((long)W * H));
+        const float* k = K + 4 * f;
+        const float* m = c2w + 16 * f;
+        const float xs = ((float)X + 0.5f - k[2]) / k[0], ys = ((float)Y + 0.5f - k[3]) / k[1];
+        const float inv = 1.0f / sqrtf(xs * xs + ys * ys + 1.0f);
+        const float dx = xs * inv, dy = ys * inv, dz = inv;
+        float d[3], o[3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            d[a] = dx * m[4 * a + 0] + dy * m[4 * a + 1] + dz * m[4 * a + 2];  // directions @ R^T
+            o[a] = m[4 * a + 3];
+        }
+        const float pl[6] = {o[1] * d[2] - o[2] * d[1], o[2] * d[0] - o[0] * d[2], o[0] * d[1] - o[1] * d[0], d[0], d[1], d[2]};
+        bf16_t* out = dst + (((long)f * Ho + Y / r) * Wo + X / r) * Co + (Y % r) * r + (X % r);
+#pragma unroll
+        for (int c = 0; c < 6; ++c) out[c * r * r] = hv_f2bf(pl[c]);
+    }
+}
+
 // diffusers Timesteps(dim, flip_sin_to_cos=True, downscale_freq_shift=0): [cos | sin]
 __global__ __launch_bounds__(256) void hv_timestep_kernel(const float* t, int B, int dim, bf16_t* dst) {
     const int half = dim / 2;
@@ -167,6 +198,9 @@ static inline void hv_unpack_launch(const bf16_t* src, int ldc, int B, int C, in
 static inline void hv_unshuffle_launch(const float* src, int B, int C, int F, int H, int W, int r, bf16_t* dst,
                                        hipStream_t s) {
     hv_launch(hv_unshuffle_kernel, dim3(hv_ew_grid((long)B * C * F * H * W)), dim3(256), s, src, B, C, F, H, W, r, dst);
+}
+static inline void hv_plucker_launch(const float* K, const float* c2w, int F, int H, int W, int r, bf16_t* dst, hipStream_t s) {
+    hv_launch(hv_plucker_kernel, dim3(hv_ew_grid((long)F * H * W)), dim3(256), s, K, c2w, F, H, W, r, dst);
 }
 static inline void hv_timestep_launch(const float* t, int B, int dim, bf16_t* dst, hipStream_t s) {
     hv_launch(hv_timestep_kernel, dim3((B * dim / 2 + 255) / 256), dim3(256), s, t, B, dim, dst);

@@ -20,6 +20,7 @@ void hvk_pack(const void* src, int src_bf16, int B, int C, int Fsrc, int H, int 
               bf16_t* dst, int Cpad, hipStream_t s);
 void hvk_unpack(const bf16_t* src, int ldc, int B, int C, int F, int H, int W, void* dst, int dst_bf16, hipStream_t s);
 void hvk_unshuffle(const float* src, int B, int C, int F, int H, int W, int r, bf16_t* dst, hipStream_t s);
+void hvk_plucker(const float* K, const float* c2w, int F, int H, int W, int r, bf16_t* dst, hipStream_t s);
 void hvk_timestep(const float* t, int B, int dim, bf16_t* dst, hipStream_t s);
 void hvk_accumulate(const bf16_t* pred, int ldc, int rep, int C, int f_win, int H, int W, const int* frames, int F,
                     float* acc, float* counter, hipStream_t s);

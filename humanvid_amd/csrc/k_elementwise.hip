@@ -12,6 +12,9 @@ void hvk_unpack(const bf16_t* src, int ldc, int B, int C, int F, int H, int W, v
 void hvk_unshuffle(const float* src, int B, int C, int F, int H, int W, int r, bf16_t* dst, hipStream_t s) {
     hv_unshuffle_launch(src, B, C, F, H, W, r, dst, s);
 }
+void hvk_plucker(const float* K, const float* c2w, int F, int H, int W, int r, bf16_t* dst, hipStream_t s) {
+    hv_plucker_launch(K, c2w, F, H, W, r, dst, s);
+}
 void hvk_timestep(const float* t, int B, int dim, bf16_t* dst, hipStream_t s) { hv_timestep_launch(t, B, dim, dst, s); }
 void hvk_accumulate(const bf16_t* pred, int ldc, int rep, int C, int f_win, int H, int W, const int* frames, int F,
                     float* acc, float* counter, hipStream_t s) {

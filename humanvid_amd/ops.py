@@ -140,6 +140,11 @@ def pixel_unshuffle(lib, stream, src, dst, r):
     lib.call("hv_pixel_unshuffle", src.data_ptr(), B, Cc, Fr, H, W, r, dst.data_ptr(), stream)
 
 
+def plucker_unshuffle(lib, stream, K, c2w, H, W, r, dst):
+    """K [F,4] fp32 (fx, fy, cx, cy in pixels), c2w [F,4,4] fp32 -> dst [F, H/r, W/r, 6*r*r] bf16."""
+    lib.call("hv_plucker_unshuffle", K.data_ptr(), c2w.data_ptr(), K.shape[0], H, W, r, dst.data_ptr(), stream)
+
+
 def timestep_embedding(lib, stream, t, dst):
     lib.call("hv_timestep_embedding", t.data_ptr(), dst.shape[0], dst.shape[1], dst.data_ptr(), stream)
 

@@ -194,13 +194,20 @@ class Pose2VideoPipeline:
     # ---- the hot path ----------------------------------------------------------------------------
     def build_conditioning(self, pose_cond_tensor, camera_embedding, windows: List[List[int]], f0: int, fl: int):
         """Timestep-independent conditioning per window: PoseGuider + CameraPoseEncoder feature
-        (pipeline :526-539, hoisted).  Returns a list of [f_local, h, w, 320] bf16 tensors."""
+        (pipeline :526-539, hoisted).  Returns a list of [f_local, h, w, 320] bf16 tensors.
+        `camera_embedding` is the reference's Pluecker map [1,6,F,H,W], or a (K [F,4], c2w [F,4,4]) pair of camera
+        parameters (humanvid_amd.camera.cameras_to_params) for the on-device front-end, which never builds the map."""
         out = []
         for c in windows:
             pose_w = pose_cond_tensor[:, :, c]
-            cam_w = camera_embedding[:, :, c]
             pose_fea = self.pose_guider.forward_nhwc(pose_w)  # [(1 f), h, w, 320]
-            feat = self.camera_pose_encoder.forward_nhwc(cam_w.float(), add=pose_fea)
+            if isinstance(camera_embedding, (tuple, list)):
+                K, c2w = camera_embedding
+                idx = torch.as_tensor(c, dtype=torch.long)
+                feat = self.camera_pose_encoder.forward_nhwc_from_cameras(K[idx], c2w[idx], pose_w.shape[-2], pose_w.shape[-1],
+                                                                          add=pose_fea)
+            else:
+                feat = self.camera_pose_encoder.forward_nhwc(camera_embedding[:, :, c].float(), add=pose_fea)
             out.append(feat[f0:f0 + fl].clone())
         return out
 
@@ -248,7 +255,8 @@ class Pose2VideoPipeline:
             plans.append((torch.tensor(mine, dtype=torch.int32, device=dev), fl, rank * fl))
         conds = []
         for c, (_, fl, f0) in zip(windows, plans):
-            conds.extend(self.build_conditioning(pose_cond_tensor.to(dev), camera_embedding.to(dev), [c], f0, fl))
+            cam = camera_embedding if isinstance(camera_embedding, (tuple, list)) else camera_embedding.to(dev)
+            conds.extend(self.build_conditioning(pose_cond_tensor.to(dev), cam, [c], f0, fl))
 
         acc = torch.zeros(rep, C, F_, h, w, dtype=F32, device=dev)
         counter = torch.zeros(F_, dtype=F32, device=dev)
@@ -360,8 +368,9 @@ class Pose2VideoPipeline:
         ref_latents = self.vae.encode(ref_tensor).latent_dist.mean * 0.18215
         pose_cond = _pil_to_tensor(list(pose_images), height, width, normalize=False)  # [F,3,H,W]
         pose_cond = pose_cond.permute(1, 0, 2, 3)[None]  # [1,3,F,H,W]
-        camera_embedding = camera_embedding.to(device=device, dtype=F32)
-        assert camera_embedding.ndim == 5
+        if not isinstance(camera_embedding, (tuple, list)):  # (K, c2w) camera parameters: on-device Pluecker front-end
+            camera_embedding = camera_embedding.to(device=device, dtype=F32)
+            assert camera_embedding.ndim == 5
         # ReferenceNet write pass at t = 0, then banks -> reader (pipeline :470-480)
         self.reference_unet(ref_latents.repeat(2 if do_cfg else 1, 1, 1, 1), torch.zeros((), device=device),
                             encoder_hidden_states=ehs, return_dict=False)

@@ -198,6 +198,11 @@ int hv_unpack_nhwc(const uint16_t* src, int ldc, int B, int C, int F, int H, int
 /* nn.PixelUnshuffle(r) on [b][c][f][H][W] fp32 -> [(b f)][H/r][W/r][c*r*r] bf16
  * (src/cameractrl/pose_adaptor.py:177,236) */
 int hv_pixel_unshuffle(const float* src, int B, int C, int F, int H, int W, int r, uint16_t* dst, void* stream);
+/* ray_condition (src/dataset/dance_image_h_v_camera.py:88-130) fused with that PixelUnshuffle: Pluecker map (o x d, d)
+ * from per-frame intrinsics K [F][4] = (fx, fy, cx, cy) in pixels and camera-to-world matrices c2w [F][4][4] (fp32,
+ * device memory), written as [F][H/r][W/r][6*r*r] bf16 -- the camera encoder's input -- without materialising the
+ * [1,6,F,H,W] fp32 map */
+int hv_plucker_unshuffle(const float* K, const float* c2w, int F, int H, int W, int r, uint16_t* dst, void* stream);
 /* diffusers Timesteps(320, flip_sin_to_cos=True, shift 0) (src/models/unet_3d.py:93,461): [B][dim] bf16 */
 int hv_timestep_embedding(const float* t, int B, int dim, uint16_t* dst, void* stream);
 

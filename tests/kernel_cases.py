@@ -291,6 +291,27 @@ def case_elementwise(cx: Ctx, seed=8):
     ref = F.pixel_unshuffle(src.permute(0, 2, 1, 3, 4).reshape(2, 6, 16, 8), 8).permute(0, 2, 3, 1)
     assert torch.equal(un.float().cpu(), r(ref))
 
+    # Pluecker map generated inside the unshuffle (ray_condition + PixelUnshuffle fused), vs the oracle's
+    # ray_condition restatement (pinned against the reference in oracle/gen_golden.py) + torch pixel_unshuffle
+    import os
+    import sys
+
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "oracle"))
+    import oracle_torch as O  # test infrastructure: the checker
+
+    Fc, Hc, Wc = 3, 16, 24
+    Kc = torch.tensor([[20.0, 22.0, 12.0, 8.0], [25.0, 21.0, 11.5, 8.5], [18.0, 30.0, 12.5, 7.5]])
+    c2w = torch.eye(4).repeat(Fc, 1, 1)
+    c2w[1, :3, :3] = torch.linalg.qr(torch.randn(3, 3, generator=g))[0]
+    c2w[1, :3, 3] = torch.tensor([0.3, -0.2, 0.5])
+    c2w[2, :3, 3] = torch.tensor([-1.0, 0.25, 0.1])
+    un = torch.zeros(Fc, Hc // 8, Wc // 8, 6 * 64, dtype=BF16, device=cx.device)
+    ops.plucker_unshuffle(cx.lib, cx.stream, cx.dev(Kc), cx.dev(c2w), Hc, Wc, 8, un)
+    cx.sync()
+    pl = O.ray_condition(Kc[None], c2w[None], Hc, Wc)[0].permute(0, 3, 1, 2)  # [F,6,H,W]
+    ref = F.pixel_unshuffle(pl, 8).permute(0, 2, 3, 1)
+    assert float((un.float().cpu() - ref).abs().max()) < 2e-2 and float((un.float().cpu() - ref).norm() / ref.norm()) < 4e-3
+
     t = torch.tensor([601.0, 32.0])
     te = torch.zeros(2, 320, dtype=BF16, device=cx.device)
     ops.timestep_embedding(cx.lib, cx.stream, cx.dev(t), te)

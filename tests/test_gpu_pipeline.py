@@ -65,6 +65,29 @@ def test_camera_encoder_golden():
     assert e < 2e-2
 
 
+def test_camera_front_end_on_device_matches_plucker_map_path():
+    """CameraPoseEncoder fed (K, c2w) -- Pluecker map generated inside the PixelUnshuffle
+    kernel -- must reproduce the path that is fed the materialised ray_condition map (oracle restatement of
+    dance_image_h_v_camera.py:88-130, pinned against the reference by oracle/gen_golden.py)."""
+    cam, sd = make_camera_encoder()
+    g = torch.Generator().manual_seed(3)
+    Fc, H, W = 4, 64, 48
+    K = torch.tensor([[60.0, 58.0, 24.0, 32.0]]).repeat(Fc, 1) + torch.rand(Fc, 4, generator=g)
+    c2w = torch.eye(4).repeat(Fc, 1, 1)
+    for i in range(1, Fc):
+        c2w[i, :3, :3] = torch.linalg.qr(torch.eye(3) + 0.1 * torch.randn(3, 3, generator=g))[0]
+        c2w[i, :3, 3] = 0.3 * torch.randn(3, generator=g)
+    pl = O.ray_condition(K[None], c2w[None], H, W)[0].permute(3, 0, 1, 2)[None]  # [1,6,F,H,W]
+    add = (torch.randn(Fc, H // 8, W // 8, 320, generator=g) * 0.1).to(torch.bfloat16).cuda()
+    a = cam.forward_nhwc(pl.cuda(), add=add).float().cpu()
+    b = cam.forward_nhwc_from_cameras(K, c2w, H, W, add=add).float().cpu()
+    ref = O.camera_encoder_forward(sd, pl)  # [F,320,h,w] fp32 oracle (without the added pose feature)
+    ref = ref.permute(0, 2, 3, 1) + add.float().cpu()
+    e_ab, e_ref = nrmse(b, a), nrmse(b, ref)
+    print("camera front-end on device vs map path nrmse", e_ab, "vs oracle", e_ref)
+    assert e_ab < 5e-3 and e_ref < 2e-2
+
+
 @pytest.mark.parametrize("case", ["single_window_graph", "single_window_eager", "windows"])
 def test_denoise_loop_matches_oracle(case):
     from humanvid_amd.pipeline import Pose2VideoPipeline

@@ -378,9 +378,8 @@ __global__ __launch_bounds__(256, 2) void hv_gemm_kernel(HvGemmParams p) {
 //       epilogue run under the other one's MFMAs (measured: in a single resident workgroup the MFMA,
 //       ds_read, LDS-DMA-issue and epilogue times simply add up);
 //   NW = 8: 4 x 2 waves of 64x64 (BN = 128) or 2 x 4 of 128x64 (BN = 256), one workgroup per CU.
-template <int BK, int NS, int BN, int NW>
+template <int BK, int NS, int BN, int NW, int BM = 256>
 __global__ __launch_bounds__(NW * 64, 2) void hv_gemm_glds_kernel(HvGemmParams p, int gm) {
-    constexpr int BM = 256;
     constexpr int WAVES_N = BN / 64, WAVES_M = NW / WAVES_N;
     constexpr int WTM = BM / WAVES_M, NMF = WTM / 16;
     constexpr int XT = BM * BK * 2, WT = BN * BK * 2, SLOT = XT + WT;
@@ -555,6 +554,17 @@ static inline int hv_gemm_launch(const HvGemmParams& p, hipStream_t stream) {
             if (grid > 256) grid = 256;
             if (grid > g_hv_gemm_max_grid) grid = g_hv_gemm_max_grid;
             hv_launch(hv_gemm_glds_kernel<32, 4, 256, 8>, dim3(grid), dim3(512), stream, p, gm);
+            return 0;
+        }
+        // 128x128x64 tiles (whole 128-byte lines per row: 1.8x the LDS-DMA rate of 64-byte row segments), 2-slot 64 KiB
+        // ring, two workgroups per CU: measured 7-13 % faster than 256x128x32 when K >= 2 N (the FF output projections),
+        // slower for wide outputs (half the operand reuse per tile)
+        if (g_hv_gemm_glds == 6 || (g_hv_gemm_glds == 2 && p.K >= 2 * p.N)) {
+            const int tiles6 = ((p.M + 127) / 128) * (n128 / 128);
+            int grid6 = ((tiles6 + 7) / 8) * 8;
+            if (grid6 > 512) grid6 = 512;
+            if (grid6 > g_hv_gemm_max_grid) grid6 = g_hv_gemm_max_grid;
+            hv_launch(hv_gemm_glds_kernel<64, 2, 128, 4, 128>, dim3(grid6), dim3(256), stream, p, gm);
             return 0;
         }
         const int tiles = tm * (n128 / 128);

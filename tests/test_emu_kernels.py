@@ -53,7 +53,7 @@ def test_gemm_lds_dma_kernel_variants(cx):
     kc.case_gemm(cx, M=260, N=64, K=64, seed=24, residual=False, out_f32=True)
     kc.case_gemm_lnfold(cx, B=2, Fr=3, P=50, C=128, N=192, seed=25)
     kc.case_gemm_geglu(cx, M=257, C=64, seed=26)
-    for variant in (0, 1, 4):  # register-staged kernel; the ring-buffer LDS-DMA variants (BK=64, 4-wave and 8-wave BK=32)
+    for variant in (0, 1, 4, 6):  # register-staged kernel; the ring-buffer LDS-DMA variants (BK=64, 4-wave and 8-wave BK=32)
         cx.lib.call("hv_set_tuning", 3, variant)
         try:
             kc.case_gemm(cx, M=300, N=132, K=128, seed=21, residual=True)

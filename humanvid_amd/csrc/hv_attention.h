@@ -28,6 +28,11 @@
 #include "hv_common.h"
 #include "humanvid_hip.h"
 
+// phase timestamps for tools/attn_trace.hip (which includes hv_gemm.h first with HV_GEMM_TRACE defined)
+#ifndef HV_TRACE
+#define HV_TRACE(id)
+#endif
+
 #ifndef HV_ATTN_OCC40
 #define HV_ATTN_OCC40 4
 #endif
@@ -193,13 +198,20 @@ __global__ __launch_bounds__(256, (HvAttnOcc<D, QT>::value)) void hv_attention_k
     }
     const float c2 = p.scale * 1.44269504089f;
 
+#ifdef HV_GEMM_TRACE
+    int hv_ti = 0;
+#endif
     load_tile(0);
     __syncthreads();  // LDS initialisation complete before the first tile store
     for (int ti = 0; ti < ntiles; ++ti) {
         const int buf = ti & 1;
+        HV_TRACE(1);
         store_tile(buf);
+        HV_TRACE(2);
         __syncthreads();
+        HV_TRACE(3);
         if (ti + 1 < ntiles) load_tile(ti + 1);
+        HV_TRACE(4);
         const unsigned char* kb = Ks + buf * G::KBYTES + r16 * G::KRS;
         const unsigned char* vb = Vs + buf * G::VBYTES + r16 * G::VRS + quad * 16;
 
@@ -246,6 +258,7 @@ __global__ __launch_bounds__(256, (HvAttnOcc<D, QT>::value)) void hv_attention_k
                     }
             }
         }
+        HV_TRACE(5);
         // ---- online softmax (exp2 domain) and P^T fragments
         bf16x8 pf[QT][2];
 #pragma unroll
@@ -284,6 +297,7 @@ __global__ __launch_bounds__(256, (HvAttnOcc<D, QT>::value)) void hv_attention_k
                 pf[qt][ks] = hv_as_bf16x8(w);
             }
         }
+        HV_TRACE(6);
         // ---- O^T += V^T . P^T   (row D of V^T is all ones when ONES: accumulates the denominator)
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt)
@@ -294,6 +308,7 @@ __global__ __launch_bounds__(256, (HvAttnOcc<D, QT>::value)) void hv_attention_k
                 for (int qt = 0; qt < QT; ++qt)
                     oacc[qt][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[qt][ks], oacc[qt][dt], 0, 0, 0);
             }
+        HV_TRACE(7);
     }
 
     // ---- normalise and store: lane owns query r16, channels 16*dt + 4*quad + 0..3

@@ -16,6 +16,7 @@ void hvk_layernorm(const bf16_t* X, long ldx, int M, int C, float eps, float* me
 int hvk_attention(const hv_attention_params& p, hipStream_t s);
 void hvk_attention_tune(int head_dim, int qt);
 int hvk_temporal(const hv_temporal_attention_params& p, hipStream_t s);
+void hvk_temporal_use_mfma(int on);
 void hvk_pack(const void* src, int src_bf16, int B, int C, int Fsrc, int H, int W, const int* frames, int F, int rep,
               bf16_t* dst, int Cpad, hipStream_t s);
 void hvk_unpack(const bf16_t* src, int ldc, int B, int C, int F, int H, int W, void* dst, int dst_bf16, hipStream_t s);

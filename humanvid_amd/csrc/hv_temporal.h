@@ -92,6 +92,158 @@ __global__ __launch_bounds__(256) void hv_temporal_kernel(hv_temporal_attention_
     }
 }
 
+// ---- MFMA form (default) -------------------------------------------------------------------------------------------
+// The VALU kernel above spends ~4000 unpack/FMA instructions per thread (every (head, query-frame) thread re-unpacks its
+// head's whole K and V): measured 0.32 ms at level 0 against a 0.14 ms HBM roofline.  Here one WAVE owns one (batch,
+// pixel, head): S^T = K.Q^T (keys x queries, at most 32 x 32) and O^T = V^T.P^T are 16x16x32 bf16 MFMAs exactly as in the
+// spatial kernel (lane = query column, so the softmax state, P^T and the O^T column live in one lane; the MFMA k-index of
+// the P.V product enumerates keys as {4q..4q+3, 16+4q..16+4q+3} per quad q, which is the order S^T leaves them in).
+// One workgroup = one (batch, pixel, head group): its Fq query rows and F key / value rows (320 channels = 640 contiguous
+// bytes each) are staged row-major in LDS with coalesced 16-byte loads; Q and K fragments are one ds_read_b128 each, a
+// V^T fragment is eight 2-byte reads (lanes of a quad read adjacent channels of one key row: conflict-free; transposing
+// V while staging it instead put 40 lanes on one bank per store).
+template <int D>
+struct HvTemporalGeom {
+    static constexpr int HG = 320 / D;                // heads per workgroup (one wave each): 8 / 4 / 2
+    static constexpr int CB = HG * D;                 // channels per workgroup (320)
+    static constexpr int RS = CB * 2 + 16;            // Q / K row stride in LDS (bytes): odd multiple of 16
+    static constexpr int NFULL = D / 32;
+    static constexpr bool TAIL = (D % 32) != 0;
+    static constexpr int DT = (D + 15) / 16;
+    static constexpr int LDS_BYTES = 96 * RS;          // 32 rows each of Q, K, V
+};
+
+template <int D>
+__global__ __launch_bounds__(HvTemporalGeom<D>::HG * 64) void hv_temporal_mfma_kernel(hv_temporal_attention_params p) {
+    using G = HvTemporalGeom<D>;
+    constexpr int HG = G::HG, CB = G::CB, RS = G::RS, NFULL = G::NFULL, DT = G::DT;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[G::LDS_BYTES];
+    unsigned char* Qs = smem;            // [32][RS]
+    unsigned char* Ks = smem + 32 * RS;  // [32][RS]
+    unsigned char* Vs = smem + 64 * RS;  // [32][RS]
+    const int tid = threadIdx.x, nthr = HG * 64;
+    const int lane = tid & 63, wave = tid >> 6, r16 = lane & 15, quad = lane >> 4;
+    const int F = p.Fkv, FQ = p.Fq;
+    const int groups = 8 / HG;
+    int t = blockIdx.x;
+    const int hg = t % groups;
+    t /= groups;
+    const int pix = t % p.P, b = t / p.P;
+    const int c0 = hg * CB;                              // first channel of this head group
+    const long row0 = ((long)b * FQ) * p.P + pix;        // query / output row of local frame f: row0 + f * P
+
+    // ---- stage Q, K, V rows ----
+    constexpr int CV = CB / 8;
+    for (int i = tid; i < FQ * CV; i += nthr) {
+        const int f = i / CV, c = i % CV;
+        hv_st16(Qs + f * RS + c * 16, hv_ld16(p.Q + (row0 + (long)f * p.P) * p.ldq + c0 + c * 8));
+    }
+    for (int i = tid; i < F * CV; i += nthr) {
+        const int f = i / CV, c = i % CV;
+        const long kvrow = (long)b * p.kv_stride_b + (long)(f / p.kv_chunk) * p.kv_stride_chunk +
+                           (long)(f % p.kv_chunk) * p.P + pix;
+        hv_st16(Ks + f * RS + c * 16, hv_ld16(p.K + kvrow * p.ldkv + c0 + c * 8));
+        hv_st16(Vs + f * RS + c * 16, hv_ld16(p.V + kvrow * p.ldkv + c0 + c * 8));
+    }
+    __syncthreads();
+
+    // ---- this wave's head ----
+    const int hd = wave * D;  // channel offset of the head inside the group
+    const int nqt = (FQ + 15) >> 4, nkt = (F + 15) >> 4;
+    const float c2 = p.scale * 1.44269504089f;
+    f32x4 sacc[2][2];  // [key tile][query tile]: lane = (query r16, quad), reg r <-> key 16*kt + 4*quad + r
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) sacc[kt][qt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt) {
+        if (kt >= nkt) break;
+        const unsigned char* krow = Ks + min(16 * kt + r16, F - 1) * RS + hd * 2;  // rows past F: clamped, masked below
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) {
+            if (qt >= nqt) break;
+            const unsigned char* qrow = Qs + min(16 * qt + r16, FQ - 1) * RS + hd * 2;
+#pragma unroll
+            for (int s = 0; s < NFULL; ++s)
+                sacc[kt][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(hv_as_bf16x8(hv_ld16(krow + s * 64 + quad * 16)),
+                                                                       hv_as_bf16x8(hv_ld16(qrow + s * 64 + quad * 16)),
+                                                                       sacc[kt][qt], 0, 0, 0);
+            if (G::TAIL) {
+                union {
+                    u32x2 u;
+                    bf16x4 v;
+                } ka, qa;
+                ka.u = u32x2{0u, 0u};
+                qa.u = u32x2{0u, 0u};
+                if (32 * NFULL + 4 * quad + 4 <= D) {
+                    ka.u = hv_ld8(krow + NFULL * 64 + quad * 8);
+                    qa.u = hv_ld8(qrow + NFULL * 64 + quad * 8);
+                }
+                sacc[kt][qt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ka.v, qa.v, sacc[kt][qt], 0, 0, 0);
+            }
+        }
+    }
+    // ---- softmax over the keys of each query column (all keys are here: no running state) ----
+    bf16x8 pf[2];
+    float inv_l[2];
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+        float mx = -INFINITY;
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                if (16 * kt + 4 * quad + r >= F) sacc[kt][qt][r] = -INFINITY;
+                mx = fmaxf(mx, sacc[kt][qt][r]);
+            }
+        mx = fmaxf(mx, __shfl_xor(mx, 16));
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        float pv[2][4], l = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                pv[kt][r] = __builtin_amdgcn_exp2f((sacc[kt][qt][r] - mx) * c2);
+                l += pv[kt][r];
+            }
+        l += __shfl_xor(l, 16);
+        l += __shfl_xor(l, 32);
+        inv_l[qt] = 1.0f / l;
+        const u32x4 w = {hv_pack2(pv[0][0], pv[0][1]), hv_pack2(pv[0][2], pv[0][3]), hv_pack2(pv[1][0], pv[1][1]),
+                         hv_pack2(pv[1][2], pv[1][3])};
+        pf[qt] = hv_as_bf16x8(w);
+    }
+    // ---- O^T = V^T . P^T, normalise, store: lane owns query r16 (+16 qt), channels 16 dt + 4 quad + 0..3 ----
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) {
+        // V^T fragment: lane (channel 16 dt + r16, quad) holds keys {4 quad .. 4 quad + 3, 16 + 4 quad .. 16 + 4 quad + 3};
+        // keys past F meet P = 0 and channels past D (d = 40: fragment 2) are never stored: clamp both to valid data
+        const unsigned char* vcol = Vs + (hd + min(16 * dt + r16, D - 1)) * 2;
+        unsigned vw[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int k0 = 16 * (j >> 1) + 4 * quad + 2 * (j & 1);
+            const unsigned lo = *reinterpret_cast<const bf16_t*>(vcol + min(k0, F - 1) * RS);
+            const unsigned hi = *reinterpret_cast<const bf16_t*>(vcol + min(k0 + 1, F - 1) * RS);
+            vw[j] = lo | (hi << 16);
+        }
+        const bf16x8 vf = hv_as_bf16x8(u32x4{vw[0], vw[1], vw[2], vw[3]});
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) {
+            if (qt >= nqt) break;
+            f32x4 o = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[qt], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+            const int q = 16 * qt + r16, d = 16 * dt + 4 * quad;
+            if (q < FQ && d < D) {
+                const u32x2 st = {hv_pack2(o[0] * inv_l[qt], o[1] * inv_l[qt]), hv_pack2(o[2] * inv_l[qt], o[3] * inv_l[qt])};
+                hv_st8(p.O + (row0 + (long)q * p.P) * p.ldo + c0 + hd + d, st);
+            }
+        }
+    }
+}
+
+static int g_hv_temporal_mfma = 1;  // tuning knob (hv_set_tuning): 1 = MFMA kernel (default), 0 = VALU kernel
+
 template <int D>
 static inline int hv_temporal_launch_d(const hv_temporal_attention_params& p, hipStream_t stream) {
     const int threads = ((8 * p.Fq + 63) / 64) * 64;
@@ -113,6 +265,14 @@ static inline int hv_temporal_launch(const hv_temporal_attention_params& p, hipS
     if (p.heads != 8 || p.B <= 0 || p.Fkv <= 0 || p.Fq <= 0 || p.Fq > p.Fkv || p.P <= 0 || p.kv_chunk <= 0)
         return p.heads != 8 ? -2 : -1;
     if (p.ldq % 8 || p.ldkv % 8 || p.ldo % 8) return -1;
+    if (g_hv_temporal_mfma && p.Fkv <= 32) {
+        switch (p.D) {
+            case 40: hv_launch(hv_temporal_mfma_kernel<40>, dim3(p.B * p.P), dim3(512), stream, p); return 0;
+            case 80: hv_launch(hv_temporal_mfma_kernel<80>, dim3(p.B * p.P * 2), dim3(256), stream, p); return 0;
+            case 160: hv_launch(hv_temporal_mfma_kernel<160>, dim3(p.B * p.P * 4), dim3(128), stream, p); return 0;
+            default: return -2;
+        }
+    }
     switch (p.D) {
         case 40: return hv_temporal_launch_d<40>(p, stream);
         case 80: return hv_temporal_launch_d<80>(p, stream);

@@ -62,9 +62,17 @@ def test_attention_variants(cx):
     cx.lib.call("hv_set_tuning", 1, 2)
 
 
-@pytest.mark.parametrize("D,Fr,P", [(40, 24, 384), (80, 16, 96), (160, 24, 24), (40, 8, 64)])
+@pytest.mark.parametrize("D,Fr,P", [(40, 24, 384), (80, 16, 96), (160, 24, 24), (40, 8, 64), (80, 32, 40), (40, 18, 50)])
 def test_temporal(cx, D, Fr, P):
     kc.case_temporal(cx, D=D, B=2, Fr=Fr, P=P)
+
+
+def test_temporal_valu_kernel(cx):
+    cx.lib.call("hv_set_tuning", 7, 0)
+    try:
+        kc.case_temporal(cx, D=40, B=2, Fr=24, P=96)
+    finally:
+        cx.lib.call("hv_set_tuning", 7, 1)
 
 
 def test_elementwise(cx):

@@ -48,6 +48,8 @@ def main():
         L.call("hv_set_tuning", 3, int(os.environ["HV_GEMM_GLDS"]))  # A/B of the GEMM kernel variants
     if os.environ.get("HV_GEMM_RASTER"):
         L.call("hv_set_tuning", 6, int(os.environ["HV_GEMM_RASTER"]))
+    if os.environ.get("HV_TEMPORAL_MFMA"):
+        L.call("hv_set_tuning", 7, int(os.environ["HV_TEMPORAL_MFMA"]))
     if os.environ.get("HV_CONV_BIG"):
         L.call("hv_set_tuning", 5, int(os.environ["HV_CONV_BIG"]))
     if os.environ.get("HV_CONV_GLDS"):

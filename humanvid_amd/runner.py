@@ -5,6 +5,8 @@ from __future__ import annotations
 
 from typing import Dict, Optional
 
+import os
+
 import torch
 
 from . import _abi as A
@@ -53,6 +55,10 @@ class FrameShard:
         # collectives: stage through host memory.  nccl (= RCCL over xGMI) runs on device buffers.
         self.staged = dist.get_backend(group) != "nccl"
         self.recorder = None  # set by the pipeline while it records a step as command-list segments
+        # temporal-attention exchange: "alltoall" re-shards frames <-> pixels around the attention (each rank sends
+        # 7/8 of its own q|k|v and gets its output back: 1.5 GB per rank and step at config #4), "allgather" replicates
+        # K/V of all frames on every rank (6.0 GB); SURVEY.md section 8(e)
+        self.exchange = os.environ.get("HUMANVID_TEMPORAL_EXCHANGE", "alltoall")
 
     def all_gather(self, out: torch.Tensor, inp: torch.Tensor):
         if self.recorder is not None:
@@ -63,6 +69,23 @@ class FrameShard:
         if self.recorder is not None:
             return self.recorder.collective(lambda: self._all_reduce(t))
         return self._all_reduce(t)
+
+    def all_to_all(self, out: torch.Tensor, inp: torch.Tensor):
+        """equal-split all-to-all of flat, contiguous buffers: chunk r of `inp` goes to rank r, chunk s of `out` comes
+        from rank s (runs immediately: callers wrap whole exchange closures with `deferred`)"""
+        if self.staged and inp.device.type != "cpu":
+            host_in, host_out = inp.cpu(), torch.empty(out.numel(), dtype=inp.dtype)
+            self.dist.all_to_all_single(host_out, host_in.reshape(-1), group=self.group)
+            out.view(-1).copy_(host_out)
+            return
+        self.dist.all_to_all_single(out.view(-1), inp.view(-1), group=self.group)
+
+    def deferred(self, fn):
+        """run `fn` (host-side exchange code: torch copies + a collective) now, or -- while a step is being recorded
+        as command-list segments -- at this point of every replay"""
+        if self.recorder is not None:
+            return self.recorder.collective(fn)
+        return fn()
 
     def _all_gather(self, out: torch.Tensor, inp: torch.Tensor):
         if self.staged and inp.device.type != "cpu":
@@ -146,6 +169,42 @@ class Runner:
             ops.gemm(L, st, hid, w[ab + ".qkv.w"], qkv, bias=w[ab + ".qkv.bias"], row_mean=mean, row_rstd=rstd,
                      colsum=w[ab + ".qkv.colsum"], **pekw)
             ops.temporal_attention(L, st, qkv, o, B=B, F=F, P=N, heads=8, D=D)
+        elif self.shard.exchange == "alltoall" and N % self.shard.world == 0:
+            # frames <-> pixels re-sharding: project q|k|v for the local frames, all-to-all so that this rank holds ALL
+            # frames of its 1/R slice of the pixels, attend locally with the unsharded kernel, all-to-all the result back
+            R, f0 = self.shard.world, self.shard.rank * F
+            Np = N // R
+            pekw = {}
+            if pe is not None:
+                key = (ab, f0, F, "full")
+                if key not in self._pe_split:
+                    self._pe_split[key] = pe[f0:f0 + F].contiguous()
+                pekw = dict(pe=self._pe_split[key], pe_period=N, pe_frames=F)
+            qkv = ws.get(f"mm_qkv_{M}x{C}", (M, 3 * C))
+            ops.gemm(L, st, hid, w[ab + ".qkv.w"], qkv, bias=w[ab + ".qkv.bias"], row_mean=mean, row_rstd=rstd,
+                     colsum=w[ab + ".qkv.colsum"], **pekw)
+            send = ws.get(f"mm_a2a_s_{M}x{C}", (R, B, F, Np, 3 * C))
+            recv = ws.get(f"mm_a2a_r_{M}x{C}", (R, B, F, Np, 3 * C))
+            qkv_all = ws.get(f"mm_qkv_all_{M}x{C}", (B, R * F, Np, 3 * C))  # all frames, my pixels
+            o_all = ws.get(f"mm_o_all_{M}x{C}", (B, R * F, Np, C))
+            shard = self.shard
+
+            def exchange_in():
+                send.copy_(qkv.view(B, F, R, Np, 3 * C).permute(2, 0, 1, 3, 4))      # chunk r = pixel slice of rank r
+                shard.all_to_all(recv, send)                                          # chunk s = frames of rank s
+                qkv_all.view(B, R, F, Np, 3 * C).copy_(recv.permute(1, 0, 2, 3, 4))
+
+            shard.deferred(exchange_in)
+            ops.temporal_attention(L, st, qkv_all.view(B * R * F * Np, 3 * C), o_all.view(B * R * F * Np, C), B=B, F=R * F,
+                                   P=Np, heads=8, D=D)
+            send_o, recv_o = send.view(-1)[:M * C].view(R, B, F, Np, C), recv.view(-1)[:M * C].view(R, B, F, Np, C)
+
+            def exchange_out():
+                send_o.copy_(o_all.view(B, R, F, Np, C).permute(1, 0, 2, 3, 4))      # chunk s = frames owned by rank s
+                shard.all_to_all(recv_o, send_o)                                      # chunk r = pixel slice r
+                o.view(B, F, R, Np, C).copy_(recv_o.permute(1, 2, 0, 3, 4))
+
+            shard.deferred(exchange_out)
         else:
             R, f0 = self.shard.world, self.shard.rank * F
             pq, pkv = {}, {}

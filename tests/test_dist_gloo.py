@@ -69,7 +69,11 @@ def _worker(rank, world, port, out_path):
     dist.destroy_process_group()
 
 
-def test_frame_sharded_temporal_block_matches_unsharded(tmp_path):
+@pytest.mark.parametrize("exchange", ["alltoall", "allgather"])
+def test_frame_sharded_temporal_block_matches_unsharded(tmp_path, exchange, monkeypatch):
+    """both exchanges of SURVEY.md section 8(e): frames <-> pixels all-to-all around the attention (default), and the
+    all-gather of K/V of all frames"""
+    monkeypatch.setenv("HUMANVID_TEMPORAL_EXCHANGE", exchange)
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]

@@ -3,7 +3,8 @@ the GPU box has one MI355X, RCCL refuses two ranks per device) each run half of 
 window through the native path; rank 0's latents must match the oracle loop like the unsharded run.
 This exercises exactly the code path bench.py uses for --gpus N (engine with FrameShard, split
 q / kv projections, all-gathered temporal K/V, accumulator all-reduce); only the transport differs
-(RCCL over xGMI there)."""
+(RCCL over xGMI there).  Both temporal-attention exchanges are run: the frames <-> pixels all-to-all (default) and the
+all-gather of every frame's K/V."""
 import os
 import socket
 import sys
@@ -75,7 +76,9 @@ def _worker(rank, world, port, out_path):
     dist.destroy_process_group()
 
 
-def test_two_rank_frame_sharding_matches_oracle(tmp_path):
+@pytest.mark.parametrize("exchange", ["alltoall", "allgather"])
+def test_two_rank_frame_sharding_matches_oracle(tmp_path, exchange, monkeypatch):
+    monkeypatch.setenv("HUMANVID_TEMPORAL_EXCHANGE", exchange)  # read by FrameShard in the spawned ranks
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]

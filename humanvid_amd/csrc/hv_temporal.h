@@ -265,7 +265,10 @@ static inline int hv_temporal_launch(const hv_temporal_attention_params& p, hipS
     if (p.heads != 8 || p.B <= 0 || p.Fkv <= 0 || p.Fq <= 0 || p.Fq > p.Fkv || p.P <= 0 || p.kv_chunk <= 0)
         return p.heads != 8 ? -2 : -1;
     if (p.ldq % 8 || p.ldkv % 8 || p.ldo % 8) return -1;
-    if (g_hv_temporal_mfma && p.Fkv <= 32) {
+    // d = 80 stays on the VALU kernel: its MFMA instantiation (two 32-deep steps + the 16-deep tail) was wrong and not
+    // run-to-run reproducible on MI355X at F = 24, P = 1536 (tools/diag_determinism.py) while passing on the host
+    // emulator and at the small test shapes -- not understood yet (round-2 item; HV_TUNE_TEMPORAL_MFMA=2 forces it)
+    if (g_hv_temporal_mfma && p.Fkv <= 32 && (p.D != 80 || g_hv_temporal_mfma == 2)) {
         switch (p.D) {
             case 40: hv_launch(hv_temporal_mfma_kernel<40>, dim3(p.B * p.P), dim3(512), stream, p); return 0;
             case 80: hv_launch(hv_temporal_mfma_kernel<80>, dim3(p.B * p.P * 2), dim3(256), stream, p); return 0;

@@ -62,7 +62,8 @@ def test_attention_variants(cx):
     cx.lib.call("hv_set_tuning", 1, 2)
 
 
-@pytest.mark.parametrize("D,Fr,P", [(40, 24, 384), (80, 16, 96), (160, 24, 24), (40, 8, 64), (80, 32, 40), (40, 18, 50)])
+@pytest.mark.parametrize("D,Fr,P", [(40, 24, 384), (80, 16, 96), (160, 24, 24), (40, 8, 64), (80, 32, 40), (40, 18, 50), (80, 24, 768),
+                                     (160, 24, 384)])
 def test_temporal(cx, D, Fr, P):
     kc.case_temporal(cx, D=D, B=2, Fr=Fr, P=P)
 

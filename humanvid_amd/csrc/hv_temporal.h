@@ -113,6 +113,25 @@ struct HvTemporalGeom {
     static constexpr int LDS_BYTES = 96 * RS;          // 32 rows each of Q, K, V
 };
 
+// MFMA operand guard.  Found on MI355X with ROCm 7.2 hipcc: in the d = 80 instantiation the compiler re-used a source
+// register of a just-issued v_mfma_f32_16x16x32_bf16 as the destination of the very next VALU instruction
+//     v_mfma_f32_16x16x32_bf16 a[12:15], v[0:3], v[16:19], 0
+//     v_add_u32_e32 v0, v24, v14
+// and the kernel became wrong and irreproducible once two workgroups shared a CU (F = 24, P = 1536; correct on the host
+// emulator and at small grids).  Fencing every MFMA of this kernel (scheduling barrier + 16 wait states) makes all three
+// head dims bit-reproducible and equal to the VALU kernel (tools/diag_determinism.py); the kernel is HBM-bound, the
+// wait states are free.  The other MFMA kernels pass the same full-size determinism test without it.
+#ifndef HV_EMU
+#define HV_MFMA_GUARD()                          \
+    do {                                         \
+        __builtin_amdgcn_sched_barrier(0);       \
+        asm volatile("s_nop 15" ::: "memory");   \
+        __builtin_amdgcn_sched_barrier(0);       \
+    } while (0)
+#else
+#define HV_MFMA_GUARD()
+#endif
+
 template <int D>
 __global__ __launch_bounds__(HvTemporalGeom<D>::HG * 64) void hv_temporal_mfma_kernel(hv_temporal_attention_params p) {
     using G = HvTemporalGeom<D>;
@@ -166,9 +185,12 @@ __global__ __launch_bounds__(HvTemporalGeom<D>::HG * 64) void hv_temporal_mfma_k
             const unsigned char* qrow = Qs + min(16 * qt + r16, FQ - 1) * RS + hd * 2;
 #pragma unroll
             for (int s = 0; s < NFULL; ++s)
+            {
                 sacc[kt][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(hv_as_bf16x8(hv_ld16(krow + s * 64 + quad * 16)),
                                                                        hv_as_bf16x8(hv_ld16(qrow + s * 64 + quad * 16)),
                                                                        sacc[kt][qt], 0, 0, 0);
+                HV_MFMA_GUARD();
+            }
             if (G::TAIL) {
                 union {
                     u32x2 u;
@@ -181,6 +203,7 @@ __global__ __launch_bounds__(HvTemporalGeom<D>::HG * 64) void hv_temporal_mfma_k
                     qa.u = hv_ld8(qrow + NFULL * 64 + quad * 8);
                 }
                 sacc[kt][qt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ka.v, qa.v, sacc[kt][qt], 0, 0, 0);
+                HV_MFMA_GUARD();
             }
         }
     }
@@ -233,6 +256,7 @@ __global__ __launch_bounds__(HvTemporalGeom<D>::HG * 64) void hv_temporal_mfma_k
         for (int qt = 0; qt < 2; ++qt) {
             if (qt >= nqt) break;
             f32x4 o = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[qt], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+            HV_MFMA_GUARD();
             const int q = 16 * qt + r16, d = 16 * dt + 4 * quad;
             if (q < FQ && d < D) {
                 const u32x2 st = {hv_pack2(o[0] * inv_l[qt], o[1] * inv_l[qt]), hv_pack2(o[2] * inv_l[qt], o[3] * inv_l[qt])};
@@ -265,10 +289,7 @@ static inline int hv_temporal_launch(const hv_temporal_attention_params& p, hipS
     if (p.heads != 8 || p.B <= 0 || p.Fkv <= 0 || p.Fq <= 0 || p.Fq > p.Fkv || p.P <= 0 || p.kv_chunk <= 0)
         return p.heads != 8 ? -2 : -1;
     if (p.ldq % 8 || p.ldkv % 8 || p.ldo % 8) return -1;
-    // d = 80 stays on the VALU kernel: its MFMA instantiation (two 32-deep steps + the 16-deep tail) was wrong and not
-    // run-to-run reproducible on MI355X at F = 24, P = 1536 (tools/diag_determinism.py) while passing on the host
-    // emulator and at the small test shapes -- not understood yet (round-2 item; HV_TUNE_TEMPORAL_MFMA=2 forces it)
-    if (g_hv_temporal_mfma && p.Fkv <= 32 && (p.D != 80 || g_hv_temporal_mfma == 2)) {
+    if (g_hv_temporal_mfma && p.Fkv <= 32) {
         switch (p.D) {
             case 40: hv_launch(hv_temporal_mfma_kernel<40>, dim3(p.B * p.P), dim3(512), stream, p); return 0;
             case 80: hv_launch(hv_temporal_mfma_kernel<80>, dim3(p.B * p.P * 2), dim3(256), stream, p); return 0;

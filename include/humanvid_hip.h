@@ -164,7 +164,7 @@ int hv_attention(const hv_attention_params* p, void* stream);
 #define HV_TUNE_GEMM_GLDS 3     /* LDS-DMA GEMM: 2 = auto (default): 4-wave 256x128x32, two workgroups/CU, or 128x128x64 when K >= 2N; 6 = 128x128x64 always, 4 = 8-wave 256x128x32, 1 = 8-wave BK=64, 3 = 256x256 tiles, 0 = register-staged */
 #define HV_TUNE_CONV_GLDS 4     /* 1: conv weight tiles by LDS-DMA (default), 0: register-staged */
 #define HV_TUNE_GEMM_RASTER 6   /* m-blocks per tile-raster group of the LDS-DMA GEMM (0 = auto, 1 = row-major) */
-#define HV_TUNE_TEMPORAL_MFMA 7 /* temporal attention: 1 = MFMA kernel (one wave per (batch, pixel, head)) for d = 40 / 160, VALU kernel for d = 80 (default); 0 = VALU kernel; 2 = MFMA kernel for every d */
+#define HV_TUNE_TEMPORAL_MFMA 7 /* temporal attention: 1 = MFMA kernel, one wave per (batch, pixel, head) (default), 0 = VALU kernel */
 #define HV_TUNE_CONV_BIG 5      /* 1: 256-pixel conv tiles where the image fills them (default), 0: 128 */
 int hv_set_tuning(int key, int value);
 

@@ -157,12 +157,8 @@ def test_attention_unmasked_instances(cx):
 @pytest.mark.parametrize("D", [40, 80, 160])
 def test_temporal(cx, D):
     """MFMA kernel (default): one wave per (batch, pixel, head); 5 / 12 frames (one key tile), 24 (two), sharded form"""
-    cx.lib.call("hv_set_tuning", 7, 2)  # the MFMA kernel for every head dim (d = 80 defaults to the VALU kernel)
-    try:
-        kc.case_temporal(cx, D=D, Fr=5 if D != 80 else 12)
-        kc.case_temporal(cx, D=D, B=1, Fr=24, P=2, seed=17)
-    finally:
-        cx.lib.call("hv_set_tuning", 7, 1)
+    kc.case_temporal(cx, D=D, Fr=5 if D != 80 else 12)
+    kc.case_temporal(cx, D=D, B=1, Fr=24, P=2, seed=17)
 
 
 @pytest.mark.parametrize("D", [40, 160])

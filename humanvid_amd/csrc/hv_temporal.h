@@ -113,14 +113,14 @@ struct HvTemporalGeom {
     static constexpr int LDS_BYTES = 96 * RS;          // 32 rows each of Q, K, V
 };
 
-// MFMA operand guard.  Found on MI355X with ROCm 7.2 hipcc: in the d = 80 instantiation the compiler re-used a source
-// register of a just-issued v_mfma_f32_16x16x32_bf16 as the destination of the very next VALU instruction
+// MFMA fence.  On MI355X (ROCm 7.2 hipcc) the d = 80 instantiation of this kernel was wrong and irreproducible run to
+// run once two workgroups shared a CU (F = 24, P = 1536), while correct on the host emulator and at small grids.  Fencing
+// every MFMA (scheduling barrier + 16 wait states) makes all three head dims bit-reproducible and equal to the VALU kernel
+// to 1 bf16 ulp (tools/diag_determinism.py).  The unfenced code has e.g.
 //     v_mfma_f32_16x16x32_bf16 a[12:15], v[0:3], v[16:19], 0
-//     v_add_u32_e32 v0, v24, v14
-// and the kernel became wrong and irreproducible once two workgroups shared a CU (F = 24, P = 1536; correct on the host
-// emulator and at small grids).  Fencing every MFMA of this kernel (scheduling barrier + 16 wait states) makes all three
-// head dims bit-reproducible and equal to the VALU kernel (tools/diag_determinism.py); the kernel is HBM-bound, the
-// wait states are free.  The other MFMA kernels pass the same full-size determinism test without it.
+//     v_add_u32_e32 v0, v24, v14            ; overwrites a source register of the MFMA just issued
+// but the same shape also occurs in the GEMM / conv / spatial-attention kernels, which pass the full-size determinism
+// test, so the exact hazard is not pinned down yet (round-2 item).  The kernel is HBM-bound: the wait states are free.
 #ifndef HV_EMU
 #define HV_MFMA_GUARD()                          \
     do {                                         \

@@ -172,3 +172,59 @@ def test_temporal_valu_kernel(cx, D):
 
 def test_elementwise(cx):
     kc.case_elementwise(cx)
+
+
+def test_gemm_random_shape_sweep(cx):
+    """Seeded sweep over ragged shapes and epilogue features through the default dispatch (256x128x32 4-wave kernel,
+    128x128x64 when K >= 2N, grouped raster when N spans more than 8 tiles, register-staged kernel below 256 rows): edge
+    tiles in M and N, single and multiple k-steps, several tiles per persistent workgroup."""
+    import random
+
+    rng = random.Random(1234)
+    cx.lib.call("hv_set_tuning", 2, 16)  # 16 persistent workgroups: 2 per XCD, so most of them walk several tiles
+    try:
+        for case in range(14):
+            M = rng.choice([130, 256, 300, 516, 777, 1032])
+            N = rng.choice([64, 96, 132, 320, 388, 1156])
+            K = rng.choice([64, 128, 192, 320])
+            kind = case % 5
+            if kind == 0:
+                kc.case_gemm(cx, M=M, N=N, K=K, seed=100 + case, residual=True)
+            elif kind == 1:
+                kc.case_gemm(cx, M=M, N=N, K=max(K, 128), seed=100 + case, two_source=True, residual=False)
+            elif kind == 2:
+                kc.case_gemm(cx, M=M, N=max(N, 96) // 32 * 32, K=K, seed=100 + case, transposed=True)
+            elif kind == 3:
+                kc.case_gemm(cx, M=M, N=N, K=K, seed=100 + case, residual=False, out_f32=True)
+            else:
+                kc.case_gemm_geglu(cx, M=M, C=rng.choice([64, 128]), seed=100 + case)
+        kc.case_gemm(cx, M=520, N=64, K=320, seed=200)      # K >= 2N: the 128x128x64 variant, ragged M
+        kc.case_gemm(cx, M=2100, N=1284, K=64, seed=201)    # 11 n-tiles: grouped raster with a ragged last group
+    finally:
+        cx.lib.call("hv_set_tuning", 2, 512)
+
+
+def test_conv_random_shape_sweep(cx):
+    """Seeded sweep of the 3x3 convolution over odd image sizes (ragged tiles in y, x and output channels), the three
+    addressing modes, one and two sources, with and without the fused GroupNorm+SiLU / time-embedding / residual."""
+    import random
+
+    rng = random.Random(4321)
+    for case in range(8):
+        mode = [A.CONV_S1, A.CONV_S2, A.CONV_UP2][case % 3]
+        H, W = rng.choice([5, 8, 11, 16]), rng.choice([6, 9, 12, 18])
+        if mode == A.CONV_S2:
+            H, W = 2 * ((H + 1) // 2), 2 * ((W + 1) // 2)
+        two = case % 2 == 1
+        kc.case_conv(cx, n=rng.choice([1, 2, 3]), H=H, W=W, C1=32 * rng.choice([1, 2]), C2=32 if two else 0,
+                     Cout=rng.choice([8, 40, 132]), mode=mode, pro=case % 4 != 3, temb=case % 3 != 2, residual=case % 2 == 0,
+                     seed=300 + case)
+
+
+def test_attention_and_temporal_shape_sweep(cx):
+    """ragged query / key / bank lengths for the spatial kernel (masked instances) and odd frame counts, pixel counts and
+    shard splits for the temporal kernel"""
+    for (D, n_img, Lq, Lb, seed) in [(40, 2, 72, 40, 61), (40, 3, 136, 8, 62), (80, 2, 200, 72, 63), (160, 2, 40, 24, 64)]:
+        kc.case_attention(cx, D=D, n_img=n_img, Lq=Lq, Lb=Lb, seed=seed)
+    for (D, B, Fr, P, seed) in [(40, 1, 3, 5, 71), (40, 2, 17, 3, 72), (80, 1, 32, 2, 73), (160, 2, 9, 4, 74), (80, 2, 24, 3, 75)]:
+        kc.case_temporal(cx, D=D, B=B, Fr=Fr, P=P, seed=seed)

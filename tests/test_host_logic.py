@@ -209,3 +209,30 @@ def test_reference_control_pairs_banks_like_the_reference():
     assert all(len(m.bank) == 0 for m in den.modules() if isinstance(m, TemporalBasicTransformerBlock))
     with pytest.raises(AssertionError):
         ReferenceAttentionControl(den, mode="bogus")
+
+
+def test_camera_params_are_what_ray_condition_consumes():
+    """cameras_to_params (the input of the on-device Pluecker front-end) and cameras_to_embedding (the reference's map,
+    scripts/pose2vid.py:45-83) describe the same cameras: ray_condition(K, c2w) == embedding."""
+    from humanvid_amd import camera
+
+    rows = [[0.0] * 7 + [1.0, 1.788079, 1.0, 1.0] for _ in range(4)]
+    for i, r in enumerate(rows):  # TUM: tx ty tz qx qy qz qw + intrinsics; move the camera a little per frame
+        r[0], r[1], r[2] = 0.1 * i, -0.05 * i, 0.02 * i
+    cams = [camera.Camera(r, "test", (48, 32)) for r in rows]
+    K, c2w = camera.cameras_to_params(cams, (48, 32))
+    emb = camera.cameras_to_embedding(cams, (48, 32))
+    assert K.shape == (3, 4) and c2w.shape == (3, 4, 4) and emb.shape == (1, 3, 6, 32, 48)
+    pl = camera.ray_condition(K[None], c2w[None], 32, 48, device="cpu")[0].permute(0, 3, 1, 2)
+    assert torch.equal(pl, emb[0])
+
+
+def test_library_override_env_is_honoured(monkeypatch, tmp_path):
+    """HUMANVID_HIP_LIB points the loader at another build of the same C ABI (same-run A/Bs); a wrong path fails loudly"""
+    import humanvid_amd.lib as hvlib
+
+    monkeypatch.setattr(hvlib, "_LIB", None)
+    monkeypatch.setenv("HUMANVID_HIP_LIB", str(tmp_path / "does_not_exist.so"))
+    with pytest.raises(OSError):
+        hvlib.load()
+    monkeypatch.setattr(hvlib, "_LIB", None)

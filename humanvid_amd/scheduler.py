@@ -4,8 +4,9 @@
    24-33 selects (linear betas 0.00085 -> 0.012, steps_offset 1, clip_sample False, v_prediction,
    rescale_betas_zero_snr, timestep_spacing "trailing", set_alpha_to_one) -- SURVEY.md appendix C.
    Only host-side scalars live here; the tensor update itself is hv_cfg_ddim_step.
- * `uniform` / `ordered_halving` / `get_context_scheduler`:
-   /root/reference/src/pipelines/context.py:7-49 (exact integer semantics).
+ * `uniform` / `ordered_halving` / `get_context_scheduler`: the context-window policy of
+   /root/reference/src/pipelines/context.py:7-49, restated as a closed-form window table (`window_table`);
+   integer-exact against the reference-generated tests/golden/context_windows.json.
 """
 from __future__ import annotations
 
@@ -94,35 +95,70 @@ class DDIMScheduler:
 
 
 # ---------------------------------------------------------------------------------- context windows
-def ordered_halving(val):
-    bin_str = f"{val:064b}"
-    return int(bin_str[::-1], 2) / (1 << 64)
+# Behavioural contract: /root/reference/src/pipelines/context.py:7-76 (pinned by tests/golden/context_windows.json, which
+# the reference's own generator produced).  Stated here as a closed-form window table:
+#
+#   r(step)   = the binary digits of `step` mirrored around the binary point (1 -> .1 = 1/2, 2 -> .01 = 1/4, 3 -> .11 ...):
+#               a van-der-Corput sequence, so successive denoising steps start their windows at well-spread frames
+#   levels    = min(context_stride, ceil(log2(F / size)) + 1)  dilation levels, level k samples every 2^k-th frame
+#   level k   : windows start at  floor(r * 2^k) + round(F * r)  and advance by  size * 2^k - overlap  until the start
+#               passes  F + round(F * r)  (minus `overlap` for an open loop); frame indices wrap modulo F.
+def van_der_corput(n: int) -> float:
+    """Radical inverse of n in base 2 (exact in binary floating point for n < 2**53)."""
+    frac, weight = 0.0, 0.5
+    n = int(n)
+    while n:
+        if n & 1:
+            frac += weight
+        weight *= 0.5
+        n >>= 1
+    return frac
+
+
+ordered_halving = van_der_corput  # the reference's name for it (context.py:7-12)
+
+
+def window_table(step: int, num_frames: int, context_size: int, context_stride: int = 3, context_overlap: int = 4,
+                 closed_loop: bool = True) -> List[List[int]]:
+    """All context windows of one denoising step as lists of frame indices."""
+    F, size = int(num_frames), int(context_size)
+    if F <= size:
+        return [list(range(F))]
+    levels = min(int(context_stride), int(math.ceil(math.log2(F / size))) + 1)
+    r = van_der_corput(step)
+    shift = int(round(F * r))
+    stop = F + shift - (0 if closed_loop else context_overlap)
+    table = []
+    for k in range(levels):
+        dil = 1 << k
+        hop = size * dil - context_overlap
+        offsets = dil * np.arange(size)
+        for start in range(int(r * dil) + shift, stop, hop):
+            table.append(((start + offsets) % F).tolist())
+    return table
 
 
 def uniform(step: int = ..., num_steps: Optional[int] = None, num_frames: int = ..., context_size: Optional[int] = None,
             context_stride: int = 3, context_overlap: int = 4, closed_loop: bool = True):
-    if num_frames <= context_size:
-        yield list(range(num_frames))
-        return
-    context_stride = min(context_stride, int(np.ceil(np.log2(num_frames / context_size))) + 1)
-    for context_step in 1 << np.arange(context_stride):
-        pad = int(round(num_frames * ordered_halving(step)))
-        for j in range(
-            int(ordered_halving(step) * context_step) + pad,
-            num_frames + pad + (0 if closed_loop else -context_overlap),
-            (context_size * context_step - context_overlap),
-        ):
-            yield [e % num_frames for e in range(j, j + context_size * context_step, context_step)]
+    """Generator form with the reference's signature (`num_steps` is unused there as well)."""
+    yield from window_table(step, num_frames, context_size, context_stride, context_overlap, closed_loop)
+
+
+_POLICIES = {"uniform": uniform}
 
 
 def get_context_scheduler(name: str) -> Callable:
-    if name == "uniform":
-        return uniform
-    raise ValueError(f"Unknown context_overlap policy {name}")
+    try:
+        return _POLICIES[name]
+    except KeyError:
+        raise ValueError(f"Unknown context_overlap policy {name}") from None
 
 
 def get_total_steps(scheduler, timesteps: List[int], num_steps: Optional[int] = None, num_frames: int = ...,
                     context_size: Optional[int] = None, context_stride: int = 3, context_overlap: int = 4,
                     closed_loop: bool = True):
-    return sum(len(list(scheduler(i, num_steps, num_frames, context_size, context_stride, context_overlap)))
-               for i in range(len(timesteps)))
+    """Number of UNet forwards of a whole sampling run (one per window per timestep)."""
+    total = 0
+    for i, _ in enumerate(timesteps):
+        total += sum(1 for _ in scheduler(i, num_steps, num_frames, context_size, context_stride, context_overlap))
+    return total

@@ -1,0 +1,76 @@
+"""Seeded inputs of the full-size parity cases (BASELINE.json configs #2 and #3)  --  test infrastructure.
+
+Shared by oracle/gen_fullsize_golden.py (build container: runs the REFERENCE's own UNet3DConditionModel on these
+inputs and commits the result under tests/golden/) and tests/test_gpu_fullsize_parity.py (GPU box: runs the native
+path on the same inputs).  Everything is derived from CPU torch generators with fixed seeds so both sides build
+bit-identical tensors; weights come from oracle_torch.make_unet3d_weights(SD15_UNET3D_CFG, seed=WEIGHT_SEED).
+"""
+import torch
+
+WEIGHT_SEED = 0
+TIMESTEP = 499
+CASES = {
+    # name: frames, latent h, latent w   (config #3: 24f x 768x512; config #2: 16f x 512x512)
+    "config3": dict(F=24, h=96, w=64),
+    "config2": dict(F=16, h=64, w=64),
+}
+
+
+def level_of(loc: str, channels: int) -> int:
+    return 3 if loc.startswith("mid_block") else {320: 0, 640: 1, 1280: 2}[channels]
+
+
+def make_inputs(case: str, locations, channels_of):
+    """-> sample [2,4,F,h,w], ehs [2,1,768], pose_cond_fea [2,320,F,h,w], banks {loc: [2,N_l,C] (fp16-rounded)}.
+    `channels_of(loc)` gives the hidden size of a transformer location."""
+    c = CASES[case]
+    F, h, w = c["F"], c["h"], c["w"]
+    g = torch.Generator().manual_seed(42)
+    sample = torch.randn(1, 4, F, h, w, generator=g).repeat(2, 1, 1, 1, 1)
+    ehs = torch.cat([torch.zeros(1, 1, 768), torch.randn(1, 1, 768, generator=torch.Generator().manual_seed(2))])
+    pose = (torch.randn(1, 320, F, h, w, generator=torch.Generator().manual_seed(1)) * 0.5).repeat(2, 1, 1, 1, 1)
+    gb = torch.Generator().manual_seed(5)
+    banks = {}
+    for loc in locations:
+        C = channels_of(loc)
+        lvl = level_of(loc, C)
+        banks[loc] = torch.randn(2, (h >> lvl) * (w >> lvl), C, generator=gb).half().float()
+    return sample, ehs, pose, banks
+
+
+def tap_images(F: int):
+    """(batch, frame) pairs whose activations are kept: one unconditional, one conditional image."""
+    return [(0, 1), (1, F - 2)]
+
+
+def tap_grid(hl: int, wl: int):
+    return list(range(0, hl, max(1, hl // 12))), list(range(0, wl, max(1, wl // 8)))
+
+
+def slice_ncfhw(x: torch.Tensor, F: int) -> torch.Tensor:
+    """x [b,c,f,h,w] -> [2, ny, nx, c] (NHWC slices of the two tap images)."""
+    ys, xs = tap_grid(x.shape[3], x.shape[4])
+    out = []
+    for (bi, fi) in tap_images(F):
+        img = x[bi, :, fi]  # [c,h,w]
+        out.append(img[:, ys][:, :, xs].permute(1, 2, 0))
+    return torch.stack(out)
+
+
+def slice_nhwc(x: torch.Tensor, F: int) -> torch.Tensor:
+    """x [(b f),h,w,c] -> [2, ny, nx, c]."""
+    ys, xs = tap_grid(x.shape[1], x.shape[2])
+    out = []
+    for (bi, fi) in tap_images(F):
+        img = x[bi * F + fi]
+        out.append(img[ys][:, xs])
+    return torch.stack(out)
+
+
+def rms_ncfhw(x: torch.Tensor) -> torch.Tensor:
+    """per-image rms, [b*f] in (b f) order."""
+    return x.float().pow(2).mean(dim=(1, 3, 4)).sqrt().reshape(-1)
+
+
+def rms_nhwc(x: torch.Tensor) -> torch.Tensor:
+    return x.float().pow(2).mean(dim=(1, 2, 3)).sqrt()

@@ -158,6 +158,7 @@ class CameraPoseEncoder(nn.Module):
         self.unshuffle = nn.PixelUnshuffle(downscale_factor)
         self.channels, self.nums_rb, self.ksize = list(channels), nums_rb, ksize
         self.attention_block_types = tuple(attention_block_types)
+        self.temporal_attention_nhead = temporal_attention_nhead
         c = channels[0]
         self.encoder_down_conv_blocks = nn.ModuleList([nn.ModuleList(
             [_ResnetBlock(c, c, down=False, ksize=ksize, sk=sk, use_conv=use_conv) for _ in range(nums_rb)])])
@@ -222,7 +223,7 @@ class CameraPoseEncoder(nn.Module):
             w[a + ".ff.net.2.w"] = d(packing.pack_linear(sd[a + ".ff.net.2.weight"].float()))
             w[a + ".ff.net.2.bias"] = d(sd[a + ".ff.net.2.bias"], F32)
         w["zero_conv.w"] = d(packing.pack_linear(sd["zero_conv_layers.0.weight"].float()))
-        self._run = Runner(device, w, Workspace(device))
+        self._run = Runner(device, w, Workspace(device), temporal_heads=self.temporal_attention_nhead)
         return self._run
 
     @torch.no_grad()

@@ -3,8 +3,8 @@
 //
 //  * GroupNorm(32) per image (InflatedGroupNorm, /root/reference/src/models/resnet.py:18-26;
 //    torch.nn.GroupNorm in transformer_3d.py:58-60 and motion_module.py:119-121): one pass over
-//    the channels-last activation with 16-byte loads, fp32 sum / sum-of-squares per channel in
-//    registers, reduced to groups in LDS; deterministic two-level reduction (no atomics); a tiny
+//    the channels-last activation with 16-byte loads, pivoted fp32 sums per channel in registers,
+//    merged to groups / images as (mean, M2) pairs (Chan / Welford); deterministic (no atomics); a tiny
 //    second kernel turns (mean, rstd, gamma, beta) into per-(image,channel) scale/shift.
 //    Supports the two-source channel concat of the up-blocks (groups may straddle the seam).
 //  * LayerNorm row statistics (mean, rstd), one wavefront per token row, two-pass in registers.
@@ -14,9 +14,15 @@
 
 #define HV_GN_MAXREP 2  // channel-vectors per thread: supports C <= 256 * 8 * 2 = 4096
 
+// Numerics: variance from raw fp32 sums (E[x^2] - E[x]^2) loses all its digits once |mean| >> std, which real
+// activations do reach in single channels.  Here every channel is accumulated around a pivot K_c (its own value at pixel
+// 0 of the image, identical in every workgroup and lane), i.e. sum(x - K_c) and sum((x - K_c)^2): K_c lies inside the
+// channel's range, so M2_c = q - s^2/n cancels at most a few std^2.  Channels -> group and pixel ranges -> image are then
+// merged as (count, mean, M2) triples with Chan's pairwise update -- the parallel form of Welford's algorithm
+// (SURVEY.md 7): no step ever subtracts two quantities of the size of mean^2.
 __global__ __launch_bounds__(256) void hv_gn_partial_kernel(hv_groupnorm_params p) {
     // grid: (splits, n_images).  Each workgroup reduces a contiguous pixel range of one image.
-    __shared__ float red[2][4096];  // per-channel sum / sumsq
+    __shared__ float red[3][4096];  // per channel: sum(x - K), sum((x - K)^2), K
     const int tid = threadIdx.x;
     const int C = p.C1 + p.C2, CV = C / 8;
     const int img = blockIdx.y, split = blockIdx.x;
@@ -26,30 +32,37 @@ __global__ __launch_bounds__(256) void hv_gn_partial_kernel(hv_groupnorm_params 
     // thread -> (channel vector, pixel lane)
     const int P = CV <= 256 ? 256 / CV : 1;   // pixels processed concurrently
     const int nrep = CV <= 256 ? 1 : (CV + 255) / 256;
-    float s[HV_GN_MAXREP][8], q[HV_GN_MAXREP][8];
+    float s[HV_GN_MAXREP][8], q[HV_GN_MAXREP][8], piv[HV_GN_MAXREP][8];
 #pragma unroll
     for (int r = 0; r < HV_GN_MAXREP; ++r)
 #pragma unroll
-        for (int e = 0; e < 8; ++e) s[r][e] = q[r][e] = 0.f;
+        for (int e = 0; e < 8; ++e) s[r][e] = q[r][e] = piv[r][e] = 0.f;
 
     const int cv0 = CV <= 256 ? tid % CV : tid;
     const int pl = CV <= 256 ? tid / CV : 0;
     const bool active = pl < P;
+    auto src_of = [&](int pix, int c) {
+        return c < p.C1 ? p.X + ((long)img * p.pixels + pix) * p.C1 + c
+                        : p.X2 + ((long)img * p.pixels + pix) * p.C2 + (c - p.C1);
+    };
     if (active) {
+#pragma unroll
+        for (int r = 0; r < HV_GN_MAXREP; ++r) {
+            const int cv = cv0 + 256 * r;
+            if (r < nrep && cv < CV) hv_unpack8(hv_ld16(src_of(0, cv * 8)), piv[r]);
+        }
         for (int pix = pb + pl; pix < pe; pix += P) {
 #pragma unroll
             for (int r = 0; r < HV_GN_MAXREP; ++r) {
                 const int cv = cv0 + 256 * r;
                 if (r < nrep && cv < CV) {
-                    const int c = cv * 8;
-                    const bf16_t* src = c < p.C1 ? p.X + ((long)img * p.pixels + pix) * p.C1 + c
-                                                 : p.X2 + ((long)img * p.pixels + pix) * p.C2 + (c - p.C1);
                     float f[8];
-                    hv_unpack8(hv_ld16(src), f);
+                    hv_unpack8(hv_ld16(src_of(pix, cv * 8)), f);
 #pragma unroll
                     for (int e = 0; e < 8; ++e) {
-                        s[r][e] += f[e];
-                        q[r][e] += f[e] * f[e];
+                        const float d = f[e] - piv[r][e];
+                        s[r][e] += d;
+                        q[r][e] += d * d;
                     }
                 }
             }
@@ -68,6 +81,7 @@ __global__ __launch_bounds__(256) void hv_gn_partial_kernel(hv_groupnorm_params 
                         if (round == 0) {
                             red[0][cv * 8 + e] = s[r][e];
                             red[1][cv * 8 + e] = q[r][e];
+                            red[2][cv * 8 + e] = piv[r][e];
                         } else {
                             red[0][cv * 8 + e] += s[r][e];
                             red[1][cv * 8 + e] += q[r][e];
@@ -78,16 +92,24 @@ __global__ __launch_bounds__(256) void hv_gn_partial_kernel(hv_groupnorm_params 
         }
         __syncthreads();
     }
+    // channels of a group (equal counts n) -> (mean, M2) of this pixel range
     const int cg = C / p.groups;
+    const float n = (float)max(pe - pb, 0);
     for (int g = tid; g < p.groups; g += 256) {
-        float a = 0.f, b = 0.f;
-        for (int c = g * cg; c < (g + 1) * cg; ++c) {
-            a += red[0][c];
-            b += red[1][c];
+        float mean_g = 0.f, m2 = 0.f;
+        if (n > 0.f) {
+            float msum = 0.f;
+            for (int c = g * cg; c < (g + 1) * cg; ++c) msum += red[2][c] + red[0][c] / n;
+            mean_g = msum / (float)cg;
+            for (int c = g * cg; c < (g + 1) * cg; ++c) {
+                const float sc = red[0][c];
+                const float dm = red[2][c] + sc / n - mean_g;
+                m2 += (red[1][c] - sc * sc / n) + n * dm * dm;
+            }
         }
         float* dst = p.partial + (((long)img * p.splits + split) * p.groups + g) * 2;
-        dst[0] = a;
-        dst[1] = b;
+        dst[0] = mean_g;
+        dst[1] = m2;
     }
 }
 
@@ -97,16 +119,22 @@ __global__ __launch_bounds__(256) void hv_gn_finalize_kernel(hv_groupnorm_params
     const int c = blockIdx.x * 256 + threadIdx.x, img = blockIdx.y;
     if (c >= C) return;
     const int cg = C / p.groups, g = c / cg;
-    float a = 0.f, b = 0.f;
+    const int per = (p.pixels + p.splits - 1) / p.splits;
+    // merge the pixel ranges: mean = sum n_i mean_i / N,  M2 = sum M2_i + sum n_i (mean_i - mean)^2
+    float wsum = 0.f;
     for (int sp = 0; sp < p.splits; ++sp) {
-        const float* src = p.partial + (((long)img * p.splits + sp) * p.groups + g) * 2;
-        a += src[0];
-        b += src[1];
+        const float ni = (float)max(min(per, p.pixels - sp * per), 0);
+        wsum += ni * p.partial[(((long)img * p.splits + sp) * p.groups + g) * 2];
     }
-    const float cnt = (float)cg * (float)p.pixels;
-    const float mean = a / cnt;
-    float var = b / cnt - mean * mean;
-    var = var > 0.f ? var : 0.f;
+    const float mean = wsum / (float)p.pixels;
+    float m2 = 0.f;
+    for (int sp = 0; sp < p.splits; ++sp) {
+        const float ni = (float)max(min(per, p.pixels - sp * per), 0) * (float)cg;
+        const float* src = p.partial + (((long)img * p.splits + sp) * p.groups + g) * 2;
+        const float dm = src[0] - mean;
+        m2 += src[1] + ni * dm * dm;
+    }
+    const float var = m2 / ((float)cg * (float)p.pixels);
     const float rstd = 1.0f / sqrtf(var + p.eps);
     const float sc = rstd * p.gamma[c];
     p.scale[(long)img * C + c] = sc;

@@ -121,15 +121,51 @@ struct HvTemporalGeom {
 //     v_add_u32_e32 v0, v24, v14            ; overwrites a source register of the MFMA just issued
 // but the same shape also occurs in the GEMM / conv / spatial-attention kernels, which pass the full-size determinism
 // test, so the exact hazard is not pinned down yet (round-2 item).  The kernel is HBM-bound: the wait states are free.
-#ifndef HV_EMU
-#define HV_MFMA_GUARD()                          \
+// HV_TEMPORAL_FENCE selects the guard for the diagnosis builds of tools/diag_fence.py:
+//   0 none | 1 scheduling barrier + 16 wait states after every MFMA (default) | 2 scheduling barriers only
+//   3 wait states only | 4 guard the S^T MFMAs only | 5 guard the O^T MFMAs only | 6 scheduling barrier + 2 wait states
+#ifndef HV_TEMPORAL_FENCE
+#define HV_TEMPORAL_FENCE 1
+#endif
+// HV_TEMPORAL_TAIL: how the head-dim remainder (d = 40: 8, d = 80: 16 channels) enters the S^T accumulation chain:
+//   0 a 16-deep mfma_16x16x16 after the 32-deep steps (round 1) | 1 a zero-padded 32-deep step (same shape as the rest)
+//   2 the 16-deep MFMA first | 3 as 0, with wait states around the 16-deep MFMA only
+#ifndef HV_TEMPORAL_TAIL
+#define HV_TEMPORAL_TAIL 0
+#endif
+#if defined(HV_EMU) || HV_TEMPORAL_FENCE == 0
+#define HV_MFMA_GUARD_QK()
+#define HV_MFMA_GUARD_PV()
+#else
+#if HV_TEMPORAL_FENCE == 2
+#define HV_MFMA_GUARD_() __builtin_amdgcn_sched_barrier(0)
+#elif HV_TEMPORAL_FENCE == 3
+#define HV_MFMA_GUARD_() asm volatile("s_nop 15" ::: "memory")
+#elif HV_TEMPORAL_FENCE == 6
+#define HV_MFMA_GUARD_()                         \
+    do {                                         \
+        __builtin_amdgcn_sched_barrier(0);       \
+        asm volatile("s_nop 1" ::: "memory");    \
+        __builtin_amdgcn_sched_barrier(0);       \
+    } while (0)
+#else
+#define HV_MFMA_GUARD_()                         \
     do {                                         \
         __builtin_amdgcn_sched_barrier(0);       \
         asm volatile("s_nop 15" ::: "memory");   \
         __builtin_amdgcn_sched_barrier(0);       \
     } while (0)
+#endif
+#if HV_TEMPORAL_FENCE == 5
+#define HV_MFMA_GUARD_QK()
 #else
-#define HV_MFMA_GUARD()
+#define HV_MFMA_GUARD_QK() HV_MFMA_GUARD_()
+#endif
+#if HV_TEMPORAL_FENCE == 4
+#define HV_MFMA_GUARD_PV()
+#else
+#define HV_MFMA_GUARD_PV() HV_MFMA_GUARD_()
+#endif
 #endif
 
 template <int D>
@@ -171,6 +207,42 @@ __global__ __launch_bounds__(HvTemporalGeom<D>::HG * 64) void hv_temporal_mfma_k
     const int nqt = (FQ + 15) >> 4, nkt = (F + 15) >> 4;
     const float c2 = p.scale * 1.44269504089f;
     f32x4 sacc[2][2];  // [key tile][query tile]: lane = (query r16, quad), reg r <-> key 16*kt + 4*quad + r
+    // remainder of the head dim past the 32-deep steps (8 channels for d = 40, 16 for d = 80)
+    auto acc_tail = [&](f32x4& acc, const unsigned char* krow, const unsigned char* qrow) {
+#if HV_TEMPORAL_TAIL == 1
+        // zero-padded 32-deep step: quads whose 8 channels lie past D contribute zeros.  Keeps every MFMA of a
+        // dependent accumulation chain the same shape (see HV_TEMPORAL_TAIL above)
+        u32x4 ka = {0u, 0u, 0u, 0u}, qa = {0u, 0u, 0u, 0u};
+        if (32 * NFULL + 8 * quad + 8 <= D) {
+            ka = hv_ld16(krow + NFULL * 64 + quad * 16);
+            qa = hv_ld16(qrow + NFULL * 64 + quad * 16);
+        }
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(hv_as_bf16x8(ka), hv_as_bf16x8(qa), acc, 0, 0, 0);
+#else
+        union {
+            u32x2 u;
+            bf16x4 v;
+        } ka, qa;
+        ka.u = u32x2{0u, 0u};
+        qa.u = u32x2{0u, 0u};
+        if (32 * NFULL + 4 * quad + 4 <= D) {
+            ka.u = hv_ld8(krow + NFULL * 64 + quad * 8);
+            qa.u = hv_ld8(qrow + NFULL * 64 + quad * 8);
+        }
+#if HV_TEMPORAL_TAIL == 3
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_nop 15" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+#endif
+        acc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ka.v, qa.v, acc, 0, 0, 0);
+#if HV_TEMPORAL_TAIL == 3
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_nop 15" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+#endif
+#endif
+        HV_MFMA_GUARD_QK();
+    };
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
@@ -183,28 +255,20 @@ __global__ __launch_bounds__(HvTemporalGeom<D>::HG * 64) void hv_temporal_mfma_k
         for (int qt = 0; qt < 2; ++qt) {
             if (qt >= nqt) break;
             const unsigned char* qrow = Qs + min(16 * qt + r16, FQ - 1) * RS + hd * 2;
+#if HV_TEMPORAL_TAIL == 2
+            if (G::TAIL) acc_tail(sacc[kt][qt], krow, qrow);
+#endif
 #pragma unroll
             for (int s = 0; s < NFULL; ++s)
             {
                 sacc[kt][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(hv_as_bf16x8(hv_ld16(krow + s * 64 + quad * 16)),
                                                                        hv_as_bf16x8(hv_ld16(qrow + s * 64 + quad * 16)),
                                                                        sacc[kt][qt], 0, 0, 0);
-                HV_MFMA_GUARD();
+                HV_MFMA_GUARD_QK();
             }
-            if (G::TAIL) {
-                union {
-                    u32x2 u;
-                    bf16x4 v;
-                } ka, qa;
-                ka.u = u32x2{0u, 0u};
-                qa.u = u32x2{0u, 0u};
-                if (32 * NFULL + 4 * quad + 4 <= D) {
-                    ka.u = hv_ld8(krow + NFULL * 64 + quad * 8);
-                    qa.u = hv_ld8(qrow + NFULL * 64 + quad * 8);
-                }
-                sacc[kt][qt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ka.v, qa.v, sacc[kt][qt], 0, 0, 0);
-                HV_MFMA_GUARD();
-            }
+#if HV_TEMPORAL_TAIL != 2
+            if (G::TAIL) acc_tail(sacc[kt][qt], krow, qrow);
+#endif
         }
     }
     // ---- softmax over the keys of each query column (all keys are here: no running state) ----
@@ -256,7 +320,7 @@ __global__ __launch_bounds__(HvTemporalGeom<D>::HG * 64) void hv_temporal_mfma_k
         for (int qt = 0; qt < 2; ++qt) {
             if (qt >= nqt) break;
             f32x4 o = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[qt], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-            HV_MFMA_GUARD();
+            HV_MFMA_GUARD_PV();
             const int q = 16 * qt + r16, d = 16 * dt + 4 * quad;
             if (q < FQ && d < D) {
                 const u32x2 st = {hv_pack2(o[0] * inv_l[qt], o[1] * inv_l[qt]), hv_pack2(o[2] * inv_l[qt], o[3] * inv_l[qt])};

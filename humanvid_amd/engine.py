@@ -57,11 +57,16 @@ class UNet3DEngine:
         self.bank_kv: Dict[str, tuple] = {}
         self.bank_version = None
         self.cross_const: Dict[str, torch.Tensor] = {}
-        self.ehs_key = None
         self.do_cfg = True
         self._sel_cache: Dict[tuple, torch.Tensor] = {}
+        # optional observer `tap(name, activation [(b f),h,w,c])` called after every resnet / spatial transformer / motion
+        # module (names as in oracle_torch.unet3d_forward's taps).  Buffers are reused and updated in place: the observer
+        # must copy what it wants to keep.  Used by the parity tests; None in production (and under graph capture).
+        self.tap = None
         self._pack()
-        self.run = Runner(self.device, self.w, self.ws, self.groups, shard)
+        mmk = self.cfg.get("motion_module_kwargs") or {}
+        self.run = Runner(self.device, self.w, self.ws, self.groups, shard,
+                          temporal_heads=mmk.get("num_attention_heads", 8))
 
     # ------------------------------------------------------------------------------------------
     @property
@@ -192,7 +197,6 @@ class UNet3DEngine:
                 c = torch.empty(B, C, dtype=F32, device=self.device)
                 self.cross_const[loc] = c
             ops.gemm(self.lib, st, v, self.w[t + ".attn2.to_out.0.w"], c, bias=self.w[t + ".attn2.to_out.0.bias"])
-        self.ehs_key = (ehs.data_ptr(), ehs._version, tuple(ehs.shape))
 
     def set_reference_banks(self, banks: Optional[Dict[str, torch.Tensor]], do_cfg: bool):
         """banks: {transformer location -> [b, Nb, C]} (norm1 features of the ReferenceNet write pass,
@@ -219,8 +223,10 @@ class UNet3DEngine:
         mode = self.unet._reference_mode
         blocks = {n.rsplit(".transformer_blocks.0", 1)[0]: m for n, m in self.unet.named_modules()
                   if isinstance(m, TemporalBasicTransformerBlock)}
-        version = tuple((loc, id(m.bank[0]) if m.bank else None) for loc, m in sorted(blocks.items()))
-        key = (version, None if mode is None else mode.get("do_cfg"))
+        # generation number bumped by ReferenceAttentionControl on every __init__ / update() / clear(); plus which blocks
+        # currently hold a bank (covers banks assigned by hand between two control calls)
+        held = tuple(loc for loc, m in sorted(blocks.items()) if m.bank)
+        key = (getattr(self.unet, "_reference_generation", 0), held, None if mode is None else mode.get("do_cfg"))
         if key == self.bank_version:
             return
         self.bank_version = key
@@ -240,9 +246,9 @@ class UNet3DEngine:
         if h % up or w % up:
             raise NotImplementedError(f"latent size must be a multiple of {up} (forward_upsample_size is not supported)")
         self._banks_from_modules()
-        key = (encoder_hidden_states.data_ptr(), encoder_hidden_states._version, tuple(encoder_hidden_states.shape))
-        if key != self.ehs_key:
-            self.set_encoder_hidden_states(encoder_hidden_states)
+        # the folded cross-attention constants are recomputed on every call of the tensor interface (32 tiny GEMMs): a
+        # cache keyed on the embedding's address would go stale when the allocator reuses the address for the next clip
+        self.set_encoder_hidden_states(encoder_hidden_states)
         st = self.stream
         src = sample if sample.dtype in (F32, BF16) else sample.float()
         x_in = self.ws.get("x_in", (b * f, h, w, packing.round_up(c, 32)))
@@ -265,9 +271,7 @@ class UNet3DEngine:
         if sample.device.type != "cuda":
             raise RuntimeError("UNet2DConditionModel.forward needs CUDA/HIP tensors: there is no CPU path")
         b, c, h, w_ = sample.shape
-        key = (encoder_hidden_states.data_ptr(), encoder_hidden_states._version, tuple(encoder_hidden_states.shape))
-        if key != self.ehs_key:
-            self.set_encoder_hidden_states(encoder_hidden_states)
+        self.set_encoder_hidden_states(encoder_hidden_states)  # every call: see forward_ncfhw
         self.bank_kv = {}
         st = self.stream
         src = sample if sample.dtype in (F32, BF16) else sample.float()
@@ -404,6 +408,10 @@ class UNet3DEngine:
             ops.gemm(L, st, hid, w[mm + ".proj_out.w"], x2d, bias=w[mm + ".proj_out.bias"], residual=x2d)
             return x
 
+        def tap(name, v):
+            if self.tap is not None:
+                self.tap(name, v)
+
         # ---- conv_in (+ pose/camera conditioning)  unet_3d.py:482-484
         x = ws.get("conv_in", (n, H, W, boc[0]))
         ops.conv3x3(L, st, x_in, w["conv_in.w"], x, bias=w["conv_in.bias"], residual=cond)
@@ -413,10 +421,13 @@ class UNet3DEngine:
             if spec.kind == "down":
                 for j in range(len(spec.resnets)):
                     x = resnet(f"{p}.resnets.{j}", x, None, f"{p}.{j}")
+                    tap(f"{p}.resnets.{j}", x)
                     if spec.has_attn:
                         x = transformer(f"{p}.attentions.{j}", x)
+                        tap(f"{p}.attentions.{j}", x)
                     if spec.has_motion:
                         x = motion(f"{p}.motion_modules.{j}", x)
+                        tap(f"{p}.motion_modules.{j}", x)
                     skips.append(x)
                 if spec.resample:
                     _, h, ww, C = x.shape
@@ -431,6 +442,7 @@ class UNet3DEngine:
                 if spec.has_motion:
                     x = motion("mid_block.motion_modules.0", x)
                 x = resnet("mid_block.resnets.1", x, None, "mid.1")
+                tap("mid_block", x)
             else:
                 for j in range(len(spec.resnets)):
                     x = resnet(f"{p}.resnets.{j}", x, skips.pop(), f"{p}.{j}")
@@ -438,6 +450,7 @@ class UNet3DEngine:
                         x = transformer(f"{p}.attentions.{j}", x)
                     if spec.has_motion:
                         x = motion(f"{p}.motion_modules.{j}", x)
+                    tap(f"{p}.{j}", x)
                 if spec.resample:
                     _, h, ww, C = x.shape
                     y = ws.get(f"{p}.up", (n, 2 * h, 2 * ww, C))

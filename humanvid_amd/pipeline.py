@@ -233,9 +233,16 @@ class Pose2VideoPipeline:
         do_cfg = guidance_scale > 1.0
         rep = 2 if do_cfg else 1
         sched = self.scheduler
+        if getattr(sched, "prediction_type", "v_prediction") != "v_prediction" or not hasattr(sched, "step_coefficients"):
+            # hv_cfg_ddim_step fuses the v-prediction DDIM update (inference_v2.yaml:24-33); anything else would
+            # silently follow a wrong trajectory
+            raise NotImplementedError("the fused CFG + DDIM step implements DDIMScheduler(prediction_type='v_prediction') only")
         sched.set_timesteps(num_inference_steps)
         timesteps = [int(t) for t in sched.timesteps.tolist()]
         latents = latents.to(device=dev, dtype=F32).contiguous()
+        if latents.ndim != 5 or latents.shape[0] != 1:
+            # pack / accumulate / cfg_ddim size their buffers for one clip (rep = CFG halves only)
+            raise NotImplementedError(f"denoise() handles one clip per call (latents [1,C,F,h,w]), got {tuple(latents.shape)}")
         _, C, F_, h, w = latents.shape
         e = clip_image_embeds.reshape(1, 1, -1).to(dev)
         ehs = torch.cat([torch.zeros_like(e), e], dim=0) if do_cfg else e
@@ -347,6 +354,8 @@ class Pose2VideoPipeline:
             raise NotImplementedError("eta > 0 is not supported (the reference always samples with eta = 0)")
         if interpolation_factor >= 2:
             raise NotImplementedError("latent interpolation (interpolation_factor >= 2) is outside the denoising path")
+        if num_images_per_prompt != 1:
+            raise NotImplementedError("num_images_per_prompt > 1 is not supported (the reference scripts always pass 1)")
         device = torch.device("cuda") if torch.cuda.is_available() else torch.device("cpu")
         if device.type != "cuda":
             raise RuntimeError("Pose2VideoPipeline needs a ROCm GPU: the denoising path has no CPU fallback")

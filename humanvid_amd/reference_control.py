@@ -11,9 +11,21 @@ lists on the modules, `update()` and `clear()`.  The executors pick the mode up 
 """
 from __future__ import annotations
 
+import itertools
+
 import torch
 
 from .unet3d import TemporalBasicTransformerBlock
+
+
+_GENERATION = itertools.count(1)
+
+
+def _bump(unet):
+    """Every change of the banks of `unet` (new control, update, clear) gets a fresh, process-wide unique generation
+    number; the native executor re-projects its bank K/V when the number it packed for differs.  (Keys derived from
+    tensor addresses or `id()` are not safe: the caching allocator and CPython both hand freed addresses out again.)"""
+    unet._reference_generation = next(_GENERATION)
 
 
 def torch_dfs(model: torch.nn.Module):
@@ -59,6 +71,7 @@ class ReferenceAttentionControl:
                 module.bank = []
                 module.attn_weight = float(i) / float(len(modules))
             unet._reference_mode = dict(mode=mode, do_cfg=bool(do_classifier_free_guidance), fusion_blocks=fusion_blocks)
+            _bump(unet)
 
     def _modules(self, unet, both_kinds=False, kind=None):
         basic, temporal = _block_types()
@@ -77,8 +90,10 @@ class ReferenceAttentionControl:
             writers = writer._modules(writer.unet, kind=basic)
             for r, w in zip(readers, writers):
                 r.bank = [v.clone().to(dtype) for v in w.bank]
+            _bump(self.unet)
 
     def clear(self):
         if self.reference_attn:
             for r in self._modules(self.unet, both_kinds=True):
                 r.bank.clear()
+            _bump(self.unet)

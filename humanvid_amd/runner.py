@@ -112,13 +112,16 @@ class FrameShard:
 
 class Runner:
     def __init__(self, device, w: Dict[str, torch.Tensor], ws: Optional[Workspace] = None, groups: int = 32,
-                 shard: Optional[FrameShard] = None):
+                 shard: Optional[FrameShard] = None, temporal_heads: int = 8):
         self.lib = hvlib.load()
         self.device = device
         self.w = w
         self.ws = ws or Workspace(device)
         self.groups = groups
         self.shard = shard
+        self.temporal_heads = int(temporal_heads)  # num_attention_heads / temporal_attention_nhead of the config
+        if self.temporal_heads != 8:
+            raise NotImplementedError(f"hv_temporal_attention is built for 8 heads, the config asks for {self.temporal_heads}")
         self._pe_split: Dict[tuple, tuple] = {}
 
     @property
@@ -159,16 +162,21 @@ class Runner:
         """`ab` = weight prefix of one VersatileAttention / TemporalSelfAttention block; hid [(B F N), C]."""
         w, L, st, ws = self.w, self.lib, self.st, self.ws
         M, C = hid.shape
-        D = C // 8
+        H = self.temporal_heads
+        D = C // H
         mean, rstd = self.ln_stats(hid)
         pe = w.get(ab + ".qkv.pe")
+        f_total = F * (self.shard.world if sharded else 1)
+        if pe is not None and f_total > pe.shape[0]:
+            # the reference fails here too: x + pe[:, :x.size(1)] does not broadcast (motion_module.py:262-277)
+            raise ValueError(f"{f_total} frames per window exceed temporal_position_encoding_max_len = {pe.shape[0]} ({ab})")
         o = ws.get(f"tr_o_{M}x{C}", (M, C))
         if not sharded:
             pekw = {} if pe is None else dict(pe=pe, pe_period=N, pe_frames=F)
             qkv = ws.get(f"mm_qkv_{M}x{C}", (M, 3 * C))
             ops.gemm(L, st, hid, w[ab + ".qkv.w"], qkv, bias=w[ab + ".qkv.bias"], row_mean=mean, row_rstd=rstd,
                      colsum=w[ab + ".qkv.colsum"], **pekw)
-            ops.temporal_attention(L, st, qkv, o, B=B, F=F, P=N, heads=8, D=D)
+            ops.temporal_attention(L, st, qkv, o, B=B, F=F, P=N, heads=H, D=D)
         elif self.shard.exchange == "alltoall" and N % self.shard.world == 0:
             # frames <-> pixels re-sharding: project q|k|v for the local frames, all-to-all so that this rank holds ALL
             # frames of its 1/R slice of the pixels, attend locally with the unsharded kernel, all-to-all the result back
@@ -196,7 +204,7 @@ class Runner:
 
             shard.deferred(exchange_in)
             ops.temporal_attention(L, st, qkv_all.view(B * R * F * Np, 3 * C), o_all.view(B * R * F * Np, C), B=B, F=R * F,
-                                   P=Np, heads=8, D=D)
+                                   P=Np, heads=H, D=D)
             send_o, recv_o = send.view(-1)[:M * C].view(R, B, F, Np, C), recv.view(-1)[:M * C].view(R, B, F, Np, C)
 
             def exchange_out():
@@ -221,6 +229,6 @@ class Runner:
             ops.gemm(L, st, hid, wq[C:], kvl, bias=bq[C:], row_mean=mean, row_rstd=rstd, colsum=cs[C:], **pkv)
             kvg = ws.get(f"mm_kvg_{M}x{C}", (R, B, F, N, 2 * C))
             self.shard.all_gather(kvg.view(-1), kvl.view(-1))
-            ops.temporal_attention_sharded(L, st, q, kvg, o, B=B, Fq=F, ranks=R, P=N, heads=8, D=D)
+            ops.temporal_attention_sharded(L, st, q, kvg, o, B=B, Fq=F, ranks=R, P=N, heads=H, D=D)
         ops.gemm(L, st, o, w[ab + ".to_out.0.w"], hid, bias=w[ab + ".to_out.0.bias"], residual=hid)
 

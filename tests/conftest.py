@@ -10,3 +10,16 @@ if REPO not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def pytest_collection_modifyitems(config, items):
+    """`pytest tests` on a machine without a GPU skips the gpu-marked items instead of erroring.  On a GPU box nothing
+    is skipped: a missing libhumanvid_hip.so must FAIL there (the product has no fallback), not skip."""
+    import torch
+
+    if torch.cuda.is_available():
+        return
+    skip = pytest.mark.skip(reason="needs a ROCm GPU (torch.cuda.is_available() is False)")
+    for item in items:
+        if "gpu" in item.keywords:
+            item.add_marker(skip)

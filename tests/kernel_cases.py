@@ -144,15 +144,17 @@ def case_gemm_geglu(cx: Ctx, M=70, C=64, seed=3):
 
 # ----------------------------------------------------------------------------------------- conv
 def case_conv(cx: Ctx, n=2, H=12, W=20, C1=32, C2=0, Cout=40, mode=A.CONV_S1, pro=True, temb=True, residual=True,
-              out_act=A.ACT_NONE, seed=4):
+              out_act=A.ACT_NONE, seed=4, check=None):
+    """check: image indices the CPU reference is evaluated on (None = all); the kernel always runs all n images."""
     g = torch.Generator().manual_seed(seed)
     Cin = C1 + C2
     x = rnd(g, n, Cin, H, W)
     w, bias = rnd(g, Cout, Cin, 3, 3, scale=(9 * Cin) ** -0.5), rnd(g, Cout, scale=0.1)
     sc, sh = 1 + 0.3 * rnd(g, n, Cin), 0.2 * rnd(g, n, Cin)
-    a = r(x)
+    idx = list(range(n)) if check is None else list(check)
+    a = r(x[idx])
     if pro:
-        a = r(F.silu(a * sc[:, :, None, None] + sh[:, :, None, None]))
+        a = r(F.silu(a * sc[idx][:, :, None, None] + sh[idx][:, :, None, None]))
     if mode == A.CONV_UP2:
         a = F.interpolate(a, scale_factor=2.0, mode="nearest")
     ref = F.conv2d(a, r(w), bias, stride=2 if mode == A.CONV_S2 else 1, padding=1)
@@ -175,16 +177,17 @@ def case_conv(cx: Ctx, n=2, H=12, W=20, C1=32, C2=0, Cout=40, mode=A.CONV_S1, pr
                 rowvec=cx.dev(tv) if temb else None, images_per_rowvec=n,
                 residual=cx.bf(res.permute(0, 2, 3, 1)) if residual else None, out_act=out_act)
     cx.sync()
-    e = nrmse(y.permute(0, 3, 1, 2), ref)
+    e = nrmse(y[idx].permute(0, 3, 1, 2), ref)
     assert e < TOL, f"conv mode {mode} nrmse {e}"
     return e
 
 
 # ----------------------------------------------------------------------------------------- norms
-def case_groupnorm(cx: Ctx, n=3, H=6, W=10, C1=320, C2=0, groups=32, seed=5):
+def case_groupnorm(cx: Ctx, n=3, H=6, W=10, C1=320, C2=0, groups=32, seed=5, offset=0.7, spread=1.0, splits=3):
+    """offset >> spread is the cancellation case of a sum / sum-of-squares variance (|mean| >> std)."""
     g = torch.Generator().manual_seed(seed)
     C = C1 + C2
-    x = rnd(g, n, C, H, W) * (1 + torch.arange(C).view(1, C, 1, 1) % 5) + 0.7
+    x = rnd(g, n, C, H, W) * (1 + torch.arange(C).view(1, C, 1, 1) % 5) * spread + offset
     gamma, beta = 1 + 0.2 * rnd(g, C), 0.1 * rnd(g, C)
     xr = r(x)
     ref = F.group_norm(xr, groups, gamma, beta, 1e-5)
@@ -192,7 +195,7 @@ def case_groupnorm(cx: Ctx, n=3, H=6, W=10, C1=320, C2=0, groups=32, seed=5):
     partial = torch.zeros(n * 64 * groups * 2, device=cx.device)
     scale, shift = torch.zeros(n, C, device=cx.device), torch.zeros(n, C, device=cx.device)
     ops.groupnorm_affine(cx.lib, cx.stream, cx.bf(xh[..., :C1]), cx.dev(gamma), cx.dev(beta), groups, 1e-5, partial,
-                         scale, shift, x2=cx.bf(xh[..., C1:]) if C2 else None, splits=3)
+                         scale, shift, x2=cx.bf(xh[..., C1:]) if C2 else None, splits=splits)
     cx.sync()
     got = xr * scale.cpu()[:, :, None, None] + shift.cpu()[:, :, None, None]
     e = nrmse(got, ref)
@@ -201,8 +204,9 @@ def case_groupnorm(cx: Ctx, n=3, H=6, W=10, C1=320, C2=0, groups=32, seed=5):
 
 
 # ----------------------------------------------------------------------------------------- attention
-def case_attention(cx: Ctx, D=40, n_img=4, Lq=72, Lb=40, seed=6):
-    """images [0, n/2) are CFG-unconditional (own keys only); the rest append bank batch 1."""
+def case_attention(cx: Ctx, D=40, n_img=4, Lq=72, Lb=40, seed=6, check=None, q_stride=1):
+    """images [0, n/2) are CFG-unconditional (own keys only); the rest append bank batch 1.
+    check / q_stride: images and query rows the CPU reference is evaluated on (the kernel runs everything)."""
     g = torch.Generator().manual_seed(seed)
     H = 8
     Cc = H * D
@@ -213,15 +217,16 @@ def case_attention(cx: Ctx, D=40, n_img=4, Lq=72, Lb=40, seed=6):
     def heads(t):
         return r(t).view(t.shape[0], t.shape[1], H, D).transpose(1, 2)
 
-    ref = torch.zeros(n_img, Lq, Cc)
-    for i in range(n_img):
+    idx = list(range(n_img)) if check is None else list(check)
+    ref = torch.zeros(len(idx), len(range(0, Lq, q_stride)), Cc)
+    for j, i in enumerate(idx):
         kk, vv = heads(k[i : i + 1]), heads(v[i : i + 1])
         if sel[i] >= 0:
             s = int(sel[i])
             kk = torch.cat([kk, heads(kb[s : s + 1])], dim=2)
             vv = torch.cat([vv, heads(vb[s : s + 1])], dim=2)
-        o = F.scaled_dot_product_attention(heads(q[i : i + 1]), kk, vv)
-        ref[i] = o.transpose(1, 2).reshape(Lq, Cc)
+        o = F.scaled_dot_product_attention(heads(q[i : i + 1, ::q_stride]), kk, vv)
+        ref[j] = o.transpose(1, 2).reshape(-1, Cc)
     qkv = cx.bf(torch.cat([q, k], dim=-1).view(n_img * Lq, 2 * Cc))  # q | k interleaved rows, ld = 2C
     vt = cx.bf(v.reshape(n_img * Lq, Cc).t())  # [C][n*Lq]
     k2 = cx.bf(kb.reshape(2 * Lb, Cc))
@@ -231,7 +236,8 @@ def case_attention(cx: Ctx, D=40, n_img=4, Lq=72, Lb=40, seed=6):
                   ldq=2 * Cc, ldk=2 * Cc, ldvt=n_img * Lq, ldo=Cc, k2=k2, vt2=vt2, ldk2=Cc, ldvt2=2 * Lb, L2=Lb,
                   bank_sel=cx.dev(sel))
     cx.sync()
-    e = nrmse(o.view(n_img, Lq, Cc), ref)
+    assert torch.isfinite(o.float()).all()
+    e = nrmse(o.view(n_img, Lq, Cc)[idx][:, ::q_stride], ref)
     assert e < 6e-3, f"attention D={D} nrmse {e}"  # P is rounded to bf16 before P.V (as SDPA kernels do)
     return e
 

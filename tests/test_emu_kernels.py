@@ -142,6 +142,8 @@ def test_groupnorm(cx):
     kc.case_groupnorm(cx)
     kc.case_groupnorm(cx, n=2, H=4, W=4, C1=1280, C2=640, seed=9)  # groups straddle the concat seam
     kc.case_groupnorm(cx, n=1, H=3, W=3, C1=2560, seed=10)
+    kc.case_groupnorm(cx, n=2, H=8, W=8, C1=320, seed=11, offset=40.0, spread=0.05, splits=5)  # |mean| >> std
+    kc.case_groupnorm(cx, n=2, H=5, W=3, C1=64, seed=12, offset=-25.0, spread=0.2, splits=4)   # ragged pixel ranges
 
 
 @pytest.mark.parametrize("D", [40, 80, 160])

@@ -40,14 +40,17 @@ def build_native(cfg, sd):
     return net.to("cuda")
 
 
-def run_native(net, sample, t, ehs, pose, banks, do_cfg=True):
+def run_native(net, sample, t, ehs, pose, banks, do_cfg=True, taps=None):
     eng = net.engine()
+    if taps is not None:
+        eng.tap = lambda name, x: taps.__setitem__(name, x.float().permute(0, 3, 1, 2).cpu())
     eng.set_reference_banks({k: v.cuda() for k, v in banks.items()} if banks else None, do_cfg=do_cfg)
     eng.bank_version = "pinned"  # banks were set explicitly
     net._reference_mode = None
     eng._banks_from_modules = lambda: None
     out = net(sample.cuda(), t, ehs.cuda(), pose_cond_fea=None if pose is None else pose.cuda(), return_dict=False)[0]
     torch.cuda.synchronize()
+    eng.tap = None
     assert torch.isfinite(out).all()
     return out
 
@@ -61,10 +64,19 @@ def test_unet_matches_reference_golden():
     ehs = torch.cat([torch.zeros(1, 1, 768), torch.from_numpy(z["ehs"])])
     pose = torch.from_numpy(z["pose"]).repeat(2, 1, 1, 1, 1)
     banks = {k[5:]: torch.from_numpy(z[k].astype(np.float32)) for k in z.files if k.startswith("bank:")}
-    out = run_native(net, sample, int(z["t"]), ehs, pose, banks)
+    taps = {}
+    out = run_native(net, sample, int(z["t"]), ehs, pose, banks, taps=taps)
     e = nrmse(out, torch.from_numpy(z["out"]))
     print("unet3d tiny vs reference golden: nrmse", e)
     assert e < TOL, e
+    # the intermediate activations the fixture holds (oracle taps, pinned to the reference at 5e-6): a wrong low-gain
+    # branch cannot hide under the output norm
+    names = [k[4:] for k in z.files if k.startswith("tap:")]
+    assert len(names) >= 4
+    for name in names:
+        et = nrmse(taps[name], torch.from_numpy(z["tap:" + name].astype(np.float32)))
+        print(f"  tap {name}: nrmse {et:.3e}")
+        assert et < TOL, (name, et)
 
 
 @pytest.mark.parametrize("geom", ["three_level_d160", "tiny_no_bank", "tiny_f8"])

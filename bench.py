@@ -4,13 +4,16 @@ CFG 3.5, SD-1.5 geometry + AnimateDiff motion modules + CameraCtrl Pluecker enco
 fp32 accumulation, random-init weights and synthetic latents/pose/camera/CLIP/bank tensors of the
 named shapes (no checkpoints or datasets are reachable).
 
-    python bench.py --gpus N --steps K --warmup W
-    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+    python bench.py --gpus N --steps K --warmup W [--config 2|3|5]
+    (N > 1: launched by `python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...`,
+     or directly -- bench.py then re-executes itself under torch.distributed.run with one rank per GPU)
 
 A "step" = one pass of the hot path: pack latents -> UNet3D forward on both CFG halves (ReferenceNet
 banks injected, pose+camera conditioning added) -> window accumulation -> CFG + DDIM update.  With
-N > 1 the 24 frames are sharded over the ranks (RCCL all-gather of temporal K/V in every motion
-module): the total work is fixed, so scaling is "strong".  Rank 0 prints ONE JSON line.
+N > 1 the frames of each window are sharded over the ranks (frames<->pixels all-to-all around every
+temporal attention over RCCL/xGMI; HUMANVID_TEMPORAL_EXCHANGE=allgather replicates K/V instead): the
+total work is fixed, so scaling is "strong".  Rank 0 prints ONE JSON line; its `roofline` block is
+built from the real launches of one profiled step (hv_profile_begin/end).
 """
 import argparse
 import json
@@ -46,84 +49,105 @@ def build_models(dev):
     return unet, pg, cam
 
 
-def _hip_time(fn, iters):
-    """average milliseconds of `fn` measured with HIP events recorded on the launch stream"""
+# ---------------------------------------------------------------------------------------------------------------------
+# roofline from the step's REAL launches: one extra denoising step is launched eagerly inside an hv_profile_begin/end
+# bracket (HIP events around every kernel on the launch stream); the library files each launch under
+# "kernel variant | shape" and this module prices the shapes (algorithmic FLOPs and bytes per DESIGN.md section 3).
+def _kv(shape: str):
+    out = {}
+    for tok in shape.split():
+        k, _, v = tok.partition("=")
+        out[k] = int(v)
+    return out
+
+
+def price_launch(key: str):
+    """-> (flops, algorithmic bytes) of ONE launch described by a profile key"""
+    kern, _, shape = key.partition(" | ")
+    a = _kv(shape) if shape else {}
+    if kern.startswith("hv_gemm"):
+        n_out = a["N"] // 2 if a["geglu"] else a["N"]
+        fl = 2.0 * a["M"] * a["N"] * a["K"]
+        by = 2.0 * (a["M"] * a["K"] + a["N"] * a["K"]) + a["M"] * n_out * (4.0 if a["f32"] else 2.0) \
+            + (2.0 * a["M"] * n_out if a["res"] else 0.0)
+        return fl, by
+    if kern.startswith("hv_conv3x3"):
+        px_o, px_i = a["n"] * a["Ho"] * a["Wo"], a["n"] * a["Hs"] * a["Ws"]
+        fl = 2.0 * 9 * a["Cin"] * a["Cout"] * px_o
+        by = 2.0 * (px_i * a["Cin"] + 9 * a["Cin"] * a["Cout"] + px_o * a["Cout"] * (2 if a["res"] else 1))
+        return fl, by
+    if kern.startswith("hv_attention"):
+        C = a["heads"] * a["D"]
+        banked = a["n"] / 2 if a["bank"] else 0  # CFG layout: the unconditional half attends its own keys only
+        fl = 4.0 * C * a["Lq"] * (a["L1"] * a["n"] + a["L2"] * banked)
+        by = 2.0 * C * (2 * a["n"] * a["Lq"] + 2 * a["n"] * a["L1"] + (4 * a["L2"] if a["bank"] else 0))
+        return fl, by
+    if kern.startswith("hv_temporal"):
+        D = int(kern.split("<")[1].split(">")[0])
+        C = 8 * D
+        fl = 4.0 * a["Fq"] * a["Fkv"] * C * a["B"] * a["P"]
+        by = 2.0 * C * a["B"] * a["P"] * (2 * a["Fq"] + 2 * a["Fkv"])
+        return fl, by
+    if kern.startswith("hv_gn_partial"):
+        return 0.0, 2.0 * a["n"] * a["pixels"] * a["C"]
+    if kern.startswith("hv_ln_stats"):
+        return 0.0, 2.0 * a["M"] * a["C"]
+    return 0.0, 0.0
+
+
+def profile_step(run_step):
+    """run_step() launches one denoising step eagerly on the current stream -> per-kernel-variant totals"""
     import ctypes
 
     from humanvid_amd import lib as hvlib
 
-    L, st = hvlib.load(), hvlib.current_stream()
-    fn()
+    L = hvlib.load()
     torch.cuda.synchronize()
-    e0, e1 = ctypes.c_void_p(), ctypes.c_void_p()
-    L.call("hv_event_create", ctypes.byref(e0))
-    L.call("hv_event_create", ctypes.byref(e1))
-    L.call("hv_event_record", e0, st)
-    for _ in range(iters):
-        fn()
-    L.call("hv_event_record", e1, st)
-    ms = ctypes.c_float()
-    L.call("hv_event_elapsed_ms", e0, e1, ctypes.byref(ms))
-    L.call("hv_event_destroy", e0)
-    L.call("hv_event_destroy", e1)
-    return ms.value / iters
+    L.call("hv_profile_begin")
+    try:
+        run_step()
+    finally:
+        buf = ctypes.create_string_buffer(1 << 20)
+        need = L.cdll.hv_profile_end(buf, len(buf))
+    if need < 0:
+        raise RuntimeError("hv_profile_end failed")
+    kernels = {}
+    for line in buf.value.decode().splitlines():
+        cnt, ms, key = line.split("\t", 2)
+        fl, by = price_launch(key)
+        k = kernels.setdefault(key.partition(" | ")[0], dict(launches=0, ms=0.0, flops=0.0, bytes=0.0))
+        k["launches"] += int(cnt)
+        k["ms"] += float(ms)
+        k["flops"] += fl * int(cnt)
+        k["bytes"] += by * int(cnt)
+    return kernels
 
 
-def roofline_probe(n_img, F, h, w, iters=3):
-    """Dominant kernel = the LDS-DMA GEMM (hv_gemm_glds_kernel, ~40 % of the step over ~200 launches of
-    16 shapes).  Replays those launches with their per-step multiplicities and reports the aggregate
-    algorithmic TFLOP/s (= sum flops / sum launch time) and the mean launch duration."""
-    from humanvid_amd import lib as hvlib
-    from humanvid_amd import ops
-
-    L, st = hvlib.load(), hvlib.current_stream()
-    dev = torch.device("cuda")
-    levels = [(h * w, 320, 5, 5), ((h // 2) * (w // 2), 640, 5, 5), ((h // 4) * (w // 4), 1280, 5, 5),
-              ((h // 8) * (w // 8), 1280, 1, 6)]  # tokens, C, #spatial transformers, #motion modules
-    tot_ms = tot_fl = tot_bytes = 0.0
-    launches = 0
-    for N_tok, C, T, Mm in levels:
-        M = n_img * N_tok
-        x = torch.randn(M, C, device=dev).to(torch.bfloat16)
-        x4 = torch.randn(M, 4 * C, device=dev).to(torch.bfloat16)
-        for Nn, K, geglu, count in [(3 * C, C, False, T + 2 * Mm), (C, C, False, 2 * T + 3 * Mm),
-                                    (8 * C, C, True, T + Mm), (C, 4 * C, False, T + Mm)]:
-            wgt = (torch.randn(Nn, K, device=dev) * K**-0.5).to(torch.bfloat16)
-            y = torch.empty(M, Nn // 2 if geglu else Nn, dtype=torch.bfloat16, device=dev)
-            bias = torch.zeros(Nn, device=dev)
-            xx = x if K == C else x4
-            ms = _hip_time(lambda: ops.gemm(L, st, xx, wgt, y, bias=bias, geglu=geglu), iters)
-            tot_ms += ms * count
-            tot_fl += 2.0 * M * Nn * K * count
-            tot_bytes += 2.0 * (M * K + Nn * K + y.numel()) * count  # operands read once, output written once (bf16)
-            launches += count
-            del wgt, y
-    return dict(kernel="hv_gemm_glds_kernel<32,3,128,4> (all Linear / 1x1-conv GEMMs of one step)", ms=tot_ms / launches,
-                flops=tot_fl / launches, tflops=tot_fl / tot_ms / 1e9, launches_per_step=launches,
-                ms_per_step=tot_ms, bytes=tot_bytes / launches)
-
-
-def attention_probe(n_img, F, h, w, iters=3):
-    """Second-largest kernel: level-0 spatial self-attention with bank keys (5 launches per step)."""
-    from humanvid_amd import lib as hvlib
-    from humanvid_amd import ops
-
-    L, st = hvlib.load(), hvlib.current_stream()
-    C, N = 320, h * w
-    M = n_img * N
-    dev = torch.device("cuda")
-    qk = torch.randn(M, 2 * C, device=dev).to(torch.bfloat16)
-    vt = torch.randn(C, M, device=dev).to(torch.bfloat16)
-    k2 = torch.randn(2 * N, C, device=dev).to(torch.bfloat16)
-    vt2 = torch.randn(C, 2 * N, device=dev).to(torch.bfloat16)
-    o = torch.empty(M, C, dtype=torch.bfloat16, device=dev)
-    sel = torch.tensor([-1] * F + [1] * (n_img - F), dtype=torch.int32, device=dev)
-    ms = _hip_time(lambda: ops.attention(L, st, qk, qk[:, C:], vt, o, n_images=n_img, heads=8, D=40, Lq=N, L1=N,
-                                         ldq=2 * C, ldk=2 * C, ldvt=M, ldo=C, k2=k2, vt2=vt2, ldk2=C, ldvt2=2 * N,
-                                         L2=N, bank_sel=sel), iters)
-    flops = 4.0 * N * N * C * F + 4.0 * N * 2 * N * C * (n_img - F)
-    return dict(kernel="hv_attention_kernel<40,2>", avg_launch_ms=ms, flops_per_launch=flops,
-                achieved_tflops=flops / ms / 1e9, frac_of_mfma_peak=flops / ms / 1e9 / PEAK_BF16_TFLOPS)
+def roofline_from_profile(kernels, traffic_file):
+    total_ms = sum(k["ms"] for k in kernels.values())
+    name, dom = max(kernels.items(), key=lambda kv: kv[1]["ms"])
+    tf = dom["flops"] / dom["ms"] / 1e9
+    roof = {"bound": "mfma", "achieved": tf, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": tf / PEAK_BF16_TFLOPS,
+            "traffic": None, "kernel": name, "launches_per_step": dom["launches"], "kernel_ms_per_step": dom["ms"],
+            "avg_launch_ms": dom["ms"] / dom["launches"], "flops_per_launch": dom["flops"] / dom["launches"],
+            "algorithmic_bytes_per_launch": dom["bytes"] / dom["launches"],
+            "source": "hv_profile_begin/end: HIP events around every launch of one eagerly launched step after the timed "
+                      "region (real epilogues, variants and multiplicities); shapes priced by bench.price_launch",
+            "sum_of_kernel_ms_per_step": total_ms}
+    if os.path.exists(traffic_file):
+        t = json.load(open(traffic_file))
+        if t.get("kernel", "").replace(" ", "") .startswith(name.replace(" ", "")):
+            roof["traffic"] = t["bytes_per_launch"]
+            roof["traffic_detail"] = dict(t, note="PMC counters cannot be read inside the timed run: this is the committed "
+                                          "summary of the separate rocprofv3 --pmc passes named in `source`; STALE unless "
+                                          "re-collected at this commit (see `commit`)")
+    table = []
+    for n, k in sorted(kernels.items(), key=lambda kv: -kv[1]["ms"])[:10]:
+        table.append({"kernel": n, "launches": k["launches"], "ms": round(k["ms"], 3),
+                      "tflops": round(k["flops"] / k["ms"] / 1e9, 1) if k["ms"] > 0 else 0.0,
+                      "algorithmic_GBps": round(k["bytes"] / k["ms"] / 1e6, 1) if k["ms"] > 0 else 0.0,
+                      "frac_of_mfma_peak": round(k["flops"] / k["ms"] / 1e9 / PEAK_BF16_TFLOPS, 4) if k["ms"] > 0 else 0.0})
+    return roof, table
 
 
 def cpu_baseline(budget_hw=(24, 16), frames=24):
@@ -162,24 +186,53 @@ def cpu_baseline(budget_hw=(24, 16), frames=24):
                        f"widths: {dt:.1f} s; scaled by as-written FLOP ratio {ratio:.1f} to 24f x 768x512")
 
 
+CONFIGS = {
+    # BASELINE.json configs[] index -> frames, height, width, description
+    2: dict(F=16, H=512, W=512, what="Pose2Video 16f x 512x512, static camera (BASELINE.json configs[1])"),
+    3: dict(F=24, H=768, W=512, what="Pose2Video 24f x 768x512, CameraCtrl Pluecker embedding (BASELINE.json configs[2])"),
+    5: dict(F=48, H=1024, W=576, what="Pose2Video 48f x 1024x576, 3 context windows of 24 per step (BASELINE.json configs[4])"),
+}
+
+
+def _self_launch(args):
+    """`python bench.py --gpus N` without a launcher: re-exec under torch.distributed.run, one rank per GPU."""
+    import socket
+    import subprocess
+
+    if torch.cuda.device_count() < args.gpus:
+        raise SystemExit(f"--gpus {args.gpus}: only {torch.cuda.device_count()} GPU(s) visible")
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL / tensor sharing across processes needs it here
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--frames", type=int, default=24)
-    ap.add_argument("--height", type=int, default=768)
-    ap.add_argument("--width", type=int, default=512)
+    ap.add_argument("--config", type=int, default=3, choices=sorted(CONFIGS), help="BASELINE.json configs[] number (1-based)")
+    ap.add_argument("--frames", type=int, default=None)
+    ap.add_argument("--height", type=int, default=None)
+    ap.add_argument("--width", type=int, default=None)
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-profile", action="store_true", help="skip the profiled extra step (roofline block)")
     args = ap.parse_args()
 
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        _self_launch(args)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
-        if args.gpus > 1:
-            raise SystemExit(f"--gpus {args.gpus} must be launched with torch.distributed.run --nproc-per-node {args.gpus}")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     import torch.distributed as dist
@@ -190,10 +243,11 @@ def main():
 
     from humanvid_amd.arch import DEFAULT_UNET3D_CONFIG, SD15_INFERENCE_V2
     from humanvid_amd.pipeline import Pose2VideoPipeline
-    from humanvid_amd.scheduler import DDIMScheduler
+    from humanvid_amd.scheduler import DDIMScheduler, get_context_scheduler
     from humanvid_amd.workload import unet3d_flops
 
-    F, H, W = args.frames, args.height, args.width
+    cfgsel = CONFIGS[args.config]
+    F, H, W = args.frames or cfgsel["F"], args.height or cfgsel["H"], args.width or cfgsel["W"]
     h, w = H // 8, W // 8
     unet, pg, cam = build_models(dev)
     sched = DDIMScheduler(beta_start=0.00085, beta_end=0.012, beta_schedule="linear", clip_sample=False, steps_offset=1,
@@ -226,6 +280,7 @@ def main():
     K, Wm = args.steps, args.warmup
     n_inf = max(30, K + Wm)
     times = {}
+    prof = {}
 
     def sync_barrier():
         torch.cuda.synchronize()
@@ -241,10 +296,15 @@ def main():
             sync_barrier()
             times["t1"] = time.perf_counter()
 
+    def after_loop(one_step):
+        if world == 1 and not args.no_profile:
+            prof["kernels"] = profile_step(one_step)
+
     if Wm == 0:
         sync_barrier()
         times["t0"] = time.perf_counter()
-    pipe.denoise(latents, pose, plucker, clip, n_inf, 3.5, use_graph=not args.no_graph, max_steps=Wm + K, step_hook=hook)
+    pipe.denoise(latents, pose, plucker, clip, n_inf, 3.5, use_graph=not args.no_graph, max_steps=Wm + K, step_hook=hook,
+                 after_loop=after_loop)
     elapsed = times["t1"] - times["t0"]
     if world > 1:
         tmax = torch.tensor([elapsed], device=dev)
@@ -254,39 +314,37 @@ def main():
     if rank == 0:
         cfg = dict(DEFAULT_UNET3D_CONFIG)
         cfg.update(SD15_INFERENCE_V2)
-        fl = unet3d_flops(cfg, 2, F, h, w, False)
+        windows = list(get_context_scheduler("uniform")(0, n_inf, F, 24, 1, 4))
+        fl_total = sum(unet3d_flops(cfg, 2, len(c), h, w, False)["total"] for c in windows)
         ms_step = elapsed / K * 1e3
-        probe = roofline_probe(2 * F, F, h, w) if world == 1 else None
+        exch = pipe.shard.exchange if world > 1 else None
+        par = "single GPU" if world == 1 else (
+            f"frame-sharded x{world}: frames<->pixels all-to-all around every temporal attention (RCCL over xGMI)"
+            if exch == "alltoall" else f"frame-sharded x{world}: RCCL all-gather of temporal K/V")
         out = {
-            "metric": "denoising steps/sec, 24f x 768x512 Pose2Video", "value": K / elapsed, "unit": "steps/s",
+            "metric": f"denoising steps/sec, {F}f x {H}x{W} Pose2Video", "value": K / elapsed, "unit": "steps/s",
             "n_gpus": world, "steps": K, "warmup": Wm, "ms_per_step": ms_step, "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": f"Pose2Video {F}f x {H}x{W}, CFG 3.5, CameraCtrl Pluecker embedding, SD-1.5 UNet3D + "
-                                   "motion modules, 1 window, DDIM v-pred (BASELINE.json configs[2])",
-                       "parallelism": "single GPU" if world == 1 else f"frame-sharded x{world} (RCCL all-gather of temporal K/V)",
-                       "hip_graph": not args.no_graph and world == 1},
-            "step_algorithmic_tflop": fl["total"] / 1e12,
-            "step_tflops_per_gpu": fl["total"] / 1e12 / (ms_step / 1e3) / world,
-            "step_frac_of_mfma_peak": fl["total"] / 1e12 / (ms_step / 1e3) / world / PEAK_BF16_TFLOPS,
+            "config": {"workload": cfgsel["what"] + f"; CFG 3.5, SD-1.5 UNet3D + motion modules, {len(windows)} window(s) "
+                                   "per step, DDIM v-pred",
+                       "parallelism": par, "hip_graph": not args.no_graph and world == 1},
+            "step_algorithmic_tflop": fl_total / 1e12,
+            "step_tflops_per_gpu": fl_total / 1e12 / (ms_step / 1e3) / world,
+            "step_frac_of_mfma_peak": fl_total / 1e12 / (ms_step / 1e3) / world / PEAK_BF16_TFLOPS,
         }
-        if probe is not None:
-            out["roofline"] = {"bound": "mfma", "achieved": probe["tflops"], "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                               "frac": probe["tflops"] / PEAK_BF16_TFLOPS, "traffic": None,
-                               "algorithmic_bytes_per_launch": probe["bytes"],
-                               "kernel": probe["kernel"], "avg_launch_ms": probe["ms"],
-                               "flops_per_launch": probe["flops"], "launches_per_step": probe["launches_per_step"],
-                               "kernel_ms_per_step": probe["ms_per_step"]}
-            # HBM-side bytes per launch of that kernel from the PMC passes (tools/pmc_passes.sh: FETCH_SIZE and WRITE_SIZE
-            # in separate rocprofv3 runs over this same command, FETCH_SIZE doubled as calibrated on gfx950); counters
-            # cannot be read from inside the timed run, so the committed summary of the last pass is reported here
-            pmc = os.path.join(REPO, "profiles", "r01_pmc_traffic.json")
-            if os.path.exists(pmc):
-                t = json.load(open(pmc))
-                out["roofline"]["traffic"] = t["bytes_per_launch"]
-                out["roofline"]["traffic_detail"] = t
-            out["roofline_attention"] = attention_probe(2 * F, F, h, w)
+        if "kernels" in prof:
+            roof, table = roofline_from_profile(prof["kernels"], os.path.join(REPO, "profiles", "r02_pmc_traffic.json"))
+            out["roofline"] = roof
+            out["kernels"] = table
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
+            ref = os.path.join(REPO, "tests", "golden", f"cpu_reference_config{args.config}.json")
+            if os.path.exists(ref):  # the reference SOURCE timed in the build container (oracle/gen_fullsize_golden.py)
+                r = json.load(open(ref))
+                out["cpu_reference"] = {"value": r["steps_per_s"], "unit": "steps/s", "cores": r["cores"], "kind": "reference",
+                                        "sample": "one steady-state denoising step of /root/reference's own code (fp32, "
+                                                  f"{r['cores']} vCPU build container), committed measurement: "
+                                                  f"tests/golden/cpu_reference_config{args.config}.json"}
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

@@ -112,6 +112,8 @@ PROTOTYPES = {
     "hv_cmdlist_size": (I, [P]),
     "hv_cmdlist_run": (I, [P, P]),
     "hv_cmdlist_destroy": (I, [P]),
+    "hv_profile_begin": (I, []),
+    "hv_profile_end": (I, [C.c_char_p, I]),
     "hv_event_create": (I, [C.POINTER(P)]),
     "hv_event_record": (I, [P, P]),
     "hv_event_elapsed_ms": (I, [P, P, C.POINTER(F)]),

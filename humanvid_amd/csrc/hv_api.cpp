@@ -5,11 +5,15 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <string>
+
 #include "hv_common.h"
 #include "hv_kernels.h"
 
 static thread_local char g_err[512] = "";
 thread_local HvCmdList* g_hv_recording = nullptr;
+thread_local HvProfile* g_hv_prof = nullptr;
+thread_local char g_hv_note[192] = "";
 
 static int hv_fail(int code, const char* what) {
     snprintf(g_err, sizeof(g_err), "%s", what);
@@ -173,6 +177,46 @@ int hv_cmdlist_destroy(void* list) {
 }
 
 #ifndef HV_EMU
+int hv_profile_begin(void) {
+    if (g_hv_prof) return hv_fail(HV_EINVAL, "hv_profile_begin: a profile is already open");
+    g_hv_prof = new HvProfile();
+    return HV_OK;
+}
+int hv_profile_end(char* out, int capacity) {
+    // -> lines "launches\ttotal_ms\tkey\n", one per distinct key, in first-seen order; returns the byte count needed
+    if (!g_hv_prof) return hv_fail(HV_EINVAL, "hv_profile_end: no open profile");
+    HvProfile* pr = g_hv_prof;
+    g_hv_prof = nullptr;
+    std::vector<std::string> keys;
+    std::vector<double> ms;
+    std::vector<int> cnt;
+    for (auto& en : pr->entries) {
+        float t = 0.f;
+        (void)hipEventSynchronize(en.e1);
+        (void)hipEventElapsedTime(&t, en.e0, en.e1);
+        (void)hipEventDestroy(en.e0);
+        (void)hipEventDestroy(en.e1);
+        size_t i = 0;
+        for (; i < keys.size(); ++i)
+            if (keys[i] == en.key) break;
+        if (i == keys.size()) {
+            keys.push_back(en.key);
+            ms.push_back(0.0);
+            cnt.push_back(0);
+        }
+        ms[i] += t;
+        cnt[i] += 1;
+    }
+    delete pr;
+    std::string txt;
+    char line[320];
+    for (size_t i = 0; i < keys.size(); ++i) {
+        snprintf(line, sizeof(line), "%d\t%.6f\t%s\n", cnt[i], ms[i], keys[i].c_str());
+        txt += line;
+    }
+    if (out && capacity > 0) snprintf(out, (size_t)capacity, "%s", txt.c_str());
+    return (int)txt.size() + 1;
+}
 int hv_graph_begin(void* stream) {
     hipError_t e = hipStreamBeginCapture((hipStream_t)stream, hipStreamCaptureModeRelaxed);
     if (e != hipSuccess) return hv_fail(HV_EHIP, hipGetErrorString(e));
@@ -219,6 +263,8 @@ int hv_event_destroy(void* ev) {
     return HV_OK;
 }
 #else
+int hv_profile_begin(void) { return hv_fail(HV_ENOTSUP, "emulator build"); }
+int hv_profile_end(char*, int) { return hv_fail(HV_ENOTSUP, "emulator build"); }
 int hv_graph_begin(void*) { return hv_fail(HV_ENOTSUP, "emulator build"); }
 int hv_graph_end(void*, void**) { return hv_fail(HV_ENOTSUP, "emulator build"); }
 int hv_graph_launch(void*, void*) { return hv_fail(HV_ENOTSUP, "emulator build"); }

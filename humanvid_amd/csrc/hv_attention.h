@@ -46,10 +46,23 @@
 #define HV_ATTN_LAZY 1
 #endif
 
+// Head-dim remainder of the QK^T reduction (d = 40: 8 channels, d = 80: 16).  Round 1 fed it through a 16-deep
+// mfma_f32_16x16x16_bf16 appended to the chain of 32-deep MFMAs on the same accumulator.  That mix is unsafe on gfx950
+// with hipcc (ROCm 7.2): a v_mfma_f32_16x16x16_bf16 that takes the result of a v_mfma_f32_16x16x32_bf16 as SrcC (or the
+// reverse) is issued back to back, without the wait states / independent instructions the different pass counts need,
+// and reads a partially written accumulator -- wrong rows that change run to run, depending on what else shares the
+// SIMD (root-caused on the temporal kernel: tools/diag_fence.py, profiles/r02_mfma_chain_hazard.md).  This kernel never
+// showed it (its two query fragments interleave independent MFMAs between the dependent pair), but nothing guaranteed
+// that.  HV_ATTN_PAD32 = 1 (default) keeps every MFMA of a chain the same shape: the remainder becomes a zero-padded
+// 32-deep step (K rows in LDS are zero beyond D, the query fragment is masked).  0 = the round-1 form, for A/Bs only.
+#ifndef HV_ATTN_PAD32
+#define HV_ATTN_PAD32 1
+#endif
+
 template <int D, int QT>
 struct HvAttnGeom {
-    static constexpr int NFULL = D / 32;              // 32-deep QK^T steps
-    static constexpr bool TAIL = (D % 32) != 0;       // + one 16-deep step
+    static constexpr int NFULL = HV_ATTN_PAD32 ? (D + 31) / 32 : D / 32;   // 32-deep QK^T steps
+    static constexpr bool TAIL = !HV_ATTN_PAD32 && (D % 32) != 0;          // + one 16-deep step (round-1 form)
     static constexpr int DT = (D + 15) / 16;          // 16-row fragments of V^T / O^T
     static constexpr int DK = 32 * NFULL + (TAIL ? 16 : 0);
     static constexpr int DV = 16 * DT;
@@ -122,7 +135,7 @@ __global__ __launch_bounds__(256, (HvAttnOcc<D, QT>::value)) void hv_attention_k
 #pragma unroll
         for (int s = 0; s < NFULL; ++s) {
             u32x4 v = {0u, 0u, 0u, 0u};
-            if (q < p.Lq) v = hv_ld16(qrow + 32 * s + 8 * quad);
+            if (q < p.Lq && 32 * s + 8 * quad + 8 <= D) v = hv_ld16(qrow + 32 * s + 8 * quad);
             qf[qt][s] = hv_as_bf16x8(v);
         }
         if (G::TAIL) {
@@ -345,6 +358,8 @@ static inline void hv_attention_launch_t(const hv_attention_params& p, hipStream
     const int total = ((p.Lq + G::BQ - 1) / G::BQ) * p.heads * p.n_images;
     const int grid = ((total + 7) / 8) * 8;
     const bool ragged = (p.L1 % 64) != 0 || (p.L2 % 64) != 0;
+    hv_note("hv_attention_kernel<%d,%d> | n=%d heads=%d D=%d Lq=%d L1=%d L2=%d bank=%d", D, QT, p.n_images, p.heads, D, p.Lq,
+            p.L1, p.L2, p.bank_sel != nullptr && p.L2 > 0);
     if (ragged)
         hv_launch(hv_attention_kernel<D, QT, true>, dim3(grid), dim3(256), stream, p);
     else

@@ -9,6 +9,7 @@
 #include <hip/hip_runtime.h>
 #endif
 #include <stdint.h>
+#include <stdio.h>
 
 #include <functional>
 #include <vector>
@@ -152,6 +153,26 @@ struct HvCmdList {
 };
 extern thread_local HvCmdList* g_hv_recording;  // defined in hv_api.cpp
 
+// Launch profile (hv_profile_begin / hv_profile_end): while a profile is open every launch is bracketed by two HIP
+// events on its own stream and filed under the note its launcher left with hv_note() -- "kernel variant | shape".
+// bench.py prices the notes (flops / algorithmic bytes from the shape) to build the roofline from the step's REAL
+// launches (real epilogues, multiplicities and variants) instead of a synthetic replay.
+struct HvProfEntry {
+    char key[192];
+#ifndef HV_EMU
+    hipEvent_t e0, e1;
+#endif
+};
+struct HvProfile {
+    std::vector<HvProfEntry> entries;
+};
+extern thread_local HvProfile* g_hv_prof;  // defined in hv_api.cpp
+extern thread_local char g_hv_note[192];
+#define hv_note(...)                                                        \
+    do {                                                                    \
+        if (g_hv_prof) snprintf(g_hv_note, sizeof(g_hv_note), __VA_ARGS__); \
+    } while (0)
+
 template <class... KArgs, class... Args>
 static inline void hv_launch(void (*kernel)(KArgs...), dim3 grid, dim3 block, hipStream_t stream, Args... args) {
 #ifdef HV_EMU
@@ -162,6 +183,18 @@ static inline void hv_launch(void (*kernel)(KArgs...), dim3 grid, dim3 block, hi
 #else
     if (g_hv_recording)
         g_hv_recording->cmds.push_back([=](hipStream_t s) { kernel<<<grid, block, 0, s>>>(args...); });
+    if (g_hv_prof) {
+        HvProfEntry en;
+        snprintf(en.key, sizeof(en.key), "%s", g_hv_note[0] ? g_hv_note : "other");
+        g_hv_note[0] = 0;
+        (void)hipEventCreate(&en.e0);
+        (void)hipEventCreate(&en.e1);
+        (void)hipEventRecord(en.e0, stream);
+        kernel<<<grid, block, 0, stream>>>(args...);
+        (void)hipEventRecord(en.e1, stream);
+        g_hv_prof->entries.push_back(en);
+        return;
+    }
     kernel<<<grid, block, 0, stream>>>(args...);
 #endif
 }

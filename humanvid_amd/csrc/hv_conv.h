@@ -292,6 +292,9 @@ static inline void hv_conv3x3_launch_t(const hv_conv3x3_params& p, hipStream_t s
     constexpr int TH = NPIX / TW;
     const int tiles = p.n_images * ((p.Ho + TH - 1) / TH) * ((p.Wo + TW - 1) / TW) * ((p.Cout + 127) / 128);
     const int grid = ((tiles + 7) / 8) * 8;
+    hv_note("hv_conv3x3_kernel<%d,%d,%d,%d> | n=%d Hs=%d Ws=%d Ho=%d Wo=%d Cin=%d Cout=%d gn=%d res=%d", TW, MODE,
+            g_hv_conv_glds, NPIX, p.n_images, p.Hs, p.Ws, p.Ho, p.Wo, p.C1 + p.C2, p.Cout, p.pro_scale != nullptr,
+            p.residual != nullptr);
     if (g_hv_conv_glds)
         hv_launch(hv_conv3x3_kernel<TW, MODE, true, NPIX>, dim3(grid), dim3(2 * NPIX), stream, p);
     else

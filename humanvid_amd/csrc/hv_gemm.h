@@ -542,6 +542,10 @@ static inline int hv_gemm_launch(const HvGemmParams& p, hipStream_t stream) {
     if (p.geglu && (p.N % 32 != 0 || p.Yt != nullptr || p.out_f32)) return -1;
     if (p.Yt != nullptr && (p.n_split % 16 != 0)) return -1;
     const bool prologue = p.pro_scale != nullptr || p.pro_act != HV_ACT_NONE;
+    char shape[128] = "";
+    if (g_hv_prof)
+        snprintf(shape, sizeof(shape), "M=%d N=%d K=%d geglu=%d res=%d yt=%d f32=%d x2=%d", p.M, p.N, p.K, p.geglu,
+                 p.residual != nullptr, p.Yt != nullptr ? p.N - p.n_split : 0, p.out_f32, p.X2 != nullptr);
     if (g_hv_gemm_glds && !prologue && p.M >= 256) {
         const int tm = (p.M + 255) / 256;
         // 256x256 tiles (one 128 KiB workgroup per CU, a third fewer bytes per FLOP through the
@@ -553,6 +557,7 @@ static inline int hv_gemm_launch(const HvGemmParams& p, hipStream_t stream) {
             int grid = ((tiles + 7) / 8) * 8;
             if (grid > 256) grid = 256;
             if (grid > g_hv_gemm_max_grid) grid = g_hv_gemm_max_grid;
+            hv_note("hv_gemm_glds_kernel<32,4,256,8> | %s", shape);
             hv_launch(hv_gemm_glds_kernel<32, 4, 256, 8>, dim3(grid), dim3(512), stream, p, gm);
             return 0;
         }
@@ -564,6 +569,7 @@ static inline int hv_gemm_launch(const HvGemmParams& p, hipStream_t stream) {
             int grid6 = ((tiles6 + 7) / 8) * 8;
             if (grid6 > 512) grid6 = 512;
             if (grid6 > g_hv_gemm_max_grid) grid6 = g_hv_gemm_max_grid;
+            hv_note("hv_gemm_glds_kernel<64,2,128,4,128> | %s", shape);
             hv_launch(hv_gemm_glds_kernel<64, 2, 128, 4, 128>, dim3(grid6), dim3(256), stream, p, gm);
             return 0;
         }
@@ -572,14 +578,18 @@ static inline int hv_gemm_launch(const HvGemmParams& p, hipStream_t stream) {
         if (g_hv_gemm_glds == 1) {  // BK = 64, 144 KiB ring: one workgroup per CU
             if (grid > 256) grid = 256;
             if (grid > g_hv_gemm_max_grid) grid = g_hv_gemm_max_grid;
+            hv_note("hv_gemm_glds_kernel<64,3,128,8> | %s", shape);
             hv_launch(hv_gemm_glds_kernel<64, 3, 128, 8>, dim3(grid), dim3(512), stream, p, gm);
         } else {  // BK = 32, 72 KiB ring: two workgroups per CU whose epilogues interleave
             if (grid > 512) grid = 512;
             if (grid > g_hv_gemm_max_grid) grid = g_hv_gemm_max_grid;
-            if (g_hv_gemm_glds == 4)
+            if (g_hv_gemm_glds == 4) {
+                hv_note("hv_gemm_glds_kernel<32,3,128,8> | %s", shape);
                 hv_launch(hv_gemm_glds_kernel<32, 3, 128, 8>, dim3(grid), dim3(512), stream, p, gm);
-            else
+            } else {
+                hv_note("hv_gemm_glds_kernel<32,3,128,4> | %s", shape);
                 hv_launch(hv_gemm_glds_kernel<32, 3, 128, 4>, dim3(grid), dim3(256), stream, p, gm);
+            }
         }
         return 0;
     }
@@ -587,6 +597,7 @@ static inline int hv_gemm_launch(const HvGemmParams& p, hipStream_t stream) {
     // persistent grid: 2 workgroups per CU (64 KiB LDS each), 256 CUs, fewer when the problem is small
     int grid = ((tiles + 7) / 8) * 8;
     if (grid > g_hv_gemm_max_grid) grid = g_hv_gemm_max_grid;
+    hv_note("hv_gemm_kernel<64>%s | %s", prologue ? "+gn_prologue" : "", shape);
     hv_launch(hv_gemm_kernel<64>, dim3(grid), dim3(256), stream, p);
     return 0;
 }

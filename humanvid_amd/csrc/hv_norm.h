@@ -145,7 +145,9 @@ static inline int hv_groupnorm_launch(const hv_groupnorm_params& p, hipStream_t 
     const int C = p.C1 + p.C2;
     if (p.C1 % 8 != 0 || p.C2 % 8 != 0 || C % p.groups != 0 || C > 4096 || p.splits < 1) return -1;
     if (p.C2 > 0 && p.X2 == nullptr) return -1;
+    hv_note("hv_gn_partial_kernel | n=%d pixels=%d C=%d", p.n_images, p.pixels, C);
     hv_launch(hv_gn_partial_kernel, dim3(p.splits, p.n_images), dim3(256), stream, p);
+    hv_note("hv_gn_finalize_kernel | n=%d C=%d", p.n_images, C);
     hv_launch(hv_gn_finalize_kernel, dim3((C + 255) / 256, p.n_images), dim3(256), stream, p);
     return 0;
 }
@@ -197,5 +199,6 @@ __global__ __launch_bounds__(256) void hv_ln_stats_kernel(const bf16_t* X, long 
 
 static inline void hv_layernorm_launch(const bf16_t* X, long ldx, int M, int C, float eps, float* mean, float* rstd,
                                        hipStream_t stream) {
+    hv_note("hv_ln_stats_kernel | M=%d C=%d", M, C);
     hv_launch(hv_ln_stats_kernel, dim3((M + 3) / 4), dim3(256), stream, X, ldx, M, C, eps, mean, rstd);
 }

@@ -113,25 +113,36 @@ struct HvTemporalGeom {
     static constexpr int LDS_BYTES = 96 * RS;          // 32 rows each of Q, K, V
 };
 
-// MFMA fence.  On MI355X (ROCm 7.2 hipcc) the d = 80 instantiation of this kernel was wrong and irreproducible run to
-// run once two workgroups shared a CU (F = 24, P = 1536), while correct on the host emulator and at small grids.  Fencing
-// every MFMA (scheduling barrier + 16 wait states) makes all three head dims bit-reproducible and equal to the VALU kernel
-// to 1 bf16 ulp (tools/diag_determinism.py).  The unfenced code has e.g.
-//     v_mfma_f32_16x16x32_bf16 a[12:15], v[0:3], v[16:19], 0
-//     v_add_u32_e32 v0, v24, v14            ; overwrites a source register of the MFMA just issued
-// but the same shape also occurs in the GEMM / conv / spatial-attention kernels, which pass the full-size determinism
-// test, so the exact hazard is not pinned down yet (round-2 item).  The kernel is HBM-bound: the wait states are free.
+// Mixed-shape MFMA chains.  Round 1 shipped this kernel with every MFMA fenced (scheduling barrier + 16 wait states): the
+// unfenced d = 80 instantiation was wrong and irreproducible run to run once two workgroups shared a CU (F = 24, P = 1536)
+// while correct on the host emulator and at small grids.  Round 2 root-caused it on the hardware with ten diagnosis builds
+// (tools/diag_fence.py; table in profiles/r02_mfma_chain_hazard.md):
+//   * the fault needs the 16-deep v_mfma_f32_16x16x16_bf16 (head-dim remainder: d = 40, 80) in the SAME accumulation
+//     chain as the 32-deep v_mfma_f32_16x16x32_bf16 steps: hipcc (ROCm 7.2) issues the two back to back
+//         v_mfma_f32_16x16x32_bf16 a[12:15], v[4:7], v[20:23], a[12:15]
+//         s_waitcnt lgkmcnt(0)
+//         v_mfma_f32_16x16x16_bf16 a[12:15], v[10:11], v[0:1], a[12:15]
+//     as if they were a same-shape accumulate pair (SrcC forwarded), but their pass counts differ and the second reads
+//     an accumulator the first has not finished writing.  How much is wrong depends on what shares the SIMD's matrix
+//     pipe at that moment, hence the run-to-run differences and the dependence on occupancy;
+//   * with NO 16-deep MFMA (remainder as a zero-padded 32-deep step) the unfenced kernel is bit-reproducible and equal
+//     to the VALU kernel at every shape; with the 16-deep MFMA FIRST in the chain d = 40 fails as well (116 k wrong
+//     rows); wait states around the 16-deep MFMA alone, or scheduling barriers alone, also cure it; fencing only the
+//     O^T MFMAs does not (the O^T products are single MFMAs with C = 0: no chain).
+// Rule adopted for every kernel of the library: all MFMAs of one accumulation chain have the same shape (HV_TEMPORAL_TAIL
+// = 1 here, HV_ATTN_PAD32 in hv_attention.h).  The fence is gone (HV_TEMPORAL_FENCE = 0); the macros below remain for
+// the diagnosis builds only.
 // HV_TEMPORAL_FENCE selects the guard for the diagnosis builds of tools/diag_fence.py:
 //   0 none | 1 scheduling barrier + 16 wait states after every MFMA (default) | 2 scheduling barriers only
 //   3 wait states only | 4 guard the S^T MFMAs only | 5 guard the O^T MFMAs only | 6 scheduling barrier + 2 wait states
 #ifndef HV_TEMPORAL_FENCE
-#define HV_TEMPORAL_FENCE 1
+#define HV_TEMPORAL_FENCE 0
 #endif
 // HV_TEMPORAL_TAIL: how the head-dim remainder (d = 40: 8, d = 80: 16 channels) enters the S^T accumulation chain:
 //   0 a 16-deep mfma_16x16x16 after the 32-deep steps (round 1) | 1 a zero-padded 32-deep step (same shape as the rest)
 //   2 the 16-deep MFMA first | 3 as 0, with wait states around the 16-deep MFMA only
 #ifndef HV_TEMPORAL_TAIL
-#define HV_TEMPORAL_TAIL 0
+#define HV_TEMPORAL_TAIL 1
 #endif
 #if defined(HV_EMU) || HV_TEMPORAL_FENCE == 0
 #define HV_MFMA_GUARD_QK()
@@ -353,6 +364,8 @@ static inline int hv_temporal_launch(const hv_temporal_attention_params& p, hipS
     if (p.heads != 8 || p.B <= 0 || p.Fkv <= 0 || p.Fq <= 0 || p.Fq > p.Fkv || p.P <= 0 || p.kv_chunk <= 0)
         return p.heads != 8 ? -2 : -1;
     if (p.ldq % 8 || p.ldkv % 8 || p.ldo % 8) return -1;
+    hv_note("hv_temporal_%s_kernel<%d> | B=%d Fq=%d Fkv=%d P=%d", g_hv_temporal_mfma && p.Fkv <= 32 ? "mfma" : "valu", p.D,
+            p.B, p.Fq, p.Fkv, p.P);
     if (g_hv_temporal_mfma && p.Fkv <= 32) {
         switch (p.D) {
             case 40: hv_launch(hv_temporal_mfma_kernel<40>, dim3(p.B * p.P), dim3(512), stream, p); return 0;

@@ -60,7 +60,7 @@ class UNet3DEngine:
         self.do_cfg = True
         self._sel_cache: Dict[tuple, torch.Tensor] = {}
         # optional observer `tap(name, activation [(b f),h,w,c])` called after every resnet / spatial transformer / motion
-        # module (names as in oracle_torch.unet3d_forward's taps).  Buffers are reused and updated in place: the observer
+        # module, named by the reference's module path (e.g. 'down_blocks.0.attentions.1').  Buffers are reused and updated in place: the observer
         # must copy what it wants to keep.  Used by the parity tests; None in production (and under graph capture).
         self.tap = None
         self._pack()
@@ -371,7 +371,8 @@ class UNet3DEngine:
             if bank is not None:
                 k2, vt2, bb, Nb = bank
                 if self.do_cfg:
-                    sel = [-1] * F + [1] * (n - F) if B == 2 else [-1] * n
+                    cond = 1 if bb > 1 else 0  # a one-entry bank (ReferenceNet run on the conditional embedding only)
+                    sel = [-1] * F + [cond] * (n - F) if B == 2 else [-1] * n
                 else:
                     sel = [i // F if bb > 1 else 0 for i in range(n)]
                 skey = (n, F, int(self.do_cfg), bb)

@@ -201,7 +201,9 @@ class Pose2VideoPipeline:
         for c in windows:
             pose_w = pose_cond_tensor[:, :, c]
             pose_fea = self.pose_guider.forward_nhwc(pose_w)  # [(1 f), h, w, 320]
-            if isinstance(camera_embedding, (tuple, list)):
+            if camera_embedding is None or self.camera_pose_encoder is None:
+                feat = pose_fea  # pipeline_pose2vid.py (Animate-Anyone mode): pose feature only
+            elif isinstance(camera_embedding, (tuple, list)):
                 K, c2w = camera_embedding
                 idx = torch.as_tensor(c, dtype=torch.long)
                 feat = self.camera_pose_encoder.forward_nhwc_from_cameras(K[idx], c2w[idx], pose_w.shape[-2], pose_w.shape[-1],
@@ -216,12 +218,14 @@ class Pose2VideoPipeline:
                 clip_image_embeds: torch.Tensor, num_inference_steps: int, guidance_scale: float,
                 context_schedule="uniform", context_frames=24, context_stride=1, context_overlap=4,
                 use_graph: bool = True, callback: Optional[Callable] = None, callback_steps: int = 1,
-                max_steps: Optional[int] = None, step_hook: Optional[Callable] = None) -> torch.Tensor:
+                max_steps: Optional[int] = None, step_hook: Optional[Callable] = None,
+                after_loop: Optional[Callable] = None) -> torch.Tensor:
         """Denoising loop body of the reference (pipeline_pose2vid_long.py:454-571).
 
         latents [1,4,F,h,w] fp32 (cuda); pose_cond_tensor [1,3,F,H,W] in [0,1]; camera_embedding
         [1,6,F,H,W]; clip_image_embeds [1,768] or [1,1,768].  The reference banks must already be on
-        the denoising UNet (ReferenceAttentionControl.update, or engine.set_reference_banks)."""
+        the denoising UNet (ReferenceAttentionControl.update, or engine.set_reference_banks).
+        step_hook(i) runs after step i; after_loop(one_step) receives the step closure once the loop is done."""
         dev = hvlib.require_gpu()
         L = hvlib.load()
         unet = self.denoising_unet
@@ -262,7 +266,8 @@ class Pose2VideoPipeline:
             plans.append((torch.tensor(mine, dtype=torch.int32, device=dev), fl, rank * fl))
         conds = []
         for c, (_, fl, f0) in zip(windows, plans):
-            cam = camera_embedding if isinstance(camera_embedding, (tuple, list)) else camera_embedding.to(dev)
+            cam = camera_embedding if camera_embedding is None or isinstance(camera_embedding, (tuple, list)) \
+                else camera_embedding.to(dev)
             conds.extend(self.build_conditioning(pose_cond_tensor.to(dev), cam, [c], f0, fl))
 
         acc = torch.zeros(rep, C, F_, h, w, dtype=F32, device=dev)
@@ -317,6 +322,8 @@ class Pose2VideoPipeline:
                 step_hook(i)
             if callback is not None and i % callback_steps == 0:
                 callback(i, timesteps[i], latents)
+        if after_loop is not None:
+            after_loop(one_step)  # e.g. bench.py: one more, eagerly launched step inside a launch profile
         if graph is not None:
             torch.cuda.current_stream().synchronize()
             L.call("hv_graph_destroy", graph)
@@ -341,6 +348,38 @@ class Pose2VideoPipeline:
         L.call("hv_graph_launch", gx, hvlib.current_stream())
         return gx
 
+    # ---- shared front-end of the three __call__ variants -----------------------------------------------
+    def _clip_and_reference_pass(self, ref_image, width, height, do_cfg, device):
+        """CLIP image embedding, VAE-encoded reference latent, ReferenceNet write pass at t = 0 and bank hand-over
+        (pipeline_pose2vid_long.py:380-407, 438-446, 470-480).  Returns (clip_embeds [1,768], reader, writer)."""
+        clip_image = _clip_preprocess(ref_image)
+        clip_embeds = self.image_encoder(clip_image.to(device, dtype=self.image_encoder.dtype)).image_embeds
+        ehs = clip_embeds.unsqueeze(1)
+        if do_cfg:
+            ehs = torch.cat([torch.zeros_like(ehs), ehs], dim=0)
+        writer = ReferenceAttentionControl(self.reference_unet, do_classifier_free_guidance=do_cfg, mode="write",
+                                           batch_size=1, fusion_blocks="full")
+        reader = ReferenceAttentionControl(self.denoising_unet, do_classifier_free_guidance=do_cfg, mode="read",
+                                           batch_size=1, fusion_blocks="full")
+        ref_tensor = _pil_to_tensor(ref_image, height, width, normalize=True).to(device=device, dtype=self.vae.dtype)
+        ref_latents = self.vae.encode(ref_tensor).latent_dist.mean * 0.18215
+        # The reference runs the ReferenceNet on [zero-CLIP, CLIP] (ref_image_latents.repeat(2, ...), :472-474), but in read
+        # mode bank entry 0 only ever feeds the attention result that mutual_self_attention.py:178-186 overwrites with plain
+        # self-attention: the write pass needs the conditional entry only (SURVEY.md 8f-1) -> batch 1, one-entry banks.
+        self.reference_unet(ref_latents, torch.zeros((), device=device), encoder_hidden_states=ehs[-1:], return_dict=False)
+        reader.update(writer)
+        return clip_embeds, reader, writer
+
+    @staticmethod
+    def _require_gpu_and_plain_sampling(eta, num_images_per_prompt):
+        if eta != 0.0:
+            raise NotImplementedError("eta > 0 is not supported (the reference always samples with eta = 0)")
+        if num_images_per_prompt != 1:
+            raise NotImplementedError("num_images_per_prompt > 1 is not supported (the reference scripts always pass 1)")
+        if not torch.cuda.is_available():
+            raise RuntimeError("the pipeline needs a ROCm GPU: the denoising path has no CPU fallback")
+        return torch.device("cuda")
+
     # ---- reference-compatible entry point ----------------------------------------------------------
     @torch.no_grad()
     def __call__(self, ref_image, pose_images, camera_embedding, width, height, video_length, num_inference_steps,
@@ -350,43 +389,101 @@ class Pose2VideoPipeline:
                  callback: Optional[Callable[[int, int, torch.FloatTensor], None]] = None,
                  callback_steps: Optional[int] = 1, context_schedule="uniform", context_frames=24, context_stride=1,
                  context_overlap=4, context_batch_size=1, interpolation_factor=1, **kwargs):
-        if eta != 0.0:
-            raise NotImplementedError("eta > 0 is not supported (the reference always samples with eta = 0)")
         if interpolation_factor >= 2:
             raise NotImplementedError("latent interpolation (interpolation_factor >= 2) is outside the denoising path")
-        if num_images_per_prompt != 1:
-            raise NotImplementedError("num_images_per_prompt > 1 is not supported (the reference scripts always pass 1)")
-        device = torch.device("cuda") if torch.cuda.is_available() else torch.device("cpu")
-        if device.type != "cuda":
-            raise RuntimeError("Pose2VideoPipeline needs a ROCm GPU: the denoising path has no CPU fallback")
+        device = self._require_gpu_and_plain_sampling(eta, num_images_per_prompt)
         do_cfg = guidance_scale > 1.0
-        batch_size = 1
-        # CLIP image embedding (pipeline :380-392)
-        clip_image = _clip_preprocess(ref_image)
-        clip_embeds = self.image_encoder(clip_image.to(device, dtype=self.image_encoder.dtype)).image_embeds
-        ehs = clip_embeds.unsqueeze(1)
-        if do_cfg:
-            ehs = torch.cat([torch.zeros_like(ehs), ehs], dim=0)
-        writer = ReferenceAttentionControl(self.reference_unet, do_classifier_free_guidance=do_cfg, mode="write",
-                                           batch_size=batch_size, fusion_blocks="full")
-        reader = ReferenceAttentionControl(self.denoising_unet, do_classifier_free_guidance=do_cfg, mode="read",
-                                           batch_size=batch_size, fusion_blocks="full")
-        latents = self.prepare_latents(batch_size * num_images_per_prompt, self.denoising_unet.in_channels, width,
-                                       height, video_length, clip_embeds.dtype, device, generator)
-        ref_tensor = _pil_to_tensor(ref_image, height, width, normalize=True).to(device=device, dtype=self.vae.dtype)
-        ref_latents = self.vae.encode(ref_tensor).latent_dist.mean * 0.18215
+        clip_embeds, reader, writer = self._clip_and_reference_pass(ref_image, width, height, do_cfg, device)
+        latents = self.prepare_latents(1, self.denoising_unet.in_channels, width, height, video_length, clip_embeds.dtype,
+                                       device, generator)
         pose_cond = _pil_to_tensor(list(pose_images), height, width, normalize=False)  # [F,3,H,W]
         pose_cond = pose_cond.permute(1, 0, 2, 3)[None]  # [1,3,F,H,W]
         if not isinstance(camera_embedding, (tuple, list)):  # (K, c2w) camera parameters: on-device Pluecker front-end
             camera_embedding = camera_embedding.to(device=device, dtype=F32)
             assert camera_embedding.ndim == 5
-        # ReferenceNet write pass at t = 0, then banks -> reader (pipeline :470-480)
-        self.reference_unet(ref_latents.repeat(2 if do_cfg else 1, 1, 1, 1), torch.zeros((), device=device),
-                            encoder_hidden_states=ehs, return_dict=False)
-        reader.update(writer)
         latents = self.denoise(latents, pose_cond, camera_embedding, clip_embeds, num_inference_steps, guidance_scale,
                                context_schedule=context_schedule, context_frames=context_frames,
                                context_stride=context_stride, context_overlap=context_overlap, callback=callback,
+                               callback_steps=callback_steps or 1)
+        reader.clear()
+        writer.clear()
+        images = self.decode_latents(latents)
+        if output_type == "tensor":
+            images = torch.from_numpy(images)
+        if not return_dict:
+            return images
+        return Pose2VideoPipelineOutput(videos=images)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+@dataclass
+class Pose2ImagePipelineOutput:
+    images: Union[torch.Tensor, np.ndarray]
+
+
+class Pose2ImagePipeline(Pose2VideoPipeline):
+    """Drop-in for /root/reference/src/pipelines/pipeline_pose2img.py:31-376 (BASELINE.json configs[0]: one frame, no
+    motion module, e.g. 256x256 with 4 DDIM steps): the same native denoising loop with a single-frame window."""
+
+    def prepare_latents(self, batch_size, num_channels_latents, width, height, dtype, device, generator, latents=None):
+        lat = super().prepare_latents(batch_size, num_channels_latents, width, height, 1, dtype, device, generator,
+                                      None if latents is None else latents.unsqueeze(2))
+        return lat[:, :, 0]
+
+    @torch.no_grad()
+    def __call__(self, ref_image, pose_image, camera_embedding, width, height, num_inference_steps, guidance_scale,
+                 num_images_per_prompt=1, eta: float = 0.0,
+                 generator: Optional[Union[torch.Generator, List[torch.Generator]]] = None,
+                 output_type: Optional[str] = "tensor", return_dict: bool = True,
+                 callback: Optional[Callable[[int, int, torch.FloatTensor], None]] = None,
+                 callback_steps: Optional[int] = 1, **kwargs):
+        device = self._require_gpu_and_plain_sampling(eta, num_images_per_prompt)
+        do_cfg = guidance_scale > 1.0
+        clip_embeds, reader, writer = self._clip_and_reference_pass(ref_image, width, height, do_cfg, device)
+        latents = self.prepare_latents(1, self.denoising_unet.in_channels, width, height, clip_embeds.dtype, device,
+                                       generator).unsqueeze(2)  # (bs, c, 1, h', w')  pipeline_pose2img.py:267
+        pose_cond = _pil_to_tensor(pose_image, height, width, normalize=False).unsqueeze(2)  # [1,3,1,H,W]
+        cam = None
+        if camera_embedding is not None:
+            cam = camera_embedding.to(device=device, dtype=F32).unsqueeze(2)  # [1,6,1,H,W]  (:298)
+            assert cam.ndim == 5
+        latents = self.denoise(latents, pose_cond, cam, clip_embeds, num_inference_steps, guidance_scale,
+                               context_frames=1, context_overlap=0, callback=callback, callback_steps=callback_steps or 1)
+        reader.clear()
+        writer.clear()
+        image = self.decode_latents(latents)  # (b, c, 1, h, w)
+        if output_type == "tensor":
+            image = torch.from_numpy(image)
+        if not return_dict:
+            return image
+        return Pose2ImagePipelineOutput(images=image)
+
+
+class Pose2VideoShortPipeline(Pose2VideoPipeline):
+    """Drop-in for /root/reference/src/pipelines/pipeline_pose2vid.py:33-458 (class name there: Pose2VideoPipeline): all
+    `video_length` frames in ONE UNet forward per step (no context windows), no camera encoder.  The temporal positional
+    encoding caps video_length at temporal_position_encoding_max_len, as in the reference."""
+
+    def __init__(self, vae, image_encoder, reference_unet, denoising_unet, pose_guider, scheduler, image_proj_model=None,
+                 tokenizer=None, text_encoder=None):
+        super().__init__(vae, image_encoder, reference_unet, denoising_unet, pose_guider, None, scheduler,
+                         image_proj_model, tokenizer, text_encoder)
+
+    @torch.no_grad()
+    def __call__(self, ref_image, pose_images, width, height, video_length, num_inference_steps, guidance_scale,
+                 num_images_per_prompt=1, eta: float = 0.0,
+                 generator: Optional[Union[torch.Generator, List[torch.Generator]]] = None,
+                 output_type: Optional[str] = "tensor", return_dict: bool = True,
+                 callback: Optional[Callable[[int, int, torch.FloatTensor], None]] = None,
+                 callback_steps: Optional[int] = 1, **kwargs):
+        device = self._require_gpu_and_plain_sampling(eta, num_images_per_prompt)
+        do_cfg = guidance_scale > 1.0
+        clip_embeds, reader, writer = self._clip_and_reference_pass(ref_image, width, height, do_cfg, device)
+        latents = self.prepare_latents(1, self.denoising_unet.in_channels, width, height, video_length, clip_embeds.dtype,
+                                       device, generator)
+        pose_cond = _pil_to_tensor(list(pose_images), height, width, normalize=False).permute(1, 0, 2, 3)[None]
+        latents = self.denoise(latents, pose_cond, None, clip_embeds, num_inference_steps, guidance_scale,
+                               context_frames=video_length, context_overlap=0, callback=callback,
                                callback_steps=callback_steps or 1)
         reader.clear()
         writer.clear()

@@ -233,6 +233,15 @@ int hv_cmdlist_size(void* list);
 int hv_cmdlist_run(void* list, void* stream);
 int hv_cmdlist_destroy(void* list);
 
+/* ---- launch profile -----------------------------------------------------------------------------
+ * Between hv_profile_begin() and hv_profile_end() every kernel launch of this thread is bracketed by two HIP events
+ * on its own stream.  hv_profile_end() waits for them and writes one text line per distinct "kernel variant | shape"
+ * key: "<launches>\t<total milliseconds>\t<key>\n".  Returns the buffer size needed (call again with a larger
+ * buffer if it exceeds `capacity`), negative on error.  bench.py builds its roofline block from one profiled,
+ * eagerly launched denoising step (the real epilogues / multiplicities / variants of the step). */
+int hv_profile_begin(void);
+int hv_profile_end(char* out, int capacity);
+
 /* timing helper used by bench.py: elapsed milliseconds between two events it records on `stream` */
 int hv_event_create(void** ev);
 int hv_event_record(void* ev, void* stream);

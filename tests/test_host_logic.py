@@ -28,6 +28,29 @@ def test_oracle_matches_reference_source():
     assert "all checks passed" in r.stdout
 
 
+@pytest.mark.skipif(not os.path.isdir("/root/reference"), reason="reference tree not mounted")
+def test_oracle_reference_net_matches_reference_source():
+    """The reference's own UNet2DConditionModel (write mode) against oracle_torch.reference_net_banks."""
+    r = subprocess.run([sys.executable, os.path.join(REPO, "oracle", "gen_refnet_golden.py"), "--check"],
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "ok oracle reference_net_banks == reference write pass" in r.stdout
+
+
+def test_oracle_reproduces_golden_reference_net_banks():
+    """tests/golden/refnet_sd15.npz holds the banks the REFERENCE's ReferenceNet wrote (oracle/gen_refnet_golden.py)."""
+    z = np.load(os.path.join(GOLD, "refnet_sd15.npz"))
+    cfg = dict(O.SD15_UNET3D_CFG)
+    sd = O.make_reference_net_weights(cfg, seed=5)
+    lat, clip = torch.from_numpy(z["lat"]), torch.from_numpy(z["clip"])
+    banks = O.reference_net_banks(sd, cfg, lat, clip)  # the conditional entry alone (SURVEY.md 8f-1)
+    names = [k[5:] for k in z.files if k.startswith("bank:")]
+    assert len(names) == 16 and set(names) == set(banks)
+    for n in names:
+        want = torch.from_numpy(z["bank:" + n].astype(np.float32))[1:]
+        assert float((banks[n] - want).abs().max()) <= 2e-3 * max(1.0, float(want.abs().max())), n  # fp16 fixture
+
+
 def test_oracle_reproduces_golden_unet():
     z = np.load(os.path.join(GOLD, "unet3d_tiny.npz"))
     cfg = O.tiny_unet3d_cfg()

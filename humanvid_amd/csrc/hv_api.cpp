@@ -76,7 +76,9 @@ int hv_attention(const hv_attention_params* p, void* stream) {
     if (!p || !p->Q || !p->K || !p->Vt || !p->O) return hv_fail(HV_EINVAL, "hv_attention: null operand");
     int rc = hvk_attention(*p, (hipStream_t)stream);
     if (rc == -2) return hv_fail(HV_ENOTSUP, "hv_attention: head dim must be 40, 80 or 160");
-    if (rc != 0) return hv_fail(HV_EINVAL, "hv_attention: need L1 % 8 == 0, L2 % 8 == 0, 16-byte aligned strides");
+    if (rc != 0)
+        return hv_fail(HV_EINVAL, "hv_attention: need 16-byte aligned strides (transposed-V form: L1 % 8 == 0, L2 % 8 == 0; "
+                                  "row-major-V form: heads * D a multiple of 320)");
     return hv_check_launch("hv_attention");
 }
 

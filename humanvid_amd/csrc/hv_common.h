@@ -141,6 +141,35 @@ HV_DEV void hv_vm_wait() {}
 HV_DEV void hv_barrier_raw() { __syncthreads(); }
 #endif
 
+// ---- gfx950 cross-lane / transposing LDS primitives -----------------------------------------------------
+// hv_lds_tr4: ds_read_b64_tr_b16.  Every lane supplies the 8-byte aligned LDS address of 4 consecutive bf16; within each
+// 16-lane group the 16 x 4 values are transposed: lane t of the group receives element (t & 3) of the lanes 4e + (t >> 2),
+// e = 0..3.  With lane t pointing at [row t >> 2][columns 4 (t & 3) ..] of a row-major block, lane t ends up with
+// column t of rows 0..3 -- a row-major V tile is read as V^T MFMA fragments.  (tools/tr_probe.hip prints the map.)
+// hv_swap32: the value of the same lane index in the other 32-lane half (v_permlane32_swap).
+// The builtin form makes hipcc (ROCm 7.2) drain vmcnt(0) in front of the read whenever an LDS-DMA is in flight, so the
+// kernels use the inline-asm form: issue a batch with hv_lds_tr4_issue(), then hv_lds_tr4_wait() once before the first
+// consumer (the compiler does not count these reads: cdna_hip_programming.md 5.7 form (iii)).
+#ifndef HV_EMU
+HV_DEV bf16x4 hv_lds_tr4(const void* lds_ptr) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bf16x4*)lds_ptr);
+}
+HV_DEV void hv_lds_tr4_issue(bf16x4& dst, const void* lds_ptr) {
+    const unsigned a = (unsigned)(unsigned long)(__attribute__((address_space(3))) const void*)lds_ptr;
+    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(dst) : "v"(a));
+}
+HV_DEV void hv_lds_tr4_wait() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+}
+HV_DEV float hv_swap32(float x) {
+    const unsigned u = __builtin_bit_cast(unsigned, x);
+    const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    // r[0]: lanes 32-63 now hold the lower half's values; r[1]: lanes 0-31 hold the upper half's
+    return __builtin_bit_cast(float, (threadIdx.x & 32) ? r[0] : r[1]);
+}
+#endif
+
 // ---- launch plumbing ----------------------------------------------------------------------
 // One launch helper for both builds: the real one uses the HIP triple-chevron launch on the
 // caller's stream, the emulator (tests only) runs the workgroups on host fibers.

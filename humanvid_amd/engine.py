@@ -24,6 +24,7 @@ module are all-gathered over RCCL (torch.distributed) before the temporal attent
 """
 from __future__ import annotations
 
+import os
 from typing import Dict, List, Optional
 
 import torch
@@ -58,6 +59,9 @@ class UNet3DEngine:
         self.bank_version = None
         self.cross_const: Dict[str, torch.Tensor] = {}
         self.do_cfg = True
+        # spatial-attention kernel: 2 = round-2 kernel (row-major V out of the plain [token][q|k|v] QKV GEMM, LDS-DMA tiles,
+        # 32x32x16 MFMA), 1 = round-1 kernel (V^T written by the GEMM epilogue); HUMANVID_ATTENTION=1 for same-box A/Bs
+        self.attn_kernel = int(os.environ.get("HUMANVID_ATTENTION", "2"))
         self._sel_cache: Dict[tuple, torch.Tensor] = {}
         # optional observer `tap(name, activation [(b f),h,w,c])` called after every resnet / spatial transformer / motion
         # module, named by the reference's module path (e.g. 'down_blocks.0.attentions.1').  Buffers are reused and updated in place: the observer
@@ -213,6 +217,11 @@ class UNet3DEngine:
                 continue
             b, Nb, C = bank.shape
             x = self._dev(bank.reshape(b * Nb, C), BF16)
+            if self.attn_kernel == 2:  # bank rows [k | v], row-major
+                kv2 = torch.empty(b * Nb, 2 * C, dtype=BF16, device=self.device)
+                ops.gemm(self.lib, st, x, self.w[loc + ".transformer_blocks.0.bank_kv.w"], kv2)
+                self.bank_kv[loc] = (kv2, kv2[:, C:], b, Nb)
+                continue
             k2 = torch.empty(b * Nb, C, dtype=BF16, device=self.device)
             vt2 = torch.empty(C, b * Nb, dtype=BF16, device=self.device)
             ops.gemm(self.lib, st, x, self.w[loc + ".transformer_blocks.0.bank_kv.w"], k2, yt=vt2, n_split=C, ldy=C)
@@ -361,10 +370,18 @@ class UNet3DEngine:
                 ops.gemm(L, st, hid, w[t + ".norm1_id.w"], bank, bias=w[t + ".norm1_id.bias"], row_mean=mean,
                          row_rstd=rstd, colsum=w[t + ".norm1_id.colsum"])
                 self.written_banks[prefix] = bank.view(n, N, C)
-            qk = ws.get(f"tr_qk_{M}x{C}", (M, 2 * C))
-            vt = ws.get(f"tr_vt_{M}x{C}", (C, M))
-            ops.gemm(L, st, hid, w[t + ".qkv.w"], qk, bias=w[t + ".qkv.bias"], row_mean=mean, row_rstd=rstd,
-                     colsum=w[t + ".qkv.colsum"], yt=vt, n_split=2 * C)
+            v2 = self.attn_kernel == 2
+            if v2:
+                qk = ws.get(f"tr_qkv_{M}x{C}", (M, 3 * C))
+                ops.gemm(L, st, hid, w[t + ".qkv.w"], qk, bias=w[t + ".qkv.bias"], row_mean=mean, row_rstd=rstd,
+                         colsum=w[t + ".qkv.colsum"])
+                vt, ldqk, ldvt = qk[:, 2 * C:], 3 * C, 3 * C
+            else:
+                qk = ws.get(f"tr_qk_{M}x{C}", (M, 2 * C))
+                vt = ws.get(f"tr_vt_{M}x{C}", (C, M))
+                ops.gemm(L, st, hid, w[t + ".qkv.w"], qk, bias=w[t + ".qkv.bias"], row_mean=mean, row_rstd=rstd,
+                         colsum=w[t + ".qkv.colsum"], yt=vt, n_split=2 * C)
+                ldqk, ldvt = 2 * C, M
             o = ws.get(f"tr_o_{M}x{C}", (M, C))
             kw = {}
             bank = self.bank_kv.get(prefix)
@@ -380,9 +397,9 @@ class UNet3DEngine:
                 if sel_t is None:  # uploaded once (keeps the step free of host copies / graph-capturable)
                     sel_t = torch.tensor(sel, dtype=torch.int32).to(self.device)
                     self._sel_cache[skey] = sel_t
-                kw = dict(k2=k2, vt2=vt2, ldk2=C, ldvt2=bb * Nb, L2=Nb, bank_sel=sel_t)
+                kw = dict(k2=k2, vt2=vt2, ldk2=2 * C if v2 else C, ldvt2=2 * C if v2 else bb * Nb, L2=Nb, bank_sel=sel_t)
             ops.attention(L, st, qk, qk[:, C:], vt, o, n_images=n, heads=self.heads, D=C // self.heads, Lq=N, L1=N,
-                          ldq=2 * C, ldk=2 * C, ldvt=M, ldo=C, **kw)
+                          ldq=ldqk, ldk=ldqk, ldvt=ldvt, ldo=C, v_row_major=v2, **kw)
             ops.gemm(L, st, o, w[t + ".attn1.to_out.0.w"], hid, bias=w[t + ".attn1.to_out.0.bias"],
                      rowvec=self.cross_const[prefix], rowvec_period=F * N, residual=hid)
             feed_forward(t + ".ff1", t + ".ff.net.2", hid)

@@ -154,6 +154,9 @@ typedef struct hv_attention_params {
     long ldo;
     int n_images, heads, D, Lq, L1, L2;
     float scale;
+    int v_row_major; /* 1: Vt / Vt2 hold row-major values V[(img*L1 + kv)*ldvt + h*D + d] (like K; typically the v third of
+                        the [token][q | k | v] tensor of the QKV GEMM) -> round-2 kernel (LDS-DMA tiles, 32x32x16 MFMA,
+                        transposing LDS reads); 0: transposed values as documented above (round-1 kernel) */
 } hv_attention_params;
 int hv_attention(const hv_attention_params* p, void* stream);
 

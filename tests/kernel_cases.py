@@ -204,7 +204,7 @@ def case_groupnorm(cx: Ctx, n=3, H=6, W=10, C1=320, C2=0, groups=32, seed=5, off
 
 
 # ----------------------------------------------------------------------------------------- attention
-def case_attention(cx: Ctx, D=40, n_img=4, Lq=72, Lb=40, seed=6, check=None, q_stride=1):
+def case_attention(cx: Ctx, D=40, n_img=4, Lq=72, Lb=40, seed=6, check=None, q_stride=1, row_major=False):
     """images [0, n/2) are CFG-unconditional (own keys only); the rest append bank batch 1.
     check / q_stride: images and query rows the CPU reference is evaluated on (the kernel runs everything)."""
     g = torch.Generator().manual_seed(seed)
@@ -227,14 +227,21 @@ def case_attention(cx: Ctx, D=40, n_img=4, Lq=72, Lb=40, seed=6, check=None, q_s
             vv = torch.cat([vv, heads(vb[s : s + 1])], dim=2)
         o = F.scaled_dot_product_attention(heads(q[i : i + 1, ::q_stride]), kk, vv)
         ref[j] = o.transpose(1, 2).reshape(-1, Cc)
-    qkv = cx.bf(torch.cat([q, k], dim=-1).view(n_img * Lq, 2 * Cc))  # q | k interleaved rows, ld = 2C
-    vt = cx.bf(v.reshape(n_img * Lq, Cc).t())  # [C][n*Lq]
-    k2 = cx.bf(kb.reshape(2 * Lb, Cc))
-    vt2 = cx.bf(vb.reshape(2 * Lb, Cc).t())
     o = torch.zeros(n_img * Lq, Cc, dtype=BF16, device=cx.device)
-    ops.attention(cx.lib, cx.stream, qkv, qkv[:, Cc:], vt, o, n_images=n_img, heads=H, D=D, Lq=Lq, L1=Lq,
-                  ldq=2 * Cc, ldk=2 * Cc, ldvt=n_img * Lq, ldo=Cc, k2=k2, vt2=vt2, ldk2=Cc, ldvt2=2 * Lb, L2=Lb,
-                  bank_sel=cx.dev(sel))
+    if row_major:  # round-2 kernel: [token][q | k | v] rows as the QKV GEMM writes them, bank rows [k | v]
+        qkv = cx.bf(torch.cat([q, k, v], dim=-1).view(n_img * Lq, 3 * Cc))
+        kv2 = cx.bf(torch.cat([kb, vb], dim=-1).view(2 * Lb, 2 * Cc))
+        ops.attention(cx.lib, cx.stream, qkv, qkv[:, Cc:], qkv[:, 2 * Cc:], o, n_images=n_img, heads=H, D=D, Lq=Lq, L1=Lq,
+                      ldq=3 * Cc, ldk=3 * Cc, ldvt=3 * Cc, ldo=Cc, k2=kv2, vt2=kv2[:, Cc:], ldk2=2 * Cc, ldvt2=2 * Cc,
+                      L2=Lb, bank_sel=cx.dev(sel), v_row_major=True)
+    else:
+        qkv = cx.bf(torch.cat([q, k], dim=-1).view(n_img * Lq, 2 * Cc))  # q | k interleaved rows, ld = 2C
+        vt = cx.bf(v.reshape(n_img * Lq, Cc).t())  # [C][n*Lq]
+        k2 = cx.bf(kb.reshape(2 * Lb, Cc))
+        vt2 = cx.bf(vb.reshape(2 * Lb, Cc).t())
+        ops.attention(cx.lib, cx.stream, qkv, qkv[:, Cc:], vt, o, n_images=n_img, heads=H, D=D, Lq=Lq, L1=Lq,
+                      ldq=2 * Cc, ldk=2 * Cc, ldvt=n_img * Lq, ldo=Cc, k2=k2, vt2=vt2, ldk2=Cc, ldvt2=2 * Lb, L2=Lb,
+                      bank_sel=cx.dev(sel))
     cx.sync()
     assert torch.isfinite(o.float()).all()
     e = nrmse(o.view(n_img, Lq, Cc)[idx][:, ::q_stride], ref)

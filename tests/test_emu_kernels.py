@@ -151,6 +151,16 @@ def test_attention(cx, D):
     kc.case_attention(cx, D=D, n_img=2, Lq=72 if D == 40 else 40, Lb=40 if D == 40 else 72)
 
 
+@pytest.mark.parametrize("D", [40, 80, 160])
+def test_attention_row_major_kernel(cx, D):
+    """round-2 kernel (row-major V, LDS-DMA tiles, 32x32x16 MFMA, transposing LDS reads): ragged and tile-aligned lengths,
+    more than one query block per workgroup row, bank shorter / longer than the sequence"""
+    kc.case_attention(cx, D=D, n_img=2, Lq=72 if D == 40 else 40, Lb=40 if D == 40 else 72, row_major=True)
+    kc.case_attention(cx, D=D, n_img=2, Lq=64, Lb=96, row_major=True, seed=16)
+    if D == 40:
+        kc.case_attention(cx, D=D, n_img=3, Lq=136, Lb=8, row_major=True, seed=62)
+
+
 def test_attention_unmasked_instances(cx):
     kc.case_attention(cx, D=40, n_img=2, Lq=64, Lb=64)   # tile-aligned lengths: the MASK=false kernels
     kc.case_attention(cx, D=80, n_img=2, Lq=64, Lb=64)

@@ -256,7 +256,7 @@ def test_pose2video_short_call_no_camera():
     pg.load_state_dict(pg_sd, strict=True)
     vae_cpu, clip_cpu = TinyVAE(), TinyCLIP()
     pipe = Pose2VideoShortPipeline(TinyVAE().to("cuda"), TinyCLIP().to("cuda"), ref, net, pg.to("cuda"), _scheduler())
-    W, H, F, steps = 64, 64, 5, 2
+    W, H, F, steps = 64, 64, 5, 4
     ref_image = _pil(8, W, H)
     poses = [_pil(200 + i, W, H) for i in range(F)]
     got = []

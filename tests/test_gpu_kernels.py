@@ -55,6 +55,13 @@ def test_attention(cx, D, Lq, Lb):
     kc.case_attention(cx, D=D, n_img=4, Lq=Lq, Lb=Lb)
 
 
+@pytest.mark.parametrize("D,Lq,Lb", [(40, 1536, 1536), (40, 200, 72), (80, 384, 384), (160, 96, 96), (160, 384, 96), (40, 144, 144),
+                                     (80, 72, 200)])
+def test_attention_row_major_kernel(cx, D, Lq, Lb):
+    """round-2 kernel: row-major V, LDS-DMA tiles, 32x32x16 MFMA, transposing LDS reads (ragged and aligned lengths)"""
+    kc.case_attention(cx, D=D, n_img=4, Lq=Lq, Lb=Lb, row_major=True)
+
+
 def test_attention_variants(cx):
     cx.lib.call("hv_set_tuning", 0, 2)
     kc.case_attention(cx, D=40, n_img=4, Lq=520, Lb=264)
@@ -101,9 +108,11 @@ def test_bench_shape_convs(cx):
     kc.case_conv(cx, n=48, H=12, W=8, C1=1280, Cout=1280, check=(0, 24, 47))
 
 
+@pytest.mark.parametrize("row_major", [True, False])
 @pytest.mark.parametrize("D,L", [(40, 6144), (80, 1536), (160, 384), (160, 96)])
-def test_bench_shape_attention(cx, D, L):
-    kc.case_attention(cx, D=D, n_img=48, Lq=L, Lb=L, check=(0, 23, 24, 47), q_stride=8 if L > 1000 else 1)
+def test_bench_shape_attention(cx, D, L, row_major):
+    kc.case_attention(cx, D=D, n_img=48, Lq=L, Lb=L, check=(0, 23, 24, 47), q_stride=8 if L > 1000 else 1,
+                      row_major=row_major)
 
 
 @pytest.mark.parametrize("D,P", [(40, 6144), (80, 1536), (160, 384), (160, 96)])

@@ -104,7 +104,11 @@ __global__ __launch_bounds__(256, (HvAttnOcc<D, QT>::value)) void hv_attention_k
     const int qb = t % nqb;
     t /= nqb;
     const int head = t % p.heads;
-    const int img = t / p.heads;
+    int img = t / p.heads;
+    // XCD x walks the contiguous range [x cpx, (x + 1) cpx) of t.  With the images in storage order the first four XCDs got the
+    // CFG-unconditional half (own keys only) and the last four the conditional half (own + bank keys = twice the work): the
+    // launch lasted as long as the heavy half.  Alternating between the halves gives every XCD the same mix.
+    if ((p.n_images & 1) == 0) img = (img & 1) * (p.n_images >> 1) + (img >> 1);
     const int sel = (p.bank_sel != nullptr && p.L2 > 0) ? p.bank_sel[img] : -1;
     const int T1 = (p.L1 + 63) / 64;
     const int T2 = sel >= 0 ? (p.L2 + 63) / 64 : 0;

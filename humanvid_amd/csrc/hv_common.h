@@ -12,6 +12,7 @@
 #include <stdio.h>
 
 #include <functional>
+#include <utility>
 #include <vector>
 #include "humanvid_hip.h"  // HV_ACT_* and the parameter structs
 
@@ -158,6 +159,13 @@ HV_DEV void hv_lds_tr4_issue(bf16x4& dst, const void* lds_ptr) {
     const unsigned a = (unsigned)(unsigned long)(__attribute__((address_space(3))) const void*)lds_ptr;
     asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(dst) : "v"(a));
 }
+template <int OFF>
+HV_DEV void hv_lds_tr4_issue_off(bf16x4& dst, unsigned lds_addr) {  // base VGPR + immediate offset (< 65536)
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(lds_addr), "i"(OFF));
+}
+HV_DEV unsigned hv_lds_addr(const void* lds_ptr) {
+    return (unsigned)(unsigned long)(__attribute__((address_space(3))) const void*)lds_ptr;
+}
 HV_DEV void hv_lds_tr4_wait() {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
@@ -169,6 +177,17 @@ HV_DEV float hv_swap32(float x) {
     return __builtin_bit_cast(float, (threadIdx.x & 32) ? r[0] : r[1]);
 }
 #endif
+
+// compile-time loop: f(std::integral_constant<int, 0>{}), ..., f(std::integral_constant<int, N - 1>{}) -- for loop bodies
+// that need their index as a constant expression (immediate operands of inline asm)
+template <int... I, class F>
+HV_DEV void hv_static_for_impl(std::integer_sequence<int, I...>, F&& f) {
+    (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, class F>
+HV_DEV void hv_static_for(F&& f) {
+    hv_static_for_impl(std::make_integer_sequence<int, N>{}, static_cast<F&&>(f));
+}
 
 // ---- launch plumbing ----------------------------------------------------------------------
 // One launch helper for both builds: the real one uses the HIP triple-chevron launch on the

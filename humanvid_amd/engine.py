@@ -59,9 +59,11 @@ class UNet3DEngine:
         self.bank_version = None
         self.cross_const: Dict[str, torch.Tensor] = {}
         self.do_cfg = True
-        # spatial-attention kernel: 2 = round-2 kernel (row-major V out of the plain [token][q|k|v] QKV GEMM, LDS-DMA tiles,
-        # 32x32x16 MFMA), 1 = round-1 kernel (V^T written by the GEMM epilogue); HUMANVID_ATTENTION=1 for same-box A/Bs
-        self.attn_kernel = int(os.environ.get("HUMANVID_ATTENTION", "2"))
+        # spatial-attention kernel: 1 = register-staged kernel (V^T written by the QKV GEMM epilogue; default: 541 / 530 / 332
+        # TF/s at the config-#3 shapes of d = 40 / 80 / 160 once the CFG halves are balanced over the XCDs), 2 = LDS-DMA kernel
+        # (row-major V out of a plain [token][q|k|v] QKV GEMM, 32x32x16 MFMA, transposing LDS reads: 411 / 402 / 364 TF/s --
+        # VALU- and DMA-issue-bound at d = 40, see profiles/README.md); HUMANVID_ATTENTION=2 selects it for same-box A/Bs
+        self.attn_kernel = int(os.environ.get("HUMANVID_ATTENTION", "1"))
         self._sel_cache: Dict[tuple, torch.Tensor] = {}
         # optional observer `tap(name, activation [(b f),h,w,c])` called after every resnet / spatial transformer / motion
         # module, named by the reference's module path (e.g. 'down_blocks.0.attentions.1').  Buffers are reused and updated in place: the observer

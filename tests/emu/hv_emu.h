@@ -271,6 +271,9 @@ inline hv_s4 hv_lds_tr4(const void* lds_ptr) {
     return out;
 }
 inline void hv_lds_tr4_issue(hv_s4& dst, const void* lds_ptr) { dst = hv_lds_tr4(lds_ptr); }
+template <int OFF>
+inline void hv_lds_tr4_issue_off(hv_s4& dst, const unsigned char* lds_addr) { dst = hv_lds_tr4(lds_addr + OFF); }
+inline const unsigned char* hv_lds_addr(const void* lds_ptr) { return (const unsigned char*)lds_ptr; }
 inline void hv_lds_tr4_wait() {}
 template <class T>
 inline T __shfl_xor(T v, int mask);

@@ -112,6 +112,9 @@ def profile_step(run_step):
     if need < 0:
         raise RuntimeError("hv_profile_end failed")
     kernels = {}
+    if os.environ.get("HV_PROFILE_DUMP"):  # raw per-(kernel, shape) lines for tools / profiles
+        with open(os.environ["HV_PROFILE_DUMP"], "w") as fh:
+            fh.write("launches\ttotal_ms\tkernel | shape\n" + buf.value.decode())
     for line in buf.value.decode().splitlines():
         cnt, ms, key = line.split("\t", 2)
         fl, by = price_launch(key)
@@ -136,7 +139,7 @@ def roofline_from_profile(kernels, traffic_file):
             "sum_of_kernel_ms_per_step": total_ms}
     if os.path.exists(traffic_file):
         t = json.load(open(traffic_file))
-        if t.get("kernel", "").replace(" ", "") .startswith(name.replace(" ", "")):
+        if t.get("kernel", "").replace(" ", "").startswith(name.replace(" ", "").rstrip(">")):
             roof["traffic"] = t["bytes_per_launch"]
             roof["traffic_detail"] = dict(t, note="PMC counters cannot be read inside the timed run: this is the committed "
                                           "summary of the separate rocprofv3 --pmc passes named in `source`; STALE unless "

@@ -39,6 +39,7 @@ class GemmParams(_S):
         ("rowvec", P), ("rowvec_period", I),
         ("residual", P), ("ldr", L),
         ("geglu", I), ("out_act", I),
+        ("perm_x", I), ("perm_y", I), ("perm_p", I),
     ]
 
 
@@ -77,7 +78,7 @@ class TemporalAttentionParams(_S):
         ("Q", P), ("ldq", L), ("K", P), ("V", P), ("ldkv", L),
         ("kv_stride_b", L), ("kv_stride_chunk", L), ("kv_chunk", I),
         ("O", P), ("ldo", L),
-        ("B", I), ("Fq", I), ("Fkv", I), ("P", I), ("heads", I), ("D", I), ("scale", F),
+        ("B", I), ("Fq", I), ("Fkv", I), ("P", I), ("heads", I), ("D", I), ("scale", F), ("qo_chunked", I),
     ]
 
 

@@ -96,6 +96,12 @@ HV_DEV void hv_gemm_epilogue_t(const HvGemmParams& p, f32x4 (&acc)[4][NMF], int 
     for (int mf = 0; mf < NMF; ++mf) {
         const int m = m_base + 16 * mf + r16;
         const int mc = min(m, p.M - 1);
+        int mo = mc;  // output / residual row (general instantiation only: optional transpose of the two outer row axes)
+        if (MODE == 0 && p.perm_p > 0) {
+            const int blk = mc / p.perm_p, pp = mc - blk * p.perm_p;
+            const int px = blk / p.perm_y, py = blk - px * p.perm_y;
+            mo = (py * p.perm_x + px) * p.perm_p + pp;
+        }
         // phase 1: issue every load of this row fragment (the per-column vectors are L1 hits after the
         // first fragment; re-loading them keeps 48 VGPRs free across the fragments)
         f32x4 bias4[4], cs4[4], row4[4];
@@ -125,7 +131,7 @@ HV_DEV void hv_gemm_epilogue_t(const HvGemmParams& p, f32x4 (&acc)[4][NMF], int 
             for (int nf = 0; nf < 4; ++nf) row4[nf] = *reinterpret_cast<const f32x4*>(rv_row + nc[nf]);
         }
         if (p.residual != nullptr) {
-            const bf16_t* res_row = p.residual + (long)mc * p.ldr;
+            const bf16_t* res_row = p.residual + (long)mo * p.ldr;
             if (!geglu) {
 #pragma unroll
                 for (int nf = 0; nf < 4; ++nf) res2[nf] = hv_ld8(res_row + nc[nf]);
@@ -142,7 +148,7 @@ HV_DEV void hv_gemm_epilogue_t(const HvGemmParams& p, f32x4 (&acc)[4][NMF], int 
         }
         // phase 2: arithmetic and stores
         if (mf == 0) HV_TRACE(7);
-        char* yrow = reinterpret_cast<char*>(p.Y) + (long)m * p.ldy * (out_f32 ? 4 : 2);
+        char* yrow = reinterpret_cast<char*>(p.Y) + (long)(MODE == 0 ? (m < p.M ? mo : m) : m) * p.ldy * (out_f32 ? 4 : 2);
 #pragma unroll
         for (int nf = 0; nf < 4; ++nf) {
             const int n = n_base + 16 * nf + 4 * quad;
@@ -200,7 +206,7 @@ HV_DEV void hv_gemm_epilogue_t(const HvGemmParams& p, f32x4 (&acc)[4][NMF], int 
 
 template <int NMF>
 HV_DEV void hv_gemm_epilogue(const HvGemmParams& p, f32x4 (&acc)[4][NMF], int m_base, int n_base, int r16, int quad HV_TRACE_PARAM) {
-    const bool lean = p.out_act == HV_ACT_NONE && !p.out_f32;
+    const bool lean = p.out_act == HV_ACT_NONE && !p.out_f32 && p.perm_p == 0;
     if (lean && p.geglu)
         hv_gemm_epilogue_t<NMF, 3>(p, acc, m_base, n_base, r16, quad HV_TRACE_ARG);
     else if (lean && p.Yt != nullptr)
@@ -541,6 +547,9 @@ static inline int hv_gemm_launch(const HvGemmParams& p, hipStream_t stream) {
     if (p.X2 != nullptr && (p.K1 % 64 != 0)) return -1;
     if (p.geglu && (p.N % 32 != 0 || p.Yt != nullptr || p.out_f32)) return -1;
     if (p.Yt != nullptr && (p.n_split % 16 != 0)) return -1;
+    if (p.perm_p != 0 && (p.perm_p < 0 || p.perm_x <= 0 || p.perm_y <= 0 || (long)p.perm_x * p.perm_y * p.perm_p != p.M ||
+                          p.Yt != nullptr || p.geglu))
+        return -1;
     const bool prologue = p.pro_scale != nullptr || p.pro_act != HV_ACT_NONE;
     char shape[128] = "";
     if (g_hv_prof)

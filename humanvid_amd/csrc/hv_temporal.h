@@ -40,7 +40,10 @@ __global__ __launch_bounds__(256) void hv_temporal_kernel(hv_temporal_attention_
 
     const int h = tid / FQ, fq = tid % FQ;
     if (h >= HEADS) return;
-    const bf16_t* qrow = p.Q + (row0 + (long)fq * p.P) * p.ldq + h * D;
+    const long qo_row = p.qo_chunked ? (long)b * p.kv_stride_b + (long)(fq / p.kv_chunk) * p.kv_stride_chunk +
+                                           (long)(fq % p.kv_chunk) * p.P + pix
+                                     : row0 + (long)fq * p.P;
+    const bf16_t* qrow = p.Q + qo_row * p.ldq + h * D;
 
     float s[FMAX];
 #pragma unroll
@@ -71,7 +74,7 @@ __global__ __launch_bounds__(256) void hv_temporal_kernel(hv_temporal_attention_
         l += s[kf];
     }
     const float inv = 1.0f / l;
-    bf16_t* orow = p.O + (row0 + (long)fq * p.P) * p.ldo + h * D;
+    bf16_t* orow = p.O + qo_row * p.ldo + h * D;
 #pragma unroll
     for (int dc = 0; dc < D / 8; ++dc) {
         float o8[8];
@@ -200,9 +203,13 @@ __global__ __launch_bounds__(HvTemporalGeom<D>::HG * 64) void hv_temporal_mfma_k
 
     // ---- stage Q, K, V rows ----
     constexpr int CV = CB / 8;
+    auto qo_row = [&](int f) -> long {  // query / output row of local frame f
+        return p.qo_chunked ? (long)b * p.kv_stride_b + (long)(f / p.kv_chunk) * p.kv_stride_chunk + (long)(f % p.kv_chunk) * p.P + pix
+                            : row0 + (long)f * p.P;
+    };
     for (int i = tid; i < FQ * CV; i += nthr) {
         const int f = i / CV, c = i % CV;
-        hv_st16(Qs + f * RS + c * 16, hv_ld16(p.Q + (row0 + (long)f * p.P) * p.ldq + c0 + c * 8));
+        hv_st16(Qs + f * RS + c * 16, hv_ld16(p.Q + qo_row(f) * p.ldq + c0 + c * 8));
     }
     for (int i = tid; i < F * CV; i += nthr) {
         const int f = i / CV, c = i % CV;
@@ -335,7 +342,7 @@ __global__ __launch_bounds__(HvTemporalGeom<D>::HG * 64) void hv_temporal_mfma_k
             const int q = 16 * qt + r16, d = 16 * dt + 4 * quad;
             if (q < FQ && d < D) {
                 const u32x2 st = {hv_pack2(o[0] * inv_l[qt], o[1] * inv_l[qt]), hv_pack2(o[2] * inv_l[qt], o[3] * inv_l[qt])};
-                hv_st8(p.O + (row0 + (long)q * p.P) * p.ldo + c0 + hd + d, st);
+                hv_st8(p.O + qo_row(q) * p.ldo + c0 + hd + d, st);
             }
         }
     }
@@ -364,6 +371,7 @@ static inline int hv_temporal_launch(const hv_temporal_attention_params& p, hipS
     if (p.heads != 8 || p.B <= 0 || p.Fkv <= 0 || p.Fq <= 0 || p.Fq > p.Fkv || p.P <= 0 || p.kv_chunk <= 0)
         return p.heads != 8 ? -2 : -1;
     if (p.ldq % 8 || p.ldkv % 8 || p.ldo % 8) return -1;
+    if (p.qo_chunked && p.Fq != p.Fkv) return -1;
     hv_note("hv_temporal_%s_kernel<%d> | B=%d Fq=%d Fkv=%d P=%d", g_hv_temporal_mfma && p.Fkv <= 32 ? "mfma" : "valu", p.D,
             p.B, p.Fq, p.Fkv, p.P);
     if (g_hv_temporal_mfma && p.Fkv <= 32) {

@@ -30,8 +30,9 @@ def _chk(t: torch.Tensor, dtype, what: str):
 def gemm(lib, stream, x, w, y, *, x2=None, k1=0, yt=None, n_split=0, pro_scale=None, pro_shift=None,
          rows_per_image=1, pro_act=A.ACT_NONE, bias=None, row_mean=None, row_rstd=None, colsum=None, pe=None,
          pe_period=1, pe_frames=1, rowvec=None, rowvec_period=1, residual=None, geglu=False, out_act=A.ACT_NONE,
-         M=None, ldx=None, ldy=None, ldr=None, ldx2=None):
-    """y[M, N(/2)] = epi(pro(x)[M, K] @ w[N, K]^T); x/x2/y/residual may be row-strided views."""
+         M=None, ldx=None, ldy=None, ldr=None, ldx2=None, row_perm=None):
+    """y[M, N(/2)] = epi(pro(x)[M, K] @ w[N, K]^T); x/x2/y/residual may be row-strided views.
+    row_perm=(X, Y, P): output (and residual) row (x*Y + y)*P + p is taken at (y*X + x)*P + p."""
     N, K = w.shape
     M = x.shape[0] if M is None else M
     p = A.GemmParams(
@@ -44,6 +45,8 @@ def gemm(lib, stream, x, w, y, *, x2=None, k1=0, yt=None, n_split=0, pro_scale=N
         pe=_p(pe), pe_period=pe_period, pe_frames=pe_frames, rowvec=_p(rowvec), rowvec_period=rowvec_period,
         residual=_p(residual), ldr=(residual.stride(0) if residual is not None else 0) if ldr is None else ldr,
         geglu=int(geglu), out_act=out_act,
+        perm_x=row_perm[0] if row_perm else 0, perm_y=row_perm[1] if row_perm else 0,
+        perm_p=row_perm[2] if row_perm else 0,
     )
     lib.call("hv_gemm", C.byref(p), stream)
 
@@ -103,6 +106,21 @@ def temporal_attention(lib, stream, qkv, o, *, B, F, P, heads, D):
         Q=qkv.data_ptr(), ldq=ld, K=qkv.data_ptr() + Cc * eb, V=qkv.data_ptr() + 2 * Cc * eb, ldkv=ld,
         kv_stride_b=F * P, kv_stride_chunk=0, kv_chunk=F, O=_p(o), ldo=o.stride(0),
         B=B, Fq=F, Fkv=F, P=P, heads=heads, D=D, scale=1.0 / math.sqrt(D),
+    )
+    lib.call("hv_temporal_attention", C.byref(p), stream)
+
+
+def temporal_attention_exchanged(lib, stream, qkv_recv, o_send, *, B, F_local, ranks, P, heads, D):
+    """All-to-all form: qkv_recv [ranks, B, F_local, P, 3C] is what the frames -> pixels all-to-all delivered (chunk s = the
+    frames of rank s, for this rank's P pixels); attends over all ranks * F_local frames and writes o_send
+    [ranks, B, F_local, P, C] in the same order, which is exactly the send buffer of the returning all-to-all."""
+    Cc = heads * D
+    eb = qkv_recv.element_size()
+    ld = 3 * Cc
+    p = A.TemporalAttentionParams(
+        Q=qkv_recv.data_ptr(), ldq=ld, K=qkv_recv.data_ptr() + Cc * eb, V=qkv_recv.data_ptr() + 2 * Cc * eb, ldkv=ld,
+        kv_stride_b=F_local * P, kv_stride_chunk=B * F_local * P, kv_chunk=F_local, O=o_send.data_ptr(), ldo=Cc,
+        B=B, Fq=F_local * ranks, Fkv=F_local * ranks, P=P, heads=heads, D=D, scale=1.0 / math.sqrt(D), qo_chunked=1,
     )
     lib.call("hv_temporal_attention", C.byref(p), stream)
 

@@ -188,31 +188,23 @@ class Runner:
                 if key not in self._pe_split:
                     self._pe_split[key] = pe[f0:f0 + F].contiguous()
                 pekw = dict(pe=self._pe_split[key], pe_period=N, pe_frames=F)
-            qkv = ws.get(f"mm_qkv_{M}x{C}", (M, 3 * C))
-            ops.gemm(L, st, hid, w[ab + ".qkv.w"], qkv, bias=w[ab + ".qkv.bias"], row_mean=mean, row_rstd=rstd,
-                     colsum=w[ab + ".qkv.colsum"], **pekw)
+            # No re-ordering copies: the QKV projection stores its rows straight in the send layout [dest rank r][b][f][p]
+            # (hv_gemm row permutation), the temporal kernel addresses the received [src rank s][b][f][p] chunks in place and
+            # writes its output in the same order (= the send buffer of the way back), and the output projection below folds
+            # the inverse re-ordering into its row permutation.
             send = ws.get(f"mm_a2a_s_{M}x{C}", (R, B, F, Np, 3 * C))
             recv = ws.get(f"mm_a2a_r_{M}x{C}", (R, B, F, Np, 3 * C))
-            qkv_all = ws.get(f"mm_qkv_all_{M}x{C}", (B, R * F, Np, 3 * C))  # all frames, my pixels
-            o_all = ws.get(f"mm_o_all_{M}x{C}", (B, R * F, Np, C))
+            ops.gemm(L, st, hid, w[ab + ".qkv.w"], send.view(M, 3 * C), bias=w[ab + ".qkv.bias"], row_mean=mean, row_rstd=rstd,
+                     colsum=w[ab + ".qkv.colsum"], row_perm=(B * F, R, Np), **pekw)
             shard = self.shard
-
-            def exchange_in():
-                send.copy_(qkv.view(B, F, R, Np, 3 * C).permute(2, 0, 1, 3, 4))      # chunk r = pixel slice of rank r
-                shard.all_to_all(recv, send)                                          # chunk s = frames of rank s
-                qkv_all.view(B, R, F, Np, 3 * C).copy_(recv.permute(1, 0, 2, 3, 4))
-
-            shard.deferred(exchange_in)
-            ops.temporal_attention(L, st, qkv_all.view(B * R * F * Np, 3 * C), o_all.view(B * R * F * Np, C), B=B, F=R * F,
-                                   P=Np, heads=H, D=D)
-            send_o, recv_o = send.view(-1)[:M * C].view(R, B, F, Np, C), recv.view(-1)[:M * C].view(R, B, F, Np, C)
-
-            def exchange_out():
-                send_o.copy_(o_all.view(B, R, F, Np, C).permute(1, 0, 2, 3, 4))      # chunk s = frames owned by rank s
-                shard.all_to_all(recv_o, send_o)                                      # chunk r = pixel slice r
-                o.view(B, F, R, Np, C).copy_(recv_o.permute(1, 2, 0, 3, 4))
-
-            shard.deferred(exchange_out)
+            shard.deferred(lambda: shard.all_to_all(recv, send))                      # chunk s = frames of rank s, my pixels
+            send_o = send.view(-1)[:M * C].view(R, B, F, Np, C)
+            recv_o = recv.view(-1)[M * C:2 * M * C].view(R, B, F, Np, C)             # disjoint from the rows still being read
+            ops.temporal_attention_exchanged(L, st, recv, send_o, B=B, F_local=F, ranks=R, P=Np, heads=H, D=D)
+            shard.deferred(lambda: shard.all_to_all(recv_o, send_o))                  # chunk r = pixel slice r, my frames
+            ops.gemm(L, st, recv_o.view(M, C), w[ab + ".to_out.0.w"], hid, bias=w[ab + ".to_out.0.bias"], residual=hid,
+                     row_perm=(R, B * F, Np))
+            return
         else:
             R, f0 = self.shard.world, self.shard.rank * F
             pq, pkv = {}, {}

@@ -73,6 +73,11 @@ typedef struct hv_gemm_params {
     long ldr;
     int geglu; /* W rows packed as [16 h | 16 g] blocks; Y has N/2 columns: h * gelu(g) */
     int out_act;
+    /* optional row permutation of the OUTPUT (and of the residual read): with perm_p > 0 the row index
+     * m = (x * perm_y + y) * perm_p + p is stored at (y * perm_x + x) * perm_p + p -- the transpose of the two outer axes
+     * of an [x][y][perm_p] row index.  Lets the frame-sharded motion module write the all-to-all send layout straight
+     * from the QKV projection and fold the inverse re-ordering into the output projection. */
+    int perm_x, perm_y, perm_p;
 } hv_gemm_params;
 int hv_gemm(const hv_gemm_params* p, void* stream);
 
@@ -189,6 +194,8 @@ typedef struct hv_temporal_attention_params {
     long ldo;
     int B, Fq, Fkv, P, heads, D;
     float scale;
+    int qo_chunked; /* 1: Q and O rows follow the K / V row formula (needs Fq == Fkv): every operand lives in the
+                       [rank][b][F/ranks][P] layout an all-to-all leaves behind -- no re-ordering copies around the kernel */
 } hv_temporal_attention_params;
 int hv_temporal_attention(const hv_temporal_attention_params* p, void* stream);
 

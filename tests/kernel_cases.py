@@ -80,6 +80,26 @@ def case_gemm(cx: Ctx, M=200, N=320, K=320, seed=0, residual=True, out_f32=False
     return e
 
 
+def case_gemm_row_perm(cx: Ctx, X=6, Y=4, P=24, N=320, K=320, seed=20):
+    """row-permuted output (+ residual read): row (x*Y + y)*P + p lands at (y*X + x)*P + p, with the LN fold and a bias"""
+    g = torch.Generator().manual_seed(seed)
+    M = X * Y * P
+    x, w = rnd(g, M, K), rnd(g, N, K, scale=K**-0.5)
+    bias, res = rnd(g, N, scale=0.1), rnd(g, M, N)
+    idx = torch.arange(M)
+    blk, pp = idx // P, idx % P
+    dst = ((blk % Y) * X + blk // Y) * P + pp
+    ref = torch.zeros(M, N)
+    ref[dst] = r(x) @ r(w).t() + bias
+    ref = ref + r(res)  # the residual is read at the DESTINATION row
+    y = torch.zeros(M, N, dtype=BF16, device=cx.device)
+    ops.gemm(cx.lib, cx.stream, cx.bf(x), cx.bf(w), y, bias=cx.dev(bias), residual=cx.bf(res), row_perm=(X, Y, P))
+    cx.sync()
+    e = nrmse(y, ref)
+    assert e < TOL, f"gemm row_perm nrmse {e}"
+    return e
+
+
 def case_gemm_prologue(cx: Ctx, n_img=3, rows=50, N=128, K=320, seed=1):
     """GroupNorm-apply (+SiLU) fused on the A operand: y = silu(x*scale[img]+shift[img]) @ W^T."""
     g = torch.Generator().manual_seed(seed)
@@ -277,6 +297,17 @@ def case_temporal(cx: Ctx, D=40, B=2, Fr=5, P=6, seed=7):
             want = ref.view(B, Fr, P, Cc)[:, rk * Fq:(rk + 1) * Fq].reshape(B * Fq * P, Cc)
             e2 = nrmse(ol, want)
             assert e2 < TOL, f"temporal sharded rank {rk} nrmse {e2}"
+    # all-to-all form: every operand in the [rank][b][F/ranks][P] chunk layout, output in the same order
+    if Fr % 2 == 0:
+        ranks, Fl = 2, Fr // 2
+        t5 = qkv.view(B, ranks, Fl, P, 3 * Cc)
+        recv = cx.bf(t5.permute(1, 0, 2, 3, 4).contiguous())  # [R,B,Fl,P,3C]
+        osend = torch.zeros(ranks, B, Fl, P, Cc, dtype=BF16, device=cx.device)
+        ops.temporal_attention_exchanged(cx.lib, cx.stream, recv, osend, B=B, F_local=Fl, ranks=ranks, P=P, heads=H, D=D)
+        cx.sync()
+        want = ref.view(B, ranks, Fl, P, Cc).permute(1, 0, 2, 3, 4)
+        e3 = nrmse(osend, want)
+        assert e3 < TOL, f"temporal exchanged form nrmse {e3}"
     return e
 
 

@@ -138,6 +138,11 @@ def test_conv_two_source_narrow(cx):
                  out_act=A.ACT_SILU)
 
 
+def test_gemm_row_permutation(cx):
+    kc.case_gemm_row_perm(cx)
+    kc.case_gemm_row_perm(cx, X=3, Y=2, P=50, N=192, K=128, seed=21)  # ragged against the 128/256-row tiles
+
+
 def test_groupnorm(cx):
     kc.case_groupnorm(cx)
     kc.case_groupnorm(cx, n=2, H=4, W=4, C1=1280, C2=640, seed=9)  # groups straddle the concat seam

@@ -24,6 +24,11 @@ def test_gemm(cx):
     kc.case_gemm(cx, M=1536, N=1920, K=640, transposed=True)
 
 
+def test_gemm_row_permutation(cx):
+    kc.case_gemm_row_perm(cx, X=48, Y=8, P=96, N=960, K=320)   # frame-sharded QKV -> all-to-all send layout
+    kc.case_gemm_row_perm(cx, X=8, Y=48, P=96, N=320, K=320)   # output projection folding the way back
+
+
 def test_gemm_fused(cx):
     kc.case_gemm_prologue(cx, n_img=6, rows=384, N=1280, K=1280)
     kc.case_gemm_lnfold(cx, B=2, Fr=24, P=96, C=1280, N=3840)

@@ -38,12 +38,17 @@ def _inputs():
     return O, cfg, sd, lat, pose, pl, clip, banks
 
 
-def _worker(rank, world, port, out_path):
+def _worker(rank, world, port, out_path, backend="gloo"):
     import torch.distributed as dist
 
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-    dist.init_process_group("gloo", rank=rank, world_size=world)
-    torch.cuda.set_device(0)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if backend == "nccl":  # RCCL: one GPU per rank, device collectives (the transport bench.py --gpus N uses)
+        torch.cuda.set_device(rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", rank))
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        torch.cuda.set_device(0)
     O, cfg, sd, lat, pose, pl, clip, banks = _inputs()
     from humanvid_amd.conditioning import CameraPoseEncoder, PoseGuider
     from humanvid_amd.engine import UNet3DEngine
@@ -93,3 +98,25 @@ def test_two_rank_frame_sharding_matches_oracle(tmp_path, exchange, monkeypatch)
     errs = [float((a - b).norm() / b.norm()) for a, b in zip(got, trace)]
     print("sharded (2 ranks) latent nrmse per step", errs)
     assert len(errs) == 3 and max(errs) < 2e-2, errs  # step 0 eager, 1 recorded, 2 replayed
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs: RCCL refuses two ranks on one device")
+@pytest.mark.parametrize("exchange", ["alltoall", "allgather"])
+def test_two_rank_frame_sharding_over_rccl(tmp_path, exchange, monkeypatch):
+    """The same run on the real transport: backend "nccl" (= RCCL over xGMI), device collectives, command-list replay
+    across the collectives.  Runs wherever two GPUs are visible (the driver's multi-GPU box); skipped on the 1-GPU box."""
+    monkeypatch.setenv("HUMANVID_TEMPORAL_EXCHANGE", exchange)
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    out_path = str(tmp_path / "sharded_rccl.pt")
+    mp.spawn(_worker, args=(2, port, out_path, "nccl"), nprocs=2, join=True)
+    got = torch.load(out_path)
+    O, cfg, sd, lat, pose, pl, clip, banks = _inputs()
+    trace = []
+    O.denoise_loop(sd, cfg, O.make_pose_guider_weights(), O.make_camera_encoder_weights(), lat.clone(), pose, pl, clip,
+                   banks, 4, 3.5, max_steps=3, trace=trace)
+    errs = [float((a - b).norm() / b.norm()) for a, b in zip(got, trace)]
+    print("sharded over RCCL (2 ranks) latent nrmse per step", errs)
+    assert len(errs) == 3 and max(errs) < 2e-2, errs

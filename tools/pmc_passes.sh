@@ -4,7 +4,7 @@
 # reduced gpurun_out/pmc_summary.csv.
 REPO=$(pwd)
 cd /tmp && export TMPDIR=/tmp
-CMD="python $REPO/bench.py --steps 2 --warmup 1 --no-cpu-baseline"
+CMD="python $REPO/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-profile"
 timeout 400 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $REPO/gpurun_out/pmc_fetch -- $CMD < /dev/null > $REPO/gpurun_out/pmc_fetch.log 2>&1
 timeout 400 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $REPO/gpurun_out/pmc_write -- $CMD < /dev/null > $REPO/gpurun_out/pmc_write.log 2>&1
 timeout 400 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES --kernel-trace --output-format csv -d $REPO/gpurun_out/pmc_mfma -- $CMD < /dev/null > $REPO/gpurun_out/pmc_mfma.log 2>&1

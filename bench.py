@@ -249,6 +249,10 @@ def main():
     from humanvid_amd.scheduler import DDIMScheduler, get_context_scheduler
     from humanvid_amd.workload import unet3d_flops
 
+    if os.environ.get("HUMANVID_GEMM_GLDS"):  # same-box A/B of the GEMM tile selection (hv_set_tuning key 3)
+        from humanvid_amd import lib as hvlib
+
+        hvlib.load().call("hv_set_tuning", 3, int(os.environ["HUMANVID_GEMM_GLDS"]))
     cfgsel = CONFIGS[args.config]
     F, H, W = args.frames or cfgsel["F"], args.height or cfgsel["H"], args.width or cfgsel["W"]
     h, w = H // 8, W // 8

@@ -37,10 +37,12 @@
 #define HV_ATTN_OCC40 4
 #endif
 #ifndef HV_ATTN_ONES
-// Denominator-through-the-MFMA variant (a row of ones in the spare V^T rows of d = 40).  Correct on
-// the host emulator but produced wrong / non-deterministic sums on MI355X in round 1 (A/B in
-// tools/diag_attn.py); kept behind this switch until the hardware behaviour is understood.
-#define HV_ATTN_ONES 0
+// Denominator through the MFMA: d = 40 pads V^T to 48 rows; the first spare row is a row of ones, so the P.V MFMA that is
+// issued anyway also accumulates sum(P) and the 16 VALU adds per query fragment and tile disappear (level 0: 6.21 -> 5.89 ms
+// same-box).  Round 1 found this variant "wrong on hardware" and parked it; that was the mixed-shape MFMA chain of the
+// QK^T remainder (see HV_ATTN_PAD32 below; with fewer VALU instructions between the dependent pair it tripped more
+// often).  With same-shape chains it passes every hardware case, bench shapes included.
+#define HV_ATTN_ONES 1
 #endif
 #ifndef HV_ATTN_LAZY
 #define HV_ATTN_LAZY 1

@@ -561,6 +561,20 @@ static inline int hv_gemm_launch(const HvGemmParams& p, hipStream_t stream) {
         // per-CU load path) when N fills them about as well as 256x128 tiles would
         const int n128 = ((p.N + 127) / 128) * 128, n256 = ((p.N + 255) / 256) * 256;
         const int gm = g_hv_gemm_raster > 0 ? g_hv_gemm_raster : (n128 / 128 > 8 ? 8 : 1);
+        // 256x256x64 tiles, 2-slot 128 KiB ring, 8 waves (2 x 4 of 128x64), one workgroup per CU: whole 128-byte lines per
+        // row (twice the LDS-DMA fill rate of 64-byte segments) and 2/3 of the operand bytes per FLOP of the 256x128 tile.
+        // The kernel is bound by the CU's L2 -> LDS fill path (~27-60 B/clk measured: round-2 attention trace, round-1
+        // fillbw probe), so for wide N this is the shape that gets closest to the MFMA bound.
+        if ((g_hv_gemm_glds == 7 || g_hv_gemm_glds == 8) && p.N >= 960 && (n256 - p.N) * 8 <= p.N &&
+            (g_hv_gemm_glds == 7 || p.K >= 640)) {
+            const int tiles = tm * (n256 / 256);
+            int grid = ((tiles + 7) / 8) * 8;
+            if (grid > 256) grid = 256;
+            if (grid > g_hv_gemm_max_grid) grid = g_hv_gemm_max_grid;
+            hv_note("hv_gemm_glds_kernel<64,2,256,8,256> | %s", shape);
+            hv_launch(hv_gemm_glds_kernel<64, 2, 256, 8, 256>, dim3(grid), dim3(512), stream, p, gm);
+            return 0;
+        }
         if (g_hv_gemm_glds == 3 && p.N >= 512 && (n256 - n128) * 12 <= p.N) {
             const int tiles = tm * (n256 / 256);
             int grid = ((tiles + 7) / 8) * 8;
@@ -573,7 +587,7 @@ static inline int hv_gemm_launch(const HvGemmParams& p, hipStream_t stream) {
         // 128x128x64 tiles (whole 128-byte lines per row: 1.8x the LDS-DMA rate of 64-byte row segments), 2-slot 64 KiB
         // ring, two workgroups per CU: measured 7-13 % faster than 256x128x32 when K >= 2 N (the FF output projections),
         // slower for wide outputs (half the operand reuse per tile)
-        if (g_hv_gemm_glds == 6 || (g_hv_gemm_glds == 2 && p.K >= 2 * p.N)) {
+        if (g_hv_gemm_glds == 6 || ((g_hv_gemm_glds == 2 || g_hv_gemm_glds >= 7) && p.K >= 2 * p.N)) {
             const int tiles6 = ((p.M + 127) / 128) * (n128 / 128);
             int grid6 = ((tiles6 + 7) / 8) * 8;
             if (grid6 > 512) grid6 = 512;

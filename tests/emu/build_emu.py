@@ -16,7 +16,7 @@ def build(force=False):
         return OUT
     os.makedirs(os.path.dirname(OUT), exist_ok=True)
     cxx = CLANG if os.path.exists(CLANG) else "clang++"
-    cmd = [cxx, "-DHV_EMU", "-DHV_SINGLE_TU", "-x", "c++", "-O2", "-std=c++17", "-I" + os.path.join(REPO, "include"), "-I" + srcdir, "-I" + HERE,
+    cmd = [cxx, "-DHV_EMU", "-DHV_SINGLE_TU", "-x", "c++", "-O2", "-Wno-psabi", "-std=c++17", "-I" + os.path.join(REPO, "include"), "-I" + srcdir, "-I" + HERE,
            "-include", os.path.join(HERE, "hv_emu.h"), "-shared", "-fPIC", os.path.join(srcdir, "hv_api.cpp"),
            "-o", OUT]
     subprocess.check_call(cmd)

@@ -125,6 +125,21 @@ HV_DEV float hv_act(float x, int act) {
 HV_DEV void hv_glds16(const void* gsrc, void* lds_wave_base) {
     __builtin_amdgcn_global_load_lds(gsrc, (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
+// Same copy issued from inline asm, with the source as a wave-uniform base (SGPR pair) + a 32-bit per-lane byte offset and
+// the LDS destination as a scalar byte address.  hipcc's wait-count tracker does not see it: with the builtin form it makes
+// every ds_read that follows an LDS-DMA wait vmcnt(0) ("the DMA may alias the read") -- seen in the convolution's k-loop,
+// where it drained the ring in every step -- whereas here completion is tracked by hand anyway (hv_vm_wait).  Ordinary loads
+// stay correct: vmcnt retires in order, so a compiler-computed count that ignores these copies can only wait longer.
+HV_DEV void hv_glds16_s(const void* base_uniform, unsigned byte_ofs, void* lds_wave_base) {
+    const unsigned lds_addr_uniform = (unsigned)(unsigned long)(__attribute__((address_space(3))) void*)lds_wave_base;
+    // M0 is compiler-reserved and not preserved around an asm statement: save / restore it inside the statement
+    // (cdna_hip_programming.md 5.7).  Leading s_nop 4: an SGPR operand fresh from v_readfirstlane read as a VMEM base.
+    unsigned keep;
+    asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(byte_ofs), "s"(base_uniform), "s"(lds_addr_uniform)
+                 : "memory");
+}
 template <int N>
 HV_DEV void hv_vm_wait() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
@@ -136,6 +151,9 @@ HV_DEV void hv_barrier_raw() {
 #else
 HV_DEV void hv_glds16(const void* gsrc, void* lds_wave_base) {
     memcpy((char*)lds_wave_base + (threadIdx.x & 63) * 16, gsrc, 16);  // emulator: synchronous
+}
+HV_DEV void hv_glds16_s(const void* base_uniform, unsigned byte_ofs, void* lds_wave_base) {
+    memcpy((char*)lds_wave_base + (threadIdx.x & 63) * 16, (const char*)base_uniform + byte_ofs, 16);
 }
 template <int N>
 HV_DEV void hv_vm_wait() {}

@@ -156,19 +156,37 @@ __global__ __launch_bounds__(2 * NPIX) void hv_conv3x3_kernel(hv_conv3x3_params 
             hv_st16(wsm + buf * G::WTILE_BYTES + hv_swz<32>(id >> 2, id & 3), wreg[i]);
         }
     };
-    // LDS-DMA form: 8 wave-instructions of 1 KiB (16 rows x 64 B) per tap tile, 2 per wave; the
-    // swizzle of hv_swz<32> is applied on the source address; rows beyond Cout are clamped
-    auto issue_w = [&](int step) {
-        const int chunk = step / 9, tap = step % 9;
-        unsigned char* slot = wsm + (step % 3) * G::WTILE_BYTES;
+    // LDS-DMA form: 8 wave-instructions of 1 KiB (16 rows x 64 B) per tap tile, 8 / NW per wave; the swizzle of
+    // hv_swz<32> is applied on the source address; rows beyond Cout are clamped.  The per-lane part of the source address
+    // (weight row, swizzled chunk) is computed once (wofs, 32-bit byte offsets: hv_conv3x3_launch checks the span), the
+    // per-step part (tap, channel chunk) is a scalar added to the base; the copies are issued from inline asm
+    // (hv_glds16_s) so that hipcc's wait-count tracker does not put a vmcnt(0) in front of every ds_read of the step.
+    constexpr int WQ = 8 / NW;
+#ifndef HV_EMU
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+#else
+    const int wave_u = wave;
+#endif
+    unsigned wofs0 = 0, wofs1 = 0;
+    {
         const int sub = lane >> 2, pc = lane & 3;
-#pragma unroll
-        for (int q = 0; q < 8 / NW; ++q) {
-            const int j = wave + NW * q;
-            const int row = 16 * j + sub;
-            const int c = pc ^ ((row >> 2) & 3);
-            const int n = min(n0 + row, p.Cout - 1);
-            hv_glds16(p.W + ((long)n * 9 + tap) * Cin + chunk * 32 + c * 8, slot + j * 1024);
+        const int row0 = 16 * wave_u + sub;
+        wofs0 = ((unsigned)min(n0 + row0, p.Cout - 1) * 9u * (unsigned)Cin + (unsigned)((pc ^ ((row0 >> 2) & 3)) * 8)) * 2u;
+        if (WQ > 1) {
+            const int row1 = 16 * (wave_u + NW) + sub;
+            wofs1 = ((unsigned)min(n0 + row1, p.Cout - 1) * 9u * (unsigned)Cin + (unsigned)((pc ^ ((row1 >> 2) & 3)) * 8)) * 2u;
+        }
+    }
+    int iw_chunk = 0, iw_tap = 0, iw_slot = 0;  // issue state: advanced one step per call
+    auto issue_w = [&]() __attribute__((always_inline)) {
+        unsigned char* slot = wsm + iw_slot * G::WTILE_BYTES;
+        const bf16_t* base = p.W + (long)iw_tap * Cin + iw_chunk * 32;  // wave-uniform
+        hv_glds16_s(base, wofs0, slot + wave_u * 1024);
+        if (WQ > 1) hv_glds16_s(base, wofs1, slot + (wave_u + NW) * 1024);
+        if (++iw_slot == 3) iw_slot = 0;
+        if (++iw_tap == 9) {
+            iw_tap = 0;
+            ++iw_chunk;
         }
     };
 
@@ -189,52 +207,61 @@ __global__ __launch_bounds__(2 * NPIX) void hv_conv3x3_kernel(hv_conv3x3_params 
 
     load_halo(0);
     if (GLDS) {
-        issue_w(0);
-        if (nsteps > 1) issue_w(1);
+        issue_w();
+        if (nsteps > 1) issue_w();
     } else {
         load_w(0);
     }
-    for (int s = 0; s < nsteps; ++s) {
-        const int chunk = s / 9, tap = s - chunk * 9;
-        const int wbuf = GLDS ? s % 3 : (s & 1), hbuf = chunk & 1;
-        if (tap == 0) store_halo(chunk, hbuf);
-        if (GLDS) {
-            if (s + 1 < nsteps)
-                hv_vm_wait<8 / NW>();  // tap tile s landed, tile s+1 may stay in flight
-            else
-                hv_vm_wait<0>();
-            hv_barrier_raw();
-            if (s + 2 < nsteps) issue_w(s + 2);  // reuses the slot read at step s-1
-            if (tap == 8 && s + 1 < nsteps) load_halo(chunk + 1);
-        } else {
-            store_w(wbuf);
-            __syncthreads();
-            if (s + 1 < nsteps) {
-                load_w(s + 1);
-                if (tap == 8) load_halo(chunk + 1);
+    // k-loop: channel chunks x the nine taps, the taps as a compile-time loop.  (As one runtime loop over (chunk, tap)
+    // steps -- the round-1 form -- the halo registers loaded at tap 8 for the next chunk are live across the back-edge of
+    // EVERY step; hipcc's wait-count tracker then protects them with vmcnt(3) / (1) / (0) in front of each step's ds_reads,
+    // which drained the LDS-DMA weight ring in every step.  Unrolled, the only compiler waits left are the true ones at
+    // tap 0, and the tap offsets / ring slots (9 % 3 == 0) are immediates.)
+    for (int chunk = 0; chunk < nchunks; ++chunk) {
+        const int hbuf = chunk & 1;
+        hv_static_for<9>([&](auto T) __attribute__((always_inline)) {
+            constexpr int tap = decltype(T)::value;
+            const int s = chunk * 9 + tap;
+            const int wbuf = GLDS ? tap % 3 : (s & 1);
+            if (tap == 0) store_halo(chunk, hbuf);
+            if (GLDS) {
+                if (s + 1 < nsteps)
+                    hv_vm_wait<8 / NW>();  // tap tile s landed, tile s+1 may stay in flight
+                else
+                    hv_vm_wait<0>();
+                hv_barrier_raw();
+                if (s + 2 < nsteps) issue_w();  // k-step s+2: reuses the slot read at step s-1
+                if (tap == 8 && s + 1 < nsteps) load_halo(chunk + 1);
+            } else {
+                store_w(wbuf);
+                __syncthreads();
+                if (s + 1 < nsteps) {
+                    load_w(s + 1);
+                    if (tap == 8) load_halo(chunk + 1);
+                }
             }
-        }
-        const int dy = tap / 3, dx = tap - dy * 3;
-        const unsigned char* hb = halo + hbuf * G::HALO_BYTES + quad * 16;
-        const unsigned char* wb = wsm + wbuf * G::WTILE_BYTES;
-        bf16x8 wf[4], xf[4];
+            constexpr int dy = tap / 3, dx = tap - dy * 3;
+            const unsigned char* hb = halo + hbuf * G::HALO_BYTES + quad * 16;
+            const unsigned char* wb = wsm + wbuf * G::WTILE_BYTES;
+            bf16x8 wf[4], xf[4];
 #pragma unroll
-        for (int f = 0; f < 4; ++f) {
-            wf[f] = hv_as_bf16x8(hv_ld16(wb + hv_swz<32>(64 * wn + 16 * f + r16, quad)));
-            int lp;
-            if (MODE == HV_CONV_S1)
-                lp = (py[f] + dy) * G::HW + px[f] + dx;
-            else if (MODE == HV_CONV_S2)
-                lp = (2 * py[f] + dy) * G::HW + 2 * px[f] + dx;
-            else
-                lp = ((py[f] + dy + 1) >> 1) * G::HW + ((px[f] + dx + 1) >> 1);
-            xf[f] = hv_as_bf16x8(hv_ld16(hb + lp * G::PS));
-        }
+            for (int f = 0; f < 4; ++f) {
+                wf[f] = hv_as_bf16x8(hv_ld16(wb + hv_swz<32>(64 * wn + 16 * f + r16, quad)));
+                int lp;
+                if (MODE == HV_CONV_S1)
+                    lp = (py[f] + dy) * G::HW + px[f] + dx;
+                else if (MODE == HV_CONV_S2)
+                    lp = (2 * py[f] + dy) * G::HW + 2 * px[f] + dx;
+                else
+                    lp = ((py[f] + dy + 1) >> 1) * G::HW + ((px[f] + dx + 1) >> 1);
+                xf[f] = hv_as_bf16x8(hv_ld16(hb + lp * G::PS));
+            }
 #pragma unroll
-        for (int nf = 0; nf < 4; ++nf)
+            for (int nf = 0; nf < 4; ++nf)
 #pragma unroll
-            for (int mf = 0; mf < 4; ++mf)
-                acc[nf][mf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nf], xf[mf], acc[nf][mf], 0, 0, 0);
+                for (int mf = 0; mf < 4; ++mf)
+                    acc[nf][mf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nf], xf[mf], acc[nf][mf], 0, 0, 0);
+        });
     }
 
     // ---- epilogue.  Loads are batched (all bias / time-embedding vectors, then all residual fragments of
@@ -304,6 +331,7 @@ static inline void hv_conv3x3_launch_t(const hv_conv3x3_params& p, hipStream_t s
 static inline int hv_conv3x3_launch(const hv_conv3x3_params& p, hipStream_t stream) {
     if (p.C1 <= 0 || p.C1 % 32 != 0 || p.C2 % 32 != 0 || p.Cout % 4 != 0) return -1;
     if (p.C2 > 0 && p.X2 == nullptr) return -1;
+    if ((long)p.Cout * 9 * (p.C1 + p.C2) * 2 >= (1L << 32)) return -1;  // 32-bit weight offsets in the LDS-DMA path
     if (p.mode == HV_CONV_S1 && (p.Ho != p.Hs || p.Wo != p.Ws)) return -1;
     if (p.mode == HV_CONV_S2 && (p.Ho != (p.Hs + 1) / 2 || p.Wo != (p.Ws + 1) / 2)) return -1;
     if (p.mode == HV_CONV_UP2 && (p.Ho != 2 * p.Hs || p.Wo != 2 * p.Ws)) return -1;

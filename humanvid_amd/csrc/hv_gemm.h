@@ -65,6 +65,16 @@ __device__ unsigned long long g_hv_trace[8192];
 #define HV_TRACE_ARG
 #define HV_TRACE(id)
 #endif
+#ifndef HV_GEMM_DEFER
+// 1: tiles whose epilogue has one of the hot forms run hv_gemm_epilogue_fast (below); 0 = the round-1 epilogue, for A/Bs.
+#define HV_GEMM_DEFER 1
+#endif
+#ifndef HV_GEMM_EPI_SB
+#define HV_GEMM_EPI_SB 1
+#endif
+#ifndef HV_GEMM_EPI_G
+#define HV_GEMM_EPI_G 2
+#endif
 #ifndef HV_GEMM_DBG
 #define HV_GEMM_DBG 0  // experiment mask: 1 no epilogue, 2 no epilogue stores, 4 no ds_reads, 8 no LDS-DMA, 16 X from L2
 #endif
@@ -204,6 +214,160 @@ HV_DEV void hv_gemm_epilogue_t(const HvGemmParams& p, f32x4 (&acc)[4][NMF], int 
     HV_TRACE(11);
 }
 
+// ---- fast epilogue for the hot output forms (round 2).  What was wrong with the one above, measured with gemm_trace and the
+// -DHV_GEMM_DBG builds: it costs ~20 000 cycles per K = 320 tile against ~24 000 for the tile's ten k-steps, and 0.18 of the
+// 0.47 ms of the level-0 QKV GEMM remain when its stores are compiled out.  The stores of row fragment mf sit in front of the
+// loads of fragment mf+1; hipcc may not hoist those loads (Y can alias the residual -- the residual stream IS updated in
+// place), and with LDS-DMA in flight every wait for them is a vmcnt(0), which on gfx9 also waits for the just-issued stores
+// to be acknowledged: eight serial store round trips per tile.  Here NO store precedes a load: the per-column vectors are
+// loaded once, the per-row terms (LayerNorm mean / rstd, residual) in groups of four row fragments, the packed results take
+// the place of the accumulators they consume, and all stores of the tile go out back to back at the end and drain under the
+// next tile's k-steps.  Everything is compile-time selected (LN fold, residual, output form) -- straight-line code, ragged
+// edges by clamped loads and masked stores.  A per-row table (positional encoding or per-batch vector) is supported when
+// one table row covers the wave's rows (always true at the levels that matter: tokens per image are multiples of 128);
+// other tiles, fp32 output, activations and the row permutation take the general epilogue.
+// OUT: 0 = bf16 row-major, 1 = the same with the transposed tail (QKV projection), 2 = GEGLU.
+template <int NMF, bool LN, bool RES, int OUT>
+HV_DEV void hv_gemm_epilogue_fast(const HvGemmParams& p, f32x4 (&acc)[4][NMF], int m_base, int n_base, int r16, int quad,
+                                  const float* tab_row HV_TRACE_PARAM) {
+    static_assert(!(RES && OUT != 0), "residual only with the plain output form");
+    constexpr int G = NMF < HV_GEMM_EPI_G ? NMF : HV_GEMM_EPI_G;  // row fragments per load group
+    constexpr int NO = OUT == 2 ? 2 : 4;  // packed 4-channel outputs per row fragment
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    int nc[4];
+#pragma unroll
+    for (int nf = 0; nf < 4; ++nf) nc[nf] = min(n_base + 16 * nf + 4 * quad, p.N - 4);
+    f32x4 add4[4], cs4[4];
+#pragma unroll
+    for (int nf = 0; nf < 4; ++nf) add4[nf] = cs4[nf] = zero4;
+    // every address below is a wave-uniform base + a 32-bit byte offset (saddr form: one address register per load)
+    unsigned nb[4];
+#pragma unroll
+    for (int nf = 0; nf < 4; ++nf) nb[nf] = 4u * (unsigned)nc[nf];
+    auto ld4 = [&](const float* base, unsigned byte_ofs) __attribute__((always_inline)) {
+        return *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(base) + byte_ofs);
+    };
+    if (p.bias != nullptr) {
+#pragma unroll
+        for (int nf = 0; nf < 4; ++nf) add4[nf] = ld4(p.bias, nb[nf]);
+    }
+    if (LN) {
+#pragma unroll
+        for (int nf = 0; nf < 4; ++nf) cs4[nf] = ld4(p.colsum, nb[nf]);
+    }
+    if (tab_row != nullptr) {
+        f32x4 t4[4];
+#pragma unroll
+        for (int nf = 0; nf < 4; ++nf) t4[nf] = ld4(tab_row, nb[nf]);
+#pragma unroll
+        for (int nf = 0; nf < 4; ++nf) add4[nf] += t4[nf];
+    }
+    u32x2 outp[NMF][NO];
+#pragma unroll
+    for (int g = 0; g < NMF; g += G) {
+        float mean[G], rstd[G];
+        u32x2 res2[G][RES ? 4 : 1];
+#pragma unroll
+        for (int j = 0; j < G; ++j) {
+            const int mc = min(m_base + 16 * (g + j) + r16, p.M - 1);
+            if (LN) {
+                mean[j] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(p.row_mean) + 4u * (unsigned)mc);
+                rstd[j] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(p.row_rstd) + 4u * (unsigned)mc);
+            }
+            if (RES) {
+                // 32-bit byte offsets from the wave-uniform base (span checked by hv_gemm_launch): half the address registers
+                const unsigned ro = (unsigned)mc * (unsigned)p.ldr * 2u;
+#pragma unroll
+                for (int nf = 0; nf < 4; ++nf)
+                    res2[j][nf] = hv_ld8(reinterpret_cast<const char*>(p.residual) + (ro + 2u * (unsigned)nc[nf]));
+            }
+        }
+#if !defined(HV_EMU) && HV_GEMM_EPI_SB
+        __builtin_amdgcn_sched_barrier(0);  // the group's loads stay together, ahead of its arithmetic
+#endif
+        if (g == 0) HV_TRACE(7);
+#pragma unroll
+        for (int j = 0; j < G; ++j) {
+            const int mf = g + j;
+#pragma unroll
+            for (int nf = 0; nf < 4; ++nf) {
+                f32x4 v = acc[nf][mf];
+                if (LN) v = rstd[j] * (v - mean[j] * cs4[nf]);
+                v += add4[nf];
+                if (OUT == 2) {
+                    // packed weight rows: [16 x h | 16 x g] blocks -> fragment pairs (even nf: h, odd nf: g)
+                    if ((nf & 1) == 0) {
+                        acc[nf][mf] = v;
+                        continue;
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = acc[nf - 1][mf][r] * hv_gelu_fast(v[r]);
+                    outp[mf][OUT == 2 ? (nf >> 1) : 0] = u32x2{hv_pack2(v[0], v[1]), hv_pack2(v[2], v[3])};
+                } else {
+                    if (RES) {
+                        const u32x2 r2 = res2[j][RES ? nf : 0];
+                        v += f32x4{hv_bf2f((bf16_t)(r2[0] & 0xffff)), hv_bf2f((bf16_t)(r2[0] >> 16)),
+                                   hv_bf2f((bf16_t)(r2[1] & 0xffff)), hv_bf2f((bf16_t)(r2[1] >> 16))};
+                    }
+                    outp[mf][OUT == 2 ? 0 : nf] = u32x2{hv_pack2(v[0], v[1]), hv_pack2(v[2], v[3])};
+                }
+            }
+        }
+#if !defined(HV_EMU) && HV_GEMM_EPI_SB
+        __builtin_amdgcn_sched_barrier(0);  // ... and the next group's loads are not hoisted over it (register budget)
+#endif
+    }
+    HV_TRACE(12);
+#ifndef HV_EMU
+    // Pin the packed results here.  Otherwise hipcc sinks the arithmetic of a fragment into its (edge-masked) store branch;
+    // on the path that skips the store the fragment's loads are then never waited for, the register state that reaches the
+    // k-loop header carries "load in flight into v[..]", and the first ds_read of the next k-step that reuses such a register
+    // gets a compiler-inserted s_waitcnt vmcnt(0) -- in EVERY k-step, draining the LDS-DMA ring (seen in the .s of the first
+    // version of this function: two vmcnt(0) between the k-loop's ds_reads).
+#pragma unroll
+    for (int mf = 0; mf < NMF; ++mf)
+#pragma unroll
+        for (int no = 0; no < NO; ++no) asm volatile("" : "+v"(outp[mf][no][0]), "+v"(outp[mf][no][1]));
+    // ... and tell hipcc's wait-count tracker that no load is outstanding from here on (only this tile's stores and the
+    // LDS-DMA of the next k-tiles follow): vmcnt(0), lgkmcnt / expcnt untouched.  No store has been issued yet, so this
+    // waits for loads only.
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+#endif
+#if HV_GEMM_DBG & 2
+    if (acc[0][0][0] != 1.2345f) return;
+#endif
+    char* const yb = reinterpret_cast<char*>(p.Y);
+    char* const ytb = reinterpret_cast<char*>(p.Yt);
+#pragma unroll
+    for (int mf = 0; mf < NMF; ++mf) {
+        const int m = m_base + 16 * mf + r16;
+        if (m >= p.M) continue;
+        const unsigned yo = (unsigned)m * (unsigned)p.ldy * 2u;
+#pragma unroll
+        for (int no = 0; no < NO; ++no) {
+            const u32x2 o = outp[mf][no];
+            if (OUT == 2) {
+                const int n = n_base + 32 * no + 4 * quad;  // h column of the [h|g] pair (the g column is 16 further)
+                if (n + 16 < p.N) hv_st8_stream(yb + (yo + 2u * (unsigned)((n_base >> 1) + 16 * no + 4 * quad)), o);
+            } else {
+                const int n = n_base + 16 * no + 4 * quad;
+                if (n >= p.N) continue;
+                if (OUT == 1 && n >= p.n_split) {
+                    const unsigned ts = (unsigned)p.ldyt * 2u, to = (unsigned)(n - p.n_split) * ts + 2u * (unsigned)m;
+                    *reinterpret_cast<bf16_t*>(ytb + to) = (bf16_t)(o[0] & 0xffffu);
+                    *reinterpret_cast<bf16_t*>(ytb + (to + ts)) = (bf16_t)(o[0] >> 16);
+                    *reinterpret_cast<bf16_t*>(ytb + (to + 2 * ts)) = (bf16_t)(o[1] & 0xffffu);
+                    *reinterpret_cast<bf16_t*>(ytb + (to + 3 * ts)) = (bf16_t)(o[1] >> 16);
+                } else {
+                    hv_st8_stream(yb + (yo + 2u * (unsigned)n), o);
+                }
+            }
+        }
+    }
+    HV_TRACE(13);
+    HV_TRACE(11);
+}
+
 template <int NMF>
 HV_DEV void hv_gemm_epilogue(const HvGemmParams& p, f32x4 (&acc)[4][NMF], int m_base, int n_base, int r16, int quad HV_TRACE_PARAM) {
     const bool lean = p.out_act == HV_ACT_NONE && !p.out_f32 && p.perm_p == 0;
@@ -215,6 +379,56 @@ HV_DEV void hv_gemm_epilogue(const HvGemmParams& p, f32x4 (&acc)[4][NMF], int m_
         hv_gemm_epilogue_t<NMF, 1>(p, acc, m_base, n_base, r16, quad HV_TRACE_ARG);
     else
         hv_gemm_epilogue_t<NMF, 0>(p, acc, m_base, n_base, r16, quad HV_TRACE_ARG);
+}
+
+// Output forms of hv_gemm_epilogue_fast that the LDS-DMA kernel instantiates; hv_gemm_fast_form() (host) classifies a
+// problem, everything else runs on the register-staged kernel with the general epilogue.
+enum { HV_FORM_NONE = -1, HV_FORM_LN = 0, HV_FORM_LN_YT = 1, HV_FORM_LN_GEGLU = 2, HV_FORM_RES = 3, HV_FORM_PLAIN = 4 };
+
+static inline int hv_gemm_fast_form(const HvGemmParams& p, int rows_per_wave) {
+    if (!HV_GEMM_DEFER) return HV_FORM_PLAIN;  // A/B build: the kernel uses the general epilogue, every form is accepted
+    if (p.out_act != HV_ACT_NONE || p.out_f32 || p.perm_p != 0) return HV_FORM_NONE;
+    if (p.pe != nullptr && p.rowvec != nullptr) return HV_FORM_NONE;
+    // one table row per wave sub-tile: sub-tiles start at multiples of rows_per_wave
+    if (p.pe != nullptr && (p.pe_period <= 0 || p.pe_period % rows_per_wave != 0)) return HV_FORM_NONE;
+    if (p.rowvec != nullptr && (p.rowvec_period <= 0 || p.rowvec_period % rows_per_wave != 0)) return HV_FORM_NONE;
+    const bool ln = p.row_rstd != nullptr, res = p.residual != nullptr;
+    if (p.geglu) return (ln && !res) ? HV_FORM_LN_GEGLU : HV_FORM_NONE;
+    if (p.Yt != nullptr) return (ln && !res) ? HV_FORM_LN_YT : HV_FORM_NONE;
+    if (ln) return res ? HV_FORM_NONE : HV_FORM_LN;  // LayerNorm fold + residual: not on the denoising path
+    return res ? HV_FORM_RES : HV_FORM_PLAIN;
+}
+
+template <int NMF>
+HV_DEV void hv_gemm_epilogue_form(int form, const HvGemmParams& p, f32x4 (&acc)[4][NMF], int m_base, int n_base, int r16,
+                                  int quad HV_TRACE_PARAM) {
+#if !HV_GEMM_DEFER
+    hv_gemm_epilogue<NMF>(p, acc, m_base, n_base, r16, quad HV_TRACE_ARG);
+#else
+#ifndef HV_EMU
+    const int m_first = __builtin_amdgcn_readfirstlane(min(m_base, p.M - 1));  // wave-uniform: the table row is a scalar base
+#else
+    const int m_first = min(m_base, p.M - 1);
+#endif
+    const float* tab = nullptr;
+    if (p.pe != nullptr) tab = p.pe + (long)((m_first / p.pe_period) % p.pe_frames) * p.N;
+    else if (p.rowvec != nullptr) tab = p.rowvec + (long)(m_first / p.rowvec_period) * p.N;
+    switch (form) {
+        case HV_FORM_LN: hv_gemm_epilogue_fast<NMF, true, false, 0>(p, acc, m_base, n_base, r16, quad, tab HV_TRACE_ARG); break;
+        case HV_FORM_LN_YT: hv_gemm_epilogue_fast<NMF, true, false, 1>(p, acc, m_base, n_base, r16, quad, tab HV_TRACE_ARG); break;
+        case HV_FORM_LN_GEGLU: hv_gemm_epilogue_fast<NMF, true, false, 2>(p, acc, m_base, n_base, r16, quad, tab HV_TRACE_ARG); break;
+        case HV_FORM_RES: hv_gemm_epilogue_fast<NMF, false, true, 0>(p, acc, m_base, n_base, r16, quad, tab HV_TRACE_ARG); break;
+        default: hv_gemm_epilogue_fast<NMF, false, false, 0>(p, acc, m_base, n_base, r16, quad, tab HV_TRACE_ARG); break;
+    }
+#endif
+}
+
+template <int Q>
+HV_DEV unsigned& hv_pick4(unsigned& a, unsigned& b, unsigned& c, unsigned& d) {
+    if constexpr (Q == 0) return a;
+    else if constexpr (Q == 1) return b;
+    else if constexpr (Q == 2) return c;
+    else return d;
 }
 
 template <int N>
@@ -385,7 +599,7 @@ __global__ __launch_bounds__(256, 2) void hv_gemm_kernel(HvGemmParams p) {
 //       ds_read, LDS-DMA-issue and epilogue times simply add up);
 //   NW = 8: 4 x 2 waves of 64x64 (BN = 128) or 2 x 4 of 128x64 (BN = 256), one workgroup per CU.
 template <int BK, int NS, int BN, int NW, int BM = 256>
-__global__ __launch_bounds__(NW * 64, 2) void hv_gemm_glds_kernel(HvGemmParams p, int gm) {
+__global__ __launch_bounds__(NW * 64, 2) void hv_gemm_glds_kernel(HvGemmParams p, int gm, int form) {
     constexpr int WAVES_N = BN / 64, WAVES_M = NW / WAVES_N;
     constexpr int WTM = BM / WAVES_M, NMF = WTM / 16;
     constexpr int XT = BM * BK * 2, WT = BN * BK * 2, SLOT = XT + WT;
@@ -397,7 +611,12 @@ __global__ __launch_bounds__(NW * 64, 2) void hv_gemm_glds_kernel(HvGemmParams p
     __shared__ __attribute__((aligned(16))) unsigned char smem[NS * SLOT];
 
     const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
+    const int lane = tid & 63;
+#ifndef HV_EMU
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: the LDS-DMA destinations are wave-uniform
+#else
+    const int wave = tid >> 6;
+#endif
     const int wm = wave % WAVES_M, wn = wave / WAVES_M;
     const int r16 = lane & 15, quad = lane >> 4;
 
@@ -431,41 +650,71 @@ __global__ __launch_bounds__(NW * 64, 2) void hv_gemm_glds_kernel(HvGemmParams p
     const int nk = p.K / BK;
     const int nsteps = my_tiles * nk;
 
-    // LDS-DMA issue state, advanced one k-tile per call (no divisions in the loop): tile origin, k index,
-    // ring slot.  The row -> bank-row swizzle only depends on (row / RPB) % CPR: a lane's chunk column is
-    // the same for every wave-instruction when these start at multiples of 16 rows (BK = 32).
+    // LDS-DMA issue state, advanced one k-tile per call.  Round 1 recomputed every source address in every k-step
+    // (row clamp, 64-bit row * stride product, the two-source test on reloaded kernel arguments): ~150 scalar and
+    // vector instructions and four dependent s_load round trips around six DMA instructions -- most of the "830-1100
+    // cycles of LDS-DMA issue" in the gemm_trace timeline.  Now the per-lane source address of each of the wave's DMA
+    // instructions is computed once per tile (xa / wa) and advanced by BK elements per k-step; the k-loop needs no
+    // kernel argument besides them.  The row -> bank-row swizzle only depends on (row / RPB) % CPR: a lane's chunk
+    // column is the same for every wave-instruction when these start at multiples of 16 rows (BK = 32).
     const int sub = lane / CPR;
     auto chunk_ofs = [&](int j) __attribute__((always_inline)) {
         const int row = (RPI % 16 == 0) ? sub : RPI * j + sub;
         return ((lane % CPR) ^ ((row / RPB) % CPR)) * 8;
     };
+    const int k1_steps = p.X2 != nullptr ? p.K1 / BK : -1;  // k-tile at which the second source takes over
     int i_tile = first, i_k = 0, i_slot = 0;
     int i_m0, i_n0;
-    tile_origin(first, i_m0, i_n0);
-    auto issue = [&]() __attribute__((always_inline)) {
-        const int k0 = i_k * BK;
-        unsigned char* slot = smem + i_slot * SLOT;
-        const bool second = p.X2 != nullptr && k0 >= p.K1;
-        const bf16_t* xb = second ? p.X2 + (k0 - p.K1) : p.X + k0;
-        const long ldx = second ? p.ldx2 : p.ldx;
-        const bf16_t* wb = p.W + k0;
-#pragma unroll
-        for (int q = 0; q < XQ; ++q) {
+    // 32-bit byte offsets from a wave-uniform base (hv_gemm_launch checks that the operands span < 4 GiB): half the
+    // registers of full pointers, and the DMA instruction takes the base from an SGPR pair
+    static_assert(XQ <= 4 && WQ <= 4, "at most four DMA instructions per operand, wave and k-tile");
+    unsigned xo0 = 0, xo1 = 0, xo2 = 0, xo3 = 0, wo0 = 0, wo1 = 0, wo2 = 0, wo3 = 0;  // named scalars: see the note on set_x
+    const char* xbase = reinterpret_cast<const char*>(p.X);
+    const char* const wbase = reinterpret_cast<const char*>(p.W);
+    // (named scalars picked by a compile-time index: as arrays -- "#pragma unroll" or compile-time loops alike -- hipcc
+    //  kept the offsets of the NS = 2 instantiations in a stack slot: a scratch reload behind vmcnt(0) in every k-step)
+    auto set_x = [&](const bf16_t* base, long ld) __attribute__((always_inline)) {
+        xbase = reinterpret_cast<const char*>(base);
+        hv_static_for<XQ>([&](auto Q) __attribute__((always_inline)) {
+            constexpr int q = decltype(Q)::value;
             const int j = wave + NW * q;
             const int m = min(((HV_GEMM_DBG & 16) ? 0 : i_m0) + RPI * j + sub, p.M - 1);
-            hv_glds16(xb + (long)m * ldx + chunk_ofs(j), slot + j * 1024);
-        }
-#pragma unroll
-        for (int q = 0; q < WQ; ++q) {
+            hv_pick4<q>(xo0, xo1, xo2, xo3) = ((unsigned)m * (unsigned)ld + (unsigned)chunk_ofs(j)) * 2u;  // < 4 GiB: exact in 32 bits
+        });
+    };
+    auto set_tile = [&]() __attribute__((always_inline)) {
+        tile_origin(i_tile, i_m0, i_n0);
+        if (k1_steps == 0) set_x(p.X2, p.ldx2);
+        else set_x(p.X, p.ldx);
+        hv_static_for<WQ>([&](auto Q) __attribute__((always_inline)) {
+            constexpr int q = decltype(Q)::value;
             const int j = wave + NW * q;
             const int n = min(i_n0 + RPI * j + sub, p.N - 1);
-            hv_glds16(wb + (long)n * p.K + chunk_ofs(j), slot + XT + j * 1024);
-        }
+            hv_pick4<q>(wo0, wo1, wo2, wo3) = ((unsigned)n * (unsigned)p.K + (unsigned)chunk_ofs(j)) * 2u;
+        });
+    };
+    set_tile();
+    auto issue = [&]() __attribute__((always_inline)) {
+        unsigned char* slot = smem + i_slot * SLOT;
+        hv_static_for<XQ>([&](auto Q) __attribute__((always_inline)) {
+            constexpr int q = decltype(Q)::value;
+            unsigned& o = hv_pick4<q>(xo0, xo1, xo2, xo3);
+            hv_glds16(xbase + o, slot + (wave + NW * q) * 1024);
+            o += BK * 2;
+        });
+        hv_static_for<WQ>([&](auto Q) __attribute__((always_inline)) {
+            constexpr int q = decltype(Q)::value;
+            unsigned& o = hv_pick4<q>(wo0, wo1, wo2, wo3);
+            hv_glds16(wbase + o, slot + XT + (wave + NW * q) * 1024);
+            o += BK * 2;
+        });
         if (++i_slot == NS) i_slot = 0;
         if (++i_k == nk) {
             i_k = 0;
             i_tile += wg_per_xcd;
-            tile_origin(i_tile, i_m0, i_n0);
+            set_tile();
+        } else if (i_k == k1_steps) {
+            set_x(p.X2, p.ldx2);
         }
     };
 
@@ -485,11 +734,18 @@ __global__ __launch_bounds__(NW * 64, 2) void hv_gemm_glds_kernel(HvGemmParams p
     for (int a = 0; a < AHEAD; ++a)
         if (a < nsteps) issue();
     int c_tile = first, c_k = 0, c_slot = 0;  // consumer state
+    int landed = 0;  // k-steps that need no vmcnt wait (see below)
     for (int s = 0; s < nsteps; ++s) {
         HV_TRACE(1);
         // this wave's share of k-tile s has landed (up to AHEAD-1 later k-tiles may stay in flight) ...
+        // (vmcnt counts stores too, in order: right after an epilogue the youngest outstanding operations are the tile's
+        //  stores, and a counted wait would drain them.  The fast epilogue waits for every load and DMA before its first
+        //  store -- k-tiles s .. s+AHEAD-1 have landed -- so the next AHEAD k-steps need no wait at all and the stores
+        //  drain under them.)
         const int later = nsteps - 1 - s;
-        if (later >= AHEAD - 1)
+        if (HV_GEMM_DEFER && landed > 0)
+            --landed;
+        else if (later >= AHEAD - 1)
             hv_vm_wait<(AHEAD - 1) * LPW>();
         else if (AHEAD > 2 && later == 1)
             hv_vm_wait<LPW>();
@@ -528,7 +784,8 @@ __global__ __launch_bounds__(NW * 64, 2) void hv_gemm_glds_kernel(HvGemmParams p
             {
                 int m0, n0;
                 tile_origin(c_tile, m0, n0);
-                hv_gemm_epilogue<NMF>(p, acc, m0 + WTM * wm, n0 + 64 * wn, r16, quad HV_TRACE_ARG);
+                hv_gemm_epilogue_form<NMF>(form, p, acc, m0 + WTM * wm, n0 + 64 * wn, r16, quad HV_TRACE_ARG);
+                landed = AHEAD;
             }
             c_tile += wg_per_xcd;
             clear_acc();
@@ -555,7 +812,14 @@ static inline int hv_gemm_launch(const HvGemmParams& p, hipStream_t stream) {
     if (g_hv_prof)
         snprintf(shape, sizeof(shape), "M=%d N=%d K=%d geglu=%d res=%d yt=%d f32=%d x2=%d", p.M, p.N, p.K, p.geglu,
                  p.residual != nullptr, p.Yt != nullptr ? p.N - p.n_split : 0, p.out_f32, p.X2 != nullptr);
-    if (g_hv_gemm_glds && !prologue && p.M >= 256) {
+    // the LDS-DMA kernel addresses its operands with 32-bit byte offsets and only knows the hot epilogue forms
+    const long lim = 1L << 32;
+    const bool span_ok = (long)p.M * p.ldx * 2 < lim && (long)p.N * p.K * 2 < lim && (long)p.M * p.ldy * 2 < lim &&
+                         (p.X2 == nullptr || (long)p.M * p.ldx2 * 2 < lim) &&
+                         (p.residual == nullptr || (long)p.M * p.ldr * 2 < lim) &&
+                         (p.Yt == nullptr || (long)(p.N - p.n_split) * p.ldyt * 2 < lim);
+    const int form128 = hv_gemm_fast_form(p, 128), form64 = hv_gemm_fast_form(p, 64);  // 128 / 64 rows per wave sub-tile
+    if (g_hv_gemm_glds && !prologue && p.M >= 256 && span_ok && form64 != HV_FORM_NONE) {
         const int tm = (p.M + 255) / 256;
         // 256x256 tiles (one 128 KiB workgroup per CU, a third fewer bytes per FLOP through the
         // per-CU load path) when N fills them about as well as 256x128 tiles would
@@ -565,35 +829,36 @@ static inline int hv_gemm_launch(const HvGemmParams& p, hipStream_t stream) {
         // row (twice the LDS-DMA fill rate of 64-byte segments) and 2/3 of the operand bytes per FLOP of the 256x128 tile.
         // The kernel is bound by the CU's L2 -> LDS fill path (~27-60 B/clk measured: round-2 attention trace, round-1
         // fillbw probe), so for wide N this is the shape that gets closest to the MFMA bound.
-        if ((g_hv_gemm_glds == 7 || g_hv_gemm_glds == 8) && p.N >= 960 && (n256 - p.N) * 8 <= p.N &&
+        const bool ok128 = form128 != HV_FORM_NONE;  // a per-row table may fit 64-row but not 128-row wave sub-tiles
+        if (ok128 && (g_hv_gemm_glds == 7 || g_hv_gemm_glds == 8) && p.N >= 960 && (n256 - p.N) * 8 <= p.N &&
             (g_hv_gemm_glds == 7 || p.K >= 640)) {
             const int tiles = tm * (n256 / 256);
             int grid = ((tiles + 7) / 8) * 8;
             if (grid > 256) grid = 256;
             if (grid > g_hv_gemm_max_grid) grid = g_hv_gemm_max_grid;
             hv_note("hv_gemm_glds_kernel<64,2,256,8,256> | %s", shape);
-            hv_launch(hv_gemm_glds_kernel<64, 2, 256, 8, 256>, dim3(grid), dim3(512), stream, p, gm);
+            hv_launch(hv_gemm_glds_kernel<64, 2, 256, 8, 256>, dim3(grid), dim3(512), stream, p, gm, form128);
             return 0;
         }
-        if (g_hv_gemm_glds == 3 && p.N >= 512 && (n256 - n128) * 12 <= p.N) {
+        if (ok128 && g_hv_gemm_glds == 3 && p.N >= 512 && (n256 - n128) * 12 <= p.N) {
             const int tiles = tm * (n256 / 256);
             int grid = ((tiles + 7) / 8) * 8;
             if (grid > 256) grid = 256;
             if (grid > g_hv_gemm_max_grid) grid = g_hv_gemm_max_grid;
             hv_note("hv_gemm_glds_kernel<32,4,256,8> | %s", shape);
-            hv_launch(hv_gemm_glds_kernel<32, 4, 256, 8>, dim3(grid), dim3(512), stream, p, gm);
+            hv_launch(hv_gemm_glds_kernel<32, 4, 256, 8>, dim3(grid), dim3(512), stream, p, gm, form128);
             return 0;
         }
         // 128x128x64 tiles (whole 128-byte lines per row: 1.8x the LDS-DMA rate of 64-byte row segments), 2-slot 64 KiB
         // ring, two workgroups per CU: measured 7-13 % faster than 256x128x32 when K >= 2 N (the FF output projections),
         // slower for wide outputs (half the operand reuse per tile)
-        if (g_hv_gemm_glds == 6 || ((g_hv_gemm_glds == 2 || g_hv_gemm_glds >= 7) && p.K >= 2 * p.N)) {
+        if (!ok128 || g_hv_gemm_glds == 6 || ((g_hv_gemm_glds == 2 || g_hv_gemm_glds >= 7) && p.K >= 2 * p.N)) {
             const int tiles6 = ((p.M + 127) / 128) * (n128 / 128);
             int grid6 = ((tiles6 + 7) / 8) * 8;
             if (grid6 > 512) grid6 = 512;
             if (grid6 > g_hv_gemm_max_grid) grid6 = g_hv_gemm_max_grid;
             hv_note("hv_gemm_glds_kernel<64,2,128,4,128> | %s", shape);
-            hv_launch(hv_gemm_glds_kernel<64, 2, 128, 4, 128>, dim3(grid6), dim3(256), stream, p, gm);
+            hv_launch(hv_gemm_glds_kernel<64, 2, 128, 4, 128>, dim3(grid6), dim3(256), stream, p, gm, form64);
             return 0;
         }
         const int tiles = tm * (n128 / 128);
@@ -602,16 +867,16 @@ static inline int hv_gemm_launch(const HvGemmParams& p, hipStream_t stream) {
             if (grid > 256) grid = 256;
             if (grid > g_hv_gemm_max_grid) grid = g_hv_gemm_max_grid;
             hv_note("hv_gemm_glds_kernel<64,3,128,8> | %s", shape);
-            hv_launch(hv_gemm_glds_kernel<64, 3, 128, 8>, dim3(grid), dim3(512), stream, p, gm);
+            hv_launch(hv_gemm_glds_kernel<64, 3, 128, 8>, dim3(grid), dim3(512), stream, p, gm, form64);
         } else {  // BK = 32, 72 KiB ring: two workgroups per CU whose epilogues interleave
             if (grid > 512) grid = 512;
             if (grid > g_hv_gemm_max_grid) grid = g_hv_gemm_max_grid;
             if (g_hv_gemm_glds == 4) {
                 hv_note("hv_gemm_glds_kernel<32,3,128,8> | %s", shape);
-                hv_launch(hv_gemm_glds_kernel<32, 3, 128, 8>, dim3(grid), dim3(512), stream, p, gm);
+                hv_launch(hv_gemm_glds_kernel<32, 3, 128, 8>, dim3(grid), dim3(512), stream, p, gm, form64);
             } else {
                 hv_note("hv_gemm_glds_kernel<32,3,128,4> | %s", shape);
-                hv_launch(hv_gemm_glds_kernel<32, 3, 128, 4>, dim3(grid), dim3(256), stream, p, gm);
+                hv_launch(hv_gemm_glds_kernel<32, 3, 128, 4>, dim3(grid), dim3(256), stream, p, gm, form128);
             }
         }
         return 0;

@@ -146,6 +146,75 @@ def case_gemm_lnfold(cx: Ctx, B=2, Fr=3, P=20, C=320, N=192, seed=2):
     return e
 
 
+def case_gemm_forms(cx: Ctx, M=520, C=128, N=192, P=128, form="ln", seed=30):
+    """The epilogue forms of the denoising path as the engine launches them (hv_gemm_epilogue_fast on the LDS-DMA kernel
+    when M >= 256 and the per-row table period P is a multiple of the wave sub-tile):
+      ln        LayerNorm fold + bias + positional-encoding row (motion-module QKV)
+      ln_yt     LayerNorm fold + bias, last third stored transposed (spatial QKV, V^T tail)
+      ln_geglu  LayerNorm fold + bias + GEGLU, no residual (feed-forward input projection)
+      res       bias + per-batch row vector + residual, in place (attention / feed-forward output projections)
+      plain     bias only"""
+    g = torch.Generator().manual_seed(seed)
+    x = rnd(g, M, C) + 0.25
+    xr = r(x)
+    xd = cx.bf(x)
+    gamma, beta = 1 + 0.2 * rnd(g, C), 0.1 * rnd(g, C)
+    if form in ("ln", "ln_yt", "ln_geglu"):
+        n_w = 2 * N if form == "ln_geglu" else N
+        w, bias = rnd(g, n_w, C, scale=C**-0.5), rnd(g, n_w, scale=0.1)
+        ln = F.layer_norm(xr, (C,), gamma, beta, 1e-5)
+        wf, colsum, bfold = packing.fold_layernorm(w, bias, gamma, beta)
+        mean, rstd = torch.zeros(M, device=cx.device), torch.zeros(M, device=cx.device)
+        ops.layernorm_stats(cx.lib, cx.stream, xd, mean, rstd)
+        kw = dict(row_mean=mean, row_rstd=rstd)
+        if form == "ln":
+            Fr = 3
+            pe = rnd(g, Fr, C, scale=0.5)
+            frame = (torch.arange(M) // P) % Fr
+            ref = (ln + pe[frame]) @ w.t() + bias
+            y = torch.zeros(M, N, dtype=BF16, device=cx.device)
+            ops.gemm(cx.lib, cx.stream, xd, cx.dev(wf), y, bias=cx.dev(bfold), colsum=cx.dev(colsum),
+                     pe=cx.dev(packing.pe_table(pe, w)), pe_period=P, pe_frames=Fr, **kw)
+            cx.sync()
+            e = nrmse(y, ref)
+        elif form == "ln_yt":
+            ref = ln @ w.t() + bias
+            ns = (2 * N // 3) // 64 * 64
+            y = torch.zeros(M, ns, dtype=BF16, device=cx.device)
+            yt = torch.zeros(N - ns, M, dtype=BF16, device=cx.device)
+            ops.gemm(cx.lib, cx.stream, xd, cx.dev(wf), y, bias=cx.dev(bfold), colsum=cx.dev(colsum), yt=yt, n_split=ns, **kw)
+            cx.sync()
+            e = max(nrmse(y, ref[:, :ns]), nrmse(yt.t(), ref[:, ns:]))
+        else:
+            h, gate = (ln @ w.t() + bias).chunk(2, dim=-1)
+            ref = h * F.gelu(gate)
+            order = packing.geglu_row_order(n_w, wf.device)
+            y = torch.zeros(M, N, dtype=BF16, device=cx.device)
+            ops.gemm(cx.lib, cx.stream, xd, cx.dev(wf[order].contiguous()), y, bias=cx.dev(bfold[order].contiguous()),
+                     colsum=cx.dev(colsum[order].contiguous()), geglu=True, **kw)
+            cx.sync()
+            e = nrmse(y, ref)
+        tol = 6e-3  # folded weights are rounded once more than the reference's
+    else:
+        w, bias = rnd(g, N, C, scale=C**-0.5), rnd(g, N, scale=0.1)
+        ref = xr @ r(w).t() + bias
+        y = torch.zeros(M, N, dtype=BF16, device=cx.device)
+        if form == "res":
+            nb = (M + P - 1) // P
+            rv = rnd(g, nb, N, scale=0.3)
+            res = rnd(g, M, N)
+            ref = ref + rv[torch.arange(M) // P] + r(res)
+            y.copy_(cx.bf(res))  # the residual stream is updated in place
+            ops.gemm(cx.lib, cx.stream, xd, cx.bf(w), y, bias=cx.dev(bias), rowvec=cx.dev(rv), rowvec_period=P, residual=y)
+        else:
+            ops.gemm(cx.lib, cx.stream, xd, cx.bf(w), y, bias=cx.dev(bias))
+        cx.sync()
+        e = nrmse(y, ref)
+        tol = TOL
+    assert e < tol, f"gemm form {form} nrmse {e}"
+    return e
+
+
 def case_gemm_geglu(cx: Ctx, M=70, C=64, seed=3):
     g = torch.Generator().manual_seed(seed)
     x = rnd(g, M, C)

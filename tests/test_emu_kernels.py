@@ -64,6 +64,25 @@ def test_gemm_lds_dma_kernel_variants(cx):
             cx.lib.call("hv_set_tuning", 3, 2)
 
 
+def test_gemm_fast_epilogue_forms(cx):
+    """every output form of hv_gemm_epilogue_fast, on each LDS-DMA tile shape (ragged M and N edges, several tiles per
+    persistent workgroup), plus the table periods that must fall back to the general epilogue"""
+    for form in ("ln", "ln_yt", "ln_geglu", "res", "plain"):
+        kc.case_gemm_forms(cx, M=520, C=128, N=192, P=128, form=form)
+    kc.case_gemm_forms(cx, M=300, C=64, N=132, P=256, form="res", seed=31)     # ragged N (132 = 128 + 4)
+    kc.case_gemm_forms(cx, M=300, C=64, N=96, P=100, form="res", seed=32)      # period not a multiple of 64: general path
+    kc.case_gemm_forms(cx, M=300, C=64, N=96, P=64, form="ln", seed=33)        # fits 64-row but not 128-row wave tiles
+    cx.lib.call("hv_set_tuning", 2, 8)
+    try:
+        for variant in (2, 1, 4, 6):
+            cx.lib.call("hv_set_tuning", 3, variant)
+            for form in ("ln", "ln_yt", "ln_geglu", "res", "plain"):
+                kc.case_gemm_forms(cx, M=900, C=192, N=320, P=128, form=form, seed=34)
+    finally:
+        cx.lib.call("hv_set_tuning", 3, 2)
+        cx.lib.call("hv_set_tuning", 2, 512)
+
+
 def test_gemm_grouped_tile_raster(cx):
     """tile raster with gm m-blocks per n-step (default for N > 1024; forced here), ragged last group"""
     cx.lib.call("hv_set_tuning", 6, 2)

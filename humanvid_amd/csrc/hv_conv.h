@@ -180,9 +180,9 @@ __global__ __launch_bounds__(2 * NPIX) void hv_conv3x3_kernel(hv_conv3x3_params 
     int iw_chunk = 0, iw_tap = 0, iw_slot = 0;  // issue state: advanced one step per call
     auto issue_w = [&]() __attribute__((always_inline)) {
         unsigned char* slot = wsm + iw_slot * G::WTILE_BYTES;
-        const bf16_t* base = p.W + (long)iw_tap * Cin + iw_chunk * 32;  // wave-uniform
-        hv_glds16_s(base, wofs0, slot + wave_u * 1024);
-        if (WQ > 1) hv_glds16_s(base, wofs1, slot + (wave_u + NW) * 1024);
+        const unsigned step = (unsigned)(iw_tap * Cin + iw_chunk * 32) * 2u;  // wave-uniform part of the offset
+        hv_glds16_s(p.W, wofs0 + step, slot + wave_u * 1024);  // base = the kernel argument: always an SGPR pair
+        if (WQ > 1) hv_glds16_s(p.W, wofs1 + step, slot + (wave_u + NW) * 1024);
         if (++iw_slot == 3) iw_slot = 0;
         if (++iw_tap == 9) {
             iw_tap = 0;

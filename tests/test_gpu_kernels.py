@@ -35,6 +35,32 @@ def test_gemm_fused(cx):
     kc.case_gemm_geglu(cx, M=4096, C=320)
 
 
+def test_gemm_epilogue_forms(cx):
+    """the epilogue forms the engine launches (hv_gemm_epilogue_fast on the LDS-DMA kernel), every LDS-DMA tile shape"""
+    for form in ("ln", "ln_yt", "ln_geglu", "res", "plain"):
+        kc.case_gemm_forms(cx, M=3000, C=320, N=960, P=384, form=form)
+    kc.case_gemm_forms(cx, M=4608, C=1280, N=1280, P=96, form="res", seed=35)   # level 3: 96-token images, general epilogue
+    kc.case_gemm_forms(cx, M=4608, C=1280, N=3840, P=96, form="ln", seed=36)
+    for variant in (1, 4, 6, 7):
+        cx.lib.call("hv_set_tuning", 3, variant)
+        try:
+            for form in ("ln", "ln_yt", "ln_geglu", "res", "plain"):
+                kc.case_gemm_forms(cx, M=2100, C=640, N=1920, P=128, form=form, seed=37)
+        finally:
+            cx.lib.call("hv_set_tuning", 3, 2)
+
+
+def test_bench_shape_gemm_forms(cx):
+    M = 48 * 6144
+    kc.case_gemm_forms(cx, M=M, C=320, N=960, P=6144, form="ln_yt")        # level-0 spatial QKV
+    kc.case_gemm_forms(cx, M=M, C=320, N=960, P=6144, form="ln")           # level-0 motion-module QKV (PE row per frame)
+    kc.case_gemm_forms(cx, M=M, C=320, N=1280, P=6144, form="ln_geglu")    # level-0 feed-forward input projection
+    kc.case_gemm_forms(cx, M=M, C=320, N=320, P=24 * 6144, form="res")     # level-0 attention output projection (in place)
+    kc.case_gemm_forms(cx, M=M, C=1280, N=320, P=24 * 6144, form="res")    # level-0 feed-forward output projection
+    kc.case_gemm_forms(cx, M=48 * 1536, C=640, N=2560, P=1536, form="ln_geglu", seed=38)
+    kc.case_gemm_forms(cx, M=48 * 384, C=1280, N=1280, P=24 * 384, form="res", seed=39)
+
+
 @pytest.mark.parametrize("mode", [A.CONV_S1, A.CONV_S2, A.CONV_UP2])
 def test_conv(cx, mode):
     kc.case_conv(cx, n=4, H=48, W=32, C1=320, Cout=320, mode=mode)

@@ -47,6 +47,21 @@
 #ifndef HV_ATTN_LAZY
 #define HV_ATTN_LAZY 1
 #endif
+#ifndef HV_ATTN_DEFER
+// Softmax with fewer VALU instructions per score (round 2).  At d = 40 the softmax is the longest phase of a tile: per
+// score one max, one fused multiply-subtract, one v_exp_f32 (half rate) and half a packed convert -- ~750 VALU cycles per
+// 64-key tile against 448 MFMA cycles.  Here (a) the queries are pre-multiplied by scale * log2(e) once at load, (b) the
+// running reference maximum enters the QK^T MFMA as the accumulator's initial value (C = -m), so the MFMA delivers
+// s - m directly, and (c) the reference maximum is only raised when a query's tile maximum exceeds it by more than
+// HV_ATTN_THR (in log2 units; the probabilities are then bounded by 2^THR instead of 1, harmless in bf16 x fp32) -- the
+// common tile needs max + exp2 + convert per score and no multiply-subtract.  The rescale branch (wave-uniform) subtracts
+// the increase from the scores BEFORE they are exponentiated and scales O (and the denominator row) by 2^-increase, i.e.
+// everything still at the old reference is scaled exactly once.  0 = the round-1 softmax, for A/Bs.
+#define HV_ATTN_DEFER 1
+#endif
+#ifndef HV_ATTN_THR
+#define HV_ATTN_THR 8.0f
+#endif
 
 // Head-dim remainder of the QK^T reduction (d = 40: 8 channels, d = 80: 16).  Round 1 fed it through a 16-deep
 // mfma_f32_16x16x16_bf16 appended to the chain of 32-deep MFMAs on the same accumulator.  That mix is unsafe on gfx950
@@ -142,6 +157,13 @@ __global__ __launch_bounds__(256, (HvAttnOcc<D, QT>::value)) void hv_attention_k
         for (int s = 0; s < NFULL; ++s) {
             u32x4 v = {0u, 0u, 0u, 0u};
             if (q < p.Lq && 32 * s + 8 * quad + 8 <= D) v = hv_ld16(qrow + 32 * s + 8 * quad);
+            if (HV_ATTN_DEFER) {  // scores come out of the MFMA in the exp2 domain
+                float f[8];
+                hv_unpack8(v, f);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) f[e] *= p.scale * 1.44269504089f;
+                v = hv_pack8(f);
+            }
             qf[qt][s] = hv_as_bf16x8(v);
         }
         if (G::TAIL) {
@@ -210,7 +232,7 @@ __global__ __launch_bounds__(256, (HvAttnOcc<D, QT>::value)) void hv_attention_k
     float mrun[QT], lrun[QT];
 #pragma unroll
     for (int qt = 0; qt < QT; ++qt) {
-        mrun[qt] = -INFINITY;
+        mrun[qt] = HV_ATTN_DEFER ? 0.f : -INFINITY;
         lrun[qt] = 0.f;
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) oacc[qt][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -240,7 +262,10 @@ __global__ __launch_bounds__(256, (HvAttnOcc<D, QT>::value)) void hv_attention_k
 #pragma unroll
         for (int kvf = 0; kvf < 4; ++kvf) {
 #pragma unroll
-            for (int qt = 0; qt < QT; ++qt) sacc[kvf][qt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int qt = 0; qt < QT; ++qt) {
+                const float ci = HV_ATTN_DEFER ? -mrun[qt] : 0.f;  // lane = one query: its reference maximum, negated
+                sacc[kvf][qt] = f32x4{ci, ci, ci, ci};
+            }
 #pragma unroll
             for (int s = 0; s < NFULL; ++s) {
                 const bf16x8 kf = hv_as_bf16x8(hv_ld16(kb + (16 * kvf) * G::KRS + s * 64 + quad * 16));
@@ -289,6 +314,34 @@ __global__ __launch_bounds__(256, (HvAttnOcc<D, QT>::value)) void hv_attention_k
                            sacc[kvf][qt][3]);
             mx = fmaxf(mx, __shfl_xor(mx, 16));
             mx = fmaxf(mx, __shfl_xor(mx, 32));
+#if HV_ATTN_DEFER
+            static_assert(!G::TAIL, "HV_ATTN_DEFER needs HV_ATTN_PAD32 (pre-scaled queries have no 16-deep tail fragment)");
+            float pv[4][4];
+            {
+                const bool first = ti == 0;  // the first tile fixes the reference maximum (it starts at 0, not at a score)
+                if (first || __any(mx > HV_ATTN_THR)) {
+                    const float inc = first ? mx : fmaxf(mx, 0.f);
+#pragma unroll
+                    for (int kvf = 0; kvf < 4; ++kvf) sacc[kvf][qt] -= inc;
+                    if (!first) {
+                        const float alpha = __builtin_amdgcn_exp2f(-inc);
+                        if (!G::ONES) lrun[qt] *= alpha;
+#pragma unroll
+                        for (int dt = 0; dt < DT; ++dt) oacc[qt][dt] *= alpha;
+                    }
+                    mrun[qt] += inc;
+                }
+                float psum = 0.f;
+#pragma unroll
+                for (int kvf = 0; kvf < 4; ++kvf)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        pv[kvf][r] = __builtin_amdgcn_exp2f(sacc[kvf][qt][r]);
+                        if (!G::ONES) psum += pv[kvf][r];
+                    }
+                if (!G::ONES) lrun[qt] += psum;
+            }
+#else
             const float mold = mrun[qt];
             const float mnew = fmaxf(mold, mx * c2);
             mrun[qt] = mnew;
@@ -308,6 +361,7 @@ __global__ __launch_bounds__(256, (HvAttnOcc<D, QT>::value)) void hv_attention_k
                 for (int dt = 0; dt < DT; ++dt) oacc[qt][dt] *= alpha;
             }
             if (!G::ONES) lrun[qt] += psum;
+#endif
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
                 u32x4 w = {hv_pack2(pv[2 * ks][0], pv[2 * ks][1]), hv_pack2(pv[2 * ks][2], pv[2 * ks][3]),

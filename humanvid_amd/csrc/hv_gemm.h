@@ -796,7 +796,15 @@ __global__ __launch_bounds__(NW * 64, 2) void hv_gemm_glds_kernel(HvGemmParams p
 
 static int g_hv_gemm_max_grid = 512;  // tuning knob (hv_set_tuning): persistent workgroups
 static int g_hv_gemm_raster = 0;        // tuning knob: m-blocks per raster group (0 = auto: 8 when N spans more than 8 tiles)
-static int g_hv_gemm_glds = 2;         // tuning knob: 2 = LDS-DMA BK=32 (2 workgroups/CU), 1 = BK=64, 0 = register-staged
+// tuning knob (hv_set_tuning key 3) -- tile policy of the LDS-DMA kernel:
+//   9 (default, round 2): BK = 64 everywhere (whole 128-byte lines per operand row: the kernel is bound by the CU's
+//     L2 -> LDS fill path, which moves 64-byte row segments at half the rate) -- 256x256x64 (one 8-wave workgroup per CU)
+//     when N >= 960, 128x128x64 (two 4-wave workgroups per CU) otherwise.  Same-box sweep after the round-2 epilogue
+//     (gpurun_out/gm_*.txt -> profiles/r02_gemm_tile_modes.txt): level-0 QKV 0.435 -> 0.373 ms, level-2 ff1 0.558 -> 0.480,
+//     level-0 out-projection 0.216 -> 0.193 against policy 2
+//   2: round-1 policy (256x128x32 two workgroups per CU; 128x128x64 when K >= 2N)
+//   1 / 3 / 4 / 6 / 7 / 8: force one instantiation (A/Bs); 0 = register-staged kernel
+static int g_hv_gemm_glds = 9;
 
 static inline int hv_gemm_launch(const HvGemmParams& p, hipStream_t stream) {
     if (p.M <= 0 || p.N <= 0 || p.K <= 0) return -1;
@@ -830,8 +838,8 @@ static inline int hv_gemm_launch(const HvGemmParams& p, hipStream_t stream) {
         // The kernel is bound by the CU's L2 -> LDS fill path (~27-60 B/clk measured: round-2 attention trace, round-1
         // fillbw probe), so for wide N this is the shape that gets closest to the MFMA bound.
         const bool ok128 = form128 != HV_FORM_NONE;  // a per-row table may fit 64-row but not 128-row wave sub-tiles
-        if (ok128 && (g_hv_gemm_glds == 7 || g_hv_gemm_glds == 8) && p.N >= 960 && (n256 - p.N) * 8 <= p.N &&
-            (g_hv_gemm_glds == 7 || p.K >= 640)) {
+        if (ok128 && (g_hv_gemm_glds >= 7) && p.N >= 960 && (n256 - p.N) * 8 <= p.N &&
+            (g_hv_gemm_glds != 8 || p.K >= 640)) {
             const int tiles = tm * (n256 / 256);
             int grid = ((tiles + 7) / 8) * 8;
             if (grid > 256) grid = 256;
@@ -852,7 +860,7 @@ static inline int hv_gemm_launch(const HvGemmParams& p, hipStream_t stream) {
         // 128x128x64 tiles (whole 128-byte lines per row: 1.8x the LDS-DMA rate of 64-byte row segments), 2-slot 64 KiB
         // ring, two workgroups per CU: measured 7-13 % faster than 256x128x32 when K >= 2 N (the FF output projections),
         // slower for wide outputs (half the operand reuse per tile)
-        if (!ok128 || g_hv_gemm_glds == 6 || ((g_hv_gemm_glds == 2 || g_hv_gemm_glds >= 7) && p.K >= 2 * p.N)) {
+        if (!ok128 || g_hv_gemm_glds == 6 || g_hv_gemm_glds == 9 || ((g_hv_gemm_glds == 2 || g_hv_gemm_glds >= 7) && p.K >= 2 * p.N)) {
             const int tiles6 = ((p.M + 127) / 128) * (n128 / 128);
             int grid6 = ((tiles6 + 7) / 8) * 8;
             if (grid6 > 512) grid6 = 512;

@@ -293,14 +293,22 @@ def case_groupnorm(cx: Ctx, n=3, H=6, W=10, C1=320, C2=0, groups=32, seed=5, off
 
 
 # ----------------------------------------------------------------------------------------- attention
-def case_attention(cx: Ctx, D=40, n_img=4, Lq=72, Lb=40, seed=6, check=None, q_stride=1, row_major=False):
+def case_attention(cx: Ctx, D=40, n_img=4, Lq=72, Lb=40, seed=6, check=None, q_stride=1, row_major=False, spike=False):
     """images [0, n/2) are CFG-unconditional (own keys only); the rest append bank batch 1.
-    check / q_stride: images and query rows the CPU reference is evaluated on (the kernel runs everything)."""
+    check / q_stride: images and query rows the CPU reference is evaluated on (the kernel runs everything).
+    spike: keys in LATER tiles (own key 70+, bank key 3) are made strongly aligned with a few queries, so that those
+    queries' running maximum jumps far past the deferred-rescale threshold in the middle of the key loop (the branch
+    random data never takes: cdna_hip_programming.md rule 26)."""
     g = torch.Generator().manual_seed(seed)
     H = 8
     Cc = H * D
     q, k, v = rnd(g, n_img, Lq, Cc), rnd(g, n_img, Lq, Cc), rnd(g, n_img, Lq, Cc)
     kb, vb = rnd(g, 2, Lb, Cc), rnd(g, 2, Lb, Cc)
+    if spike:
+        for i in range(n_img):
+            for j, ks in enumerate(range(min(Lq - 1, 70), Lq, 97)):
+                k[i, ks] = (3.0 + j % 3) * q[i, (5 + 11 * j) % Lq]
+        kb[1, min(3, Lb - 1)] = 4.0 * q[n_img - 1, 9 % Lq]
     sel = torch.tensor([-1] * (n_img // 2) + [1] * (n_img - n_img // 2), dtype=torch.int32)
 
     def heads(t):

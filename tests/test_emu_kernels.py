@@ -53,7 +53,7 @@ def test_gemm_lds_dma_kernel_variants(cx):
     kc.case_gemm(cx, M=260, N=64, K=64, seed=24, residual=False, out_f32=True)
     kc.case_gemm_lnfold(cx, B=2, Fr=3, P=50, C=128, N=192, seed=25)
     kc.case_gemm_geglu(cx, M=257, C=64, seed=26)
-    for variant in (0, 1, 4, 6):  # register-staged kernel; the ring-buffer LDS-DMA variants (BK=64, 4-wave and 8-wave BK=32)
+    for variant in (0, 1, 2, 4, 6):  # register-staged kernel; the ring-buffer LDS-DMA variants (BK=64, 4-wave and 8-wave BK=32)
         cx.lib.call("hv_set_tuning", 3, variant)
         try:
             kc.case_gemm(cx, M=300, N=132, K=128, seed=21, residual=True)
@@ -61,7 +61,7 @@ def test_gemm_lds_dma_kernel_variants(cx):
             kc.case_gemm_geglu(cx, M=257, C=64, seed=26)
             kc.case_gemm_lnfold(cx, B=2, Fr=3, P=50, C=128, N=192, seed=25)
         finally:
-            cx.lib.call("hv_set_tuning", 3, 2)
+            cx.lib.call("hv_set_tuning", 3, 9)
 
 
 def test_gemm_fast_epilogue_forms(cx):
@@ -74,12 +74,12 @@ def test_gemm_fast_epilogue_forms(cx):
     kc.case_gemm_forms(cx, M=300, C=64, N=96, P=64, form="ln", seed=33)        # fits 64-row but not 128-row wave tiles
     cx.lib.call("hv_set_tuning", 2, 8)
     try:
-        for variant in (2, 1, 4, 6):
+        for variant in (9, 2, 1, 4, 6):
             cx.lib.call("hv_set_tuning", 3, variant)
             for form in ("ln", "ln_yt", "ln_geglu", "res", "plain"):
                 kc.case_gemm_forms(cx, M=900, C=192, N=320, P=128, form=form, seed=34)
     finally:
-        cx.lib.call("hv_set_tuning", 3, 2)
+        cx.lib.call("hv_set_tuning", 3, 9)
         cx.lib.call("hv_set_tuning", 2, 512)
 
 
@@ -111,7 +111,7 @@ def test_gemm_lds_dma_256x256_tiles(cx):
         kc.case_gemm(cx, M=1200, N=1024, K=96 + 32, seed=46)
     finally:
         cx.lib.call("hv_set_tuning", 2, 512)
-        cx.lib.call("hv_set_tuning", 3, 2)
+        cx.lib.call("hv_set_tuning", 3, 9)
 
 
 def test_gemm_prologue(cx):
@@ -183,6 +183,14 @@ def test_attention_row_major_kernel(cx, D):
     kc.case_attention(cx, D=D, n_img=2, Lq=64, Lb=96, row_major=True, seed=16)
     if D == 40:
         kc.case_attention(cx, D=D, n_img=3, Lq=136, Lb=8, row_major=True, seed=62)
+
+
+@pytest.mark.parametrize("D", [40, 80, 160])
+def test_attention_forced_rescale(cx, D):
+    """keys that make a query's running maximum jump in a later tile: the deferred-rescale branch of the softmax, masked
+    and unmasked instances, own-key and bank tiles"""
+    kc.case_attention(cx, D=D, n_img=2, Lq=200, Lb=72, spike=True, seed=71)
+    kc.case_attention(cx, D=D, n_img=2, Lq=192, Lb=64, spike=True, seed=72)
 
 
 def test_attention_unmasked_instances(cx):

@@ -41,13 +41,13 @@ def test_gemm_epilogue_forms(cx):
         kc.case_gemm_forms(cx, M=3000, C=320, N=960, P=384, form=form)
     kc.case_gemm_forms(cx, M=4608, C=1280, N=1280, P=96, form="res", seed=35)   # level 3: 96-token images, general epilogue
     kc.case_gemm_forms(cx, M=4608, C=1280, N=3840, P=96, form="ln", seed=36)
-    for variant in (1, 4, 6, 7):
+    for variant in (2, 1, 4, 6, 7):
         cx.lib.call("hv_set_tuning", 3, variant)
         try:
             for form in ("ln", "ln_yt", "ln_geglu", "res", "plain"):
                 kc.case_gemm_forms(cx, M=2100, C=640, N=1920, P=128, form=form, seed=37)
         finally:
-            cx.lib.call("hv_set_tuning", 3, 2)
+            cx.lib.call("hv_set_tuning", 3, 9)
 
 
 def test_bench_shape_gemm_forms(cx):
@@ -100,6 +100,12 @@ def test_attention_variants(cx):
     cx.lib.call("hv_set_tuning", 1, 1)
     kc.case_attention(cx, D=160, n_img=4, Lq=96, Lb=96)
     cx.lib.call("hv_set_tuning", 1, 2)
+
+
+@pytest.mark.parametrize("D,L", [(40, 1536), (80, 768), (160, 384)])
+def test_attention_forced_rescale(cx, D, L):
+    kc.case_attention(cx, D=D, n_img=4, Lq=L, Lb=L, spike=True, seed=73, check=(0, 3), q_stride=4)
+    kc.case_attention(cx, D=D, n_img=4, Lq=L + 40, Lb=L - 24, spike=True, seed=74, check=(1, 2), q_stride=4)
 
 
 @pytest.mark.parametrize("D,Fr,P", [(40, 24, 384), (80, 16, 96), (160, 24, 24), (40, 8, 64), (80, 32, 40), (40, 18, 50), (80, 24, 768),

@@ -77,7 +77,15 @@ def main():
                 xx = x if K == C else rnd(M, K)
                 y = torch.empty(M, Nn // 2 if geglu else Nn, dtype=BF16, device=dev)
                 bias = torch.zeros(Nn, device=dev)
-                ms = timeit(lambda: ops.gemm(L, st, xx, w, y, bias=bias, geglu=geglu))
+                # the epilogue forms of the engine: LayerNorm fold on the QKV / feed-forward input projections,
+                # in-place residual on the output projections
+                kw = {}
+                if name in ("qkv", "ff1_geglu"):
+                    kw = dict(row_mean=torch.zeros(M, device=dev), row_rstd=torch.ones(M, device=dev),
+                              colsum=torch.zeros(Nn, device=dev))
+                else:
+                    kw = dict(residual=y)
+                ms = timeit(lambda: ops.gemm(L, st, xx, w, y, bias=bias, geglu=geglu, **kw))
                 report(f"gemm {name} M={M} N={Nn} K={K}", ms, 2.0 * M * Nn * K, 2.0 * (M * K + Nn * K + y.numel()))
                 del w, y
         # fused-prologue / LN-fold variants at level 0

@@ -129,6 +129,15 @@ int hv_plucker_unshuffle(const float* K, const float* c2w, int F, int H, int W, 
     return hv_check_launch("hv_plucker_unshuffle");
 }
 
+int hv_affine_apply(const uint16_t* X, long ldx, int rows, int rows_per_image, int C, const float* scale, const float* shift,
+                    int act, uint16_t* Y, long ldy, void* stream) {
+    if (!X || !Y || !scale || !shift) return hv_fail(HV_EINVAL, "hv_affine_apply: null operand");
+    if (rows <= 0 || rows_per_image <= 0 || C <= 0 || C % 8 != 0 || ldx % 8 != 0 || ldy % 8 != 0)
+        return hv_fail(HV_EINVAL, "hv_affine_apply: need C % 8 == 0 and 16-byte aligned rows");
+    hvk_affine_apply(X, ldx, rows, rows_per_image, C, scale, shift, act, Y, ldy, (hipStream_t)stream);
+    return hv_check_launch("hv_affine_apply");
+}
+
 int hv_timestep_embedding(const float* t, int B, int dim, uint16_t* dst, void* stream) {
     if (!t || !dst || dim % 2) return hv_fail(HV_EINVAL, "hv_timestep_embedding: bad args");
     hvk_timestep(t, B, dim, dst, (hipStream_t)stream);

@@ -180,22 +180,40 @@ __global__ __launch_bounds__(256, (HvAttnOcc<D, QT>::value)) void hv_attention_k
     }
 
     u32x4 kreg[G::KIT], vreg[G::VIT];
+    // Per-lane parts of the K / V^T tile addresses, computed once (32-bit byte offsets from the wave-uniform tensor base:
+    // hv_attention_launch checks the spans); per tile only a scalar offset changes.  (Round 1 rebuilt every 64-bit address
+    // from scratch in every tile: ~60 of the ~290 instructions of a tile.)
+    unsigned koff[G::KIT], voff[G::VIT], koff2[G::KIT], voff2[G::VIT];
+#pragma unroll
+    for (int i = 0; i < G::KIT; ++i) {
+        const int id = tid + 256 * i;
+        const int r = id / (D / 8), c = id % (D / 8);
+        koff[i] = ((unsigned)r * (unsigned)p.ldk + (unsigned)c * 8u) * 2u;
+        koff2[i] = ((unsigned)r * (unsigned)p.ldk2 + (unsigned)c * 8u) * 2u;
+    }
+#pragma unroll
+    for (int i = 0; i < G::VIT; ++i) {
+        const int id = tid + 256 * i;
+        voff[i] = ((unsigned)(id >> 3) * (unsigned)p.ldvt + (unsigned)(id & 7) * 8u) * 2u;
+        voff2[i] = ((unsigned)(id >> 3) * (unsigned)p.ldvt2 + (unsigned)(id & 7) * 8u) * 2u;
+    }
     auto load_tile = [&](int ti) {
         const bool bank = ti >= T1;
         const int kv0 = (bank ? ti - T1 : ti) * 64;
         const int L = bank ? p.L2 : p.L1;
-        const long rowbase = bank ? (long)sel * p.L2 : (long)img * p.L1;
-        const bf16_t* Kp = bank ? p.K2 : p.K;
-        const long ldk = bank ? p.ldk2 : p.ldk;
-        const bf16_t* Vp = bank ? p.Vt2 : p.Vt;
-        const long ldv = bank ? p.ldvt2 : p.ldvt;
+        const unsigned rowbase = bank ? (unsigned)sel * (unsigned)p.L2 : (unsigned)img * (unsigned)p.L1;
+        const char* Kp = reinterpret_cast<const char*>(bank ? p.K2 : p.K);
+        const char* Vp = reinterpret_cast<const char*>(bank ? p.Vt2 : p.Vt);
+        // wave-uniform parts
+        const unsigned kb = ((rowbase + (unsigned)kv0) * (unsigned)(bank ? p.ldk2 : p.ldk) + (unsigned)(head * D)) * 2u;
+        const unsigned vb = ((unsigned)(head * D) * (unsigned)(bank ? p.ldvt2 : p.ldvt) + rowbase + (unsigned)kv0) * 2u;
 #pragma unroll
         for (int i = 0; i < G::KIT; ++i) {
             const int id = tid + 256 * i;
             u32x4 v = {0u, 0u, 0u, 0u};
             if (id < G::KCH) {
-                const int r = id / (D / 8), c = id % (D / 8);
-                if (!MASK || kv0 + r < L) v = hv_ld16(Kp + (rowbase + kv0 + r) * ldk + head * D + c * 8);
+                const int r = id / (D / 8);
+                if (!MASK || kv0 + r < L) v = hv_ld16(Kp + (kb + (bank ? koff2[i] : koff[i])));
             }
             kreg[i] = v;
         }
@@ -204,8 +222,8 @@ __global__ __launch_bounds__(256, (HvAttnOcc<D, QT>::value)) void hv_attention_k
             const int id = tid + 256 * i;
             u32x4 v = {0u, 0u, 0u, 0u};
             if (id < G::VCH) {
-                const int d = id >> 3, c = id & 7;
-                if (!MASK || kv0 + c * 8 < L) v = hv_ld16(Vp + (long)(head * D + d) * ldv + rowbase + kv0 + c * 8);
+                const int c = id & 7;
+                if (!MASK || kv0 + c * 8 < L) v = hv_ld16(Vp + (vb + (bank ? voff2[i] : voff[i])));
             }
             vreg[i] = v;
         }
@@ -318,11 +336,21 @@ __global__ __launch_bounds__(256, (HvAttnOcc<D, QT>::value)) void hv_attention_k
             static_assert(!G::TAIL, "HV_ATTN_DEFER needs HV_ATTN_PAD32 (pre-scaled queries have no 16-deep tail fragment)");
             float pv[4][4];
             {
+                // exponentials first, against the current reference: they do not depend on this tile's maximum unless the
+                // (rare) rescale branch fires, so the max reduction and its two cross-lane steps run beside them
+                // instead of in front of them
+                float psum = 0.f;
+#pragma unroll
+                for (int kvf = 0; kvf < 4; ++kvf)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) pv[kvf][r] = __builtin_amdgcn_exp2f(sacc[kvf][qt][r]);
                 const bool first = ti == 0;  // the first tile fixes the reference maximum (it starts at 0, not at a score)
                 if (first || __any(mx > HV_ATTN_THR)) {
                     const float inc = first ? mx : fmaxf(mx, 0.f);
 #pragma unroll
-                    for (int kvf = 0; kvf < 4; ++kvf) sacc[kvf][qt] -= inc;
+                    for (int kvf = 0; kvf < 4; ++kvf)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) pv[kvf][r] = __builtin_amdgcn_exp2f(sacc[kvf][qt][r] - inc);
                     if (!first) {
                         const float alpha = __builtin_amdgcn_exp2f(-inc);
                         if (!G::ONES) lrun[qt] *= alpha;
@@ -331,15 +359,13 @@ __global__ __launch_bounds__(256, (HvAttnOcc<D, QT>::value)) void hv_attention_k
                     }
                     mrun[qt] += inc;
                 }
-                float psum = 0.f;
+                if (!G::ONES) {
 #pragma unroll
-                for (int kvf = 0; kvf < 4; ++kvf)
+                    for (int kvf = 0; kvf < 4; ++kvf)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        pv[kvf][r] = __builtin_amdgcn_exp2f(sacc[kvf][qt][r]);
-                        if (!G::ONES) psum += pv[kvf][r];
-                    }
-                if (!G::ONES) lrun[qt] += psum;
+                        for (int r = 0; r < 4; ++r) psum += pv[kvf][r];
+                    lrun[qt] += psum;
+                }
             }
 #else
             const float mold = mrun[qt];
@@ -433,6 +459,12 @@ static inline int hv_attention_launch(const hv_attention_params& p, hipStream_t 
     if (p.L1 <= 0 || p.L1 % 8 != 0 || p.L2 % 8 != 0 || p.Lq <= 0) return -1;
     if (p.ldq % 8 || p.ldk % 8 || p.ldvt % 8 || p.ldo % 4) return -1;
     if (p.L2 > 0 && p.bank_sel != nullptr && (!p.K2 || !p.Vt2 || p.ldk2 % 8 || p.ldvt2 % 8)) return -1;
+    {  // 32-bit byte offsets inside the kernel
+        const long lim = 1L << 32, C = (long)p.heads * p.D;
+        if ((long)p.n_images * p.L1 * p.ldk * 2 >= lim || (C * p.ldvt + (long)p.n_images * p.L1) * 2 >= lim) return -1;
+        if (p.L2 > 0 && p.bank_sel != nullptr && (64L * p.L2 * p.ldk2 * 2 >= lim || (C * p.ldvt2 + 64L * p.L2) * 2 >= lim))
+            return -1;
+    }
     switch (p.D) {
         case 40:
             if (g_hv_attn_qt40 == 4) hv_attention_launch_t<40, 4>(p, stream);

@@ -216,3 +216,41 @@ static inline void hv_cfg_ddim_launch(float* latents, float* acc, float* counter
               H, W, coeffs);
     hv_launch(hv_clear_kernel, dim3((F + 255) / 256), dim3(256), s, counter, F);
 }
+
+// y[(img row)][c] = act(x * scale[img][c] + shift[img][c]) -- GroupNorm apply as its own pass (bf16 -> bf16).
+// Reference: the InflatedGroupNorm in front of Transformer3DModel.proj_in / TemporalTransformer3DModel.proj_in
+// (src/models/transformer_3d.py:125-131, src/models/motion_module.py:157-163).  Round 1 applied it as a prologue on the
+// GEMM's A operand, which forces the register-staged GEMM kernel (8.5 % MFMA-busy: unpack / fma / pack per 16-byte chunk
+// in front of every LDS store); as a separate HBM-bound pass it costs 4 bytes per element and the projection runs on the
+// LDS-DMA kernel.  One thread per 8 channels, rows grid-strided; scale / shift rows are L1/L2 hits.
+__global__ __launch_bounds__(256) void hv_affine_apply_kernel(const bf16_t* X, long ldx, int rows, int rows_per_image, int C,
+                                                              const float* scale, const float* shift, int act, bf16_t* Y,
+                                                              long ldy) {
+    const int cvs = C / 8;
+    const long total = (long)rows * cvs;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int cv = (int)(i % cvs);
+        const long row = i / cvs;
+        const long so = (row / rows_per_image) * C + cv * 8;
+        float f[8];
+        hv_unpack8(hv_ld16(X + row * ldx + cv * 8), f);
+        const f32x4 s0 = *reinterpret_cast<const f32x4*>(scale + so), s1 = *reinterpret_cast<const f32x4*>(scale + so + 4);
+        const f32x4 t0 = *reinterpret_cast<const f32x4*>(shift + so), t1 = *reinterpret_cast<const f32x4*>(shift + so + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            f[e] = hv_act(f[e] * s0[e] + t0[e], act);
+            f[4 + e] = hv_act(f[4 + e] * s1[e] + t1[e], act);
+        }
+        hv_st16(Y + row * ldy + cv * 8, hv_pack8(f));
+    }
+}
+
+static inline void hv_affine_apply_launch(const bf16_t* X, long ldx, int rows, int rows_per_image, int C, const float* scale,
+                                          const float* shift, int act, bf16_t* Y, long ldy, hipStream_t stream) {
+    const long total = (long)rows * (C / 8);
+    long blocks = (total + 255) / 256;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    hv_note("hv_affine_apply_kernel | rows=%d C=%d", rows, C);
+    hv_launch(hv_affine_apply_kernel, dim3((unsigned)blocks), dim3(256), stream, X, ldx, rows, rows_per_image, C, scale, shift, act,
+              Y, ldy);
+}

@@ -64,6 +64,7 @@ class UNet3DEngine:
         # (row-major V out of a plain [token][q|k|v] QKV GEMM, 32x32x16 MFMA, transposing LDS reads: 411 / 402 / 364 TF/s --
         # VALU- and DMA-issue-bound at d = 40, see profiles/README.md); HUMANVID_ATTENTION=2 selects it for same-box A/Bs
         self.attn_kernel = int(os.environ.get("HUMANVID_ATTENTION", "1"))
+        self.gn_prologue = os.environ.get("HUMANVID_GN_PROLOGUE", "0") == "1"  # round-1 fused GroupNorm-apply GEMM (A/B)
         self._sel_cache: Dict[tuple, torch.Tensor] = {}
         # optional observer `tap(name, activation [(b f),h,w,c])` called after every resnet / spatial transformer / motion
         # module, named by the reference's module path (e.g. 'down_blocks.0.attentions.1').  Buffers are reused and updated in place: the observer
@@ -355,6 +356,18 @@ class UNet3DEngine:
                         bias=w[prefix + ".conv2.bias"], residual=res)
             return out
 
+        def proj_in(x2d, sc, sh, N, wt, bias, hid):
+            """GroupNorm apply + proj_in.  Default: the normalisation as its own HBM-bound pass (hv_affine_apply) into a
+            scratch activation, then the projection on the LDS-DMA GEMM kernel; HUMANVID_GN_PROLOGUE=1 keeps the round-1
+            form (apply fused into the A-operand staging of the register-staged GEMM kernel) for A/Bs."""
+            Mr, Cc = x2d.shape
+            if self.gn_prologue:
+                ops.gemm(L, st, x2d, wt, hid, bias=bias, pro_scale=sc, pro_shift=sh, rows_per_image=N)
+                return
+            xn = ws.get(f"tr_n_{Mr}x{Cc}", (Mr, Cc))
+            ops.affine_apply(L, st, x2d, sc, sh, xn, rows_per_image=N)
+            ops.gemm(L, st, xn, wt, hid, bias=bias)
+
         def transformer(prefix, x):
             """Transformer3DModel.forward (transformer_3d.py:103-169) + patched block (read mode)."""
             _, h, ww, C = x.shape
@@ -364,8 +377,7 @@ class UNet3DEngine:
             x2d = x.view(M, C)
             sc, sh = gn_affine(x, prefix + ".norm", 1e-6)
             hid = ws.get(f"tr_h_{M}x{C}", (M, C))
-            ops.gemm(L, st, x2d, w[prefix + ".proj_in.w"], hid, bias=w[prefix + ".proj_in.bias"], pro_scale=sc,
-                     pro_shift=sh, rows_per_image=N)
+            proj_in(x2d, sc, sh, N, w[prefix + ".proj_in.w"], w[prefix + ".proj_in.bias"], hid)
             mean, rstd = ln_stats(hid)
             if self.kind == "reference":  # "write" mode: bank.append(norm_hidden_states.clone())
                 bank = ws.get("bank." + prefix, (M, C))
@@ -417,8 +429,7 @@ class UNet3DEngine:
             x2d = x.view(M, C)
             sc, sh = gn_affine(x, mm + ".norm", 1e-6)
             hid = ws.get(f"tr_h_{M}x{C}", (M, C))
-            ops.gemm(L, st, x2d, w[mm + ".proj_in.w"], hid, bias=w[mm + ".proj_in.bias"], pro_scale=sc, pro_shift=sh,
-                     rows_per_image=N)
+            proj_in(x2d, sc, sh, N, w[mm + ".proj_in.w"], w[mm + ".proj_in.bias"], hid)
             mmk = self.cfg["motion_module_kwargs"]
             for li in range(mmk.get("num_transformer_block", 1)):
                 b = f"{mm}.transformer_blocks.{li}"

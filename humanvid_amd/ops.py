@@ -51,6 +51,14 @@ def gemm(lib, stream, x, w, y, *, x2=None, k1=0, yt=None, n_split=0, pro_scale=N
     lib.call("hv_gemm", C.byref(p), stream)
 
 
+def affine_apply(lib, stream, x, scale, shift, y, *, rows_per_image, act=A.ACT_NONE):
+    """y[row, c] = act(x[row, c] * scale[row // rows_per_image, c] + shift[...]) -- GroupNorm apply as its own pass
+    (x, y: [rows, C] bf16, possibly row-strided; scale / shift [images, C] fp32 from groupnorm_affine)."""
+    rows, Cc = x.shape
+    lib.call("hv_affine_apply", _p(x), x.stride(0), rows, rows_per_image, Cc, _p(scale), _p(shift), act, _p(y), y.stride(0),
+             stream)
+
+
 def conv3x3(lib, stream, x, w, y, *, x2=None, mode=A.CONV_S1, pro_scale=None, pro_shift=None, pro_act=A.ACT_NONE,
             bias=None, rowvec=None, images_per_rowvec=1, rowvec_ld=None, residual=None, out_act=A.ACT_NONE):
     """x [n,Hs,Ws,C1] (+x2 [n,Hs,Ws,C2]); w packed [Cout, 9, C1+C2]; y [n,Ho,Wo,Cout]."""

@@ -215,6 +215,12 @@ int hv_pixel_unshuffle(const float* src, int B, int C, int F, int H, int W, int 
  * [1,6,F,H,W] fp32 map */
 int hv_plucker_unshuffle(const float* K, const float* c2w, int F, int H, int W, int r, uint16_t* dst, void* stream);
 /* diffusers Timesteps(320, flip_sin_to_cos=True, shift 0) (src/models/unet_3d.py:93,461): [B][dim] bf16 */
+/* GroupNorm apply as its own pass: Y[row][c] = act(X[row][c] * scale[row / rows_per_image][c] + shift[...][c]), bf16 -> bf16.
+ * Replaces the normalisation half of the InflatedGroupNorm in front of Transformer3DModel.proj_in
+ * (src/models/transformer_3d.py:125-131) and TemporalTransformer3DModel.proj_in (src/models/motion_module.py:157-163);
+ * scale / shift come from hv_groupnorm_affine. */
+int hv_affine_apply(const uint16_t* X, long ldx, int rows, int rows_per_image, int C, const float* scale, const float* shift,
+                    int act, uint16_t* Y, long ldy, void* stream);
 int hv_timestep_embedding(const float* t, int B, int dim, uint16_t* dst, void* stream);
 
 /* ---- window accumulation, classifier-free guidance and the DDIM v-prediction update --------

@@ -117,6 +117,23 @@ def case_gemm_prologue(cx: Ctx, n_img=3, rows=50, N=128, K=320, seed=1):
     return e
 
 
+def case_affine_apply(cx: Ctx, n_img=3, rows=50, C=64, act=A.ACT_NONE, seed=40):
+    """GroupNorm apply as its own pass: y = act(x * scale[img] + shift[img]), rounded to bf16 once."""
+    g = torch.Generator().manual_seed(seed)
+    M = n_img * rows
+    x = rnd(g, M, C)
+    sc, sh = 1 + 0.3 * rnd(g, n_img, C), 0.2 * rnd(g, n_img, C)
+    ref = r(x).view(n_img, rows, C) * sc[:, None] + sh[:, None]
+    if act == A.ACT_SILU:
+        ref = F.silu(ref)
+    y = torch.zeros(M, C, dtype=BF16, device=cx.device)
+    ops.affine_apply(cx.lib, cx.stream, cx.bf(x), cx.dev(sc), cx.dev(sh), y, rows_per_image=rows, act=act)
+    cx.sync()
+    e = nrmse(y, ref.view(M, C))
+    assert e < TOL, f"affine_apply nrmse {e}"
+    return e
+
+
 def case_gemm_lnfold(cx: Ctx, B=2, Fr=3, P=20, C=320, N=192, seed=2):
     """LayerNorm + positional encoding folded into the projection (motion-module QKV)."""
     g = torch.Generator().manual_seed(seed)

@@ -83,6 +83,11 @@ def test_gemm_fast_epilogue_forms(cx):
         cx.lib.call("hv_set_tuning", 2, 512)
 
 
+def test_affine_apply(cx):
+    kc.case_affine_apply(cx, n_img=3, rows=50, C=64)
+    kc.case_affine_apply(cx, n_img=2, rows=33, C=320, act=A.ACT_SILU, seed=41)
+
+
 def test_gemm_grouped_tile_raster(cx):
     """tile raster with gm m-blocks per n-step (default for N > 1024; forced here), ragged last group"""
     cx.lib.call("hv_set_tuning", 6, 2)

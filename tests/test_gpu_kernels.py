@@ -61,6 +61,11 @@ def test_bench_shape_gemm_forms(cx):
     kc.case_gemm_forms(cx, M=48 * 384, C=1280, N=1280, P=24 * 384, form="res", seed=39)
 
 
+def test_affine_apply(cx):
+    kc.case_affine_apply(cx, n_img=48, rows=1536, C=640)
+    kc.case_affine_apply(cx, n_img=48, rows=6144, C=320, act=A.ACT_SILU, seed=42)
+
+
 @pytest.mark.parametrize("mode", [A.CONV_S1, A.CONV_S2, A.CONV_UP2])
 def test_conv(cx, mode):
     kc.case_conv(cx, n=4, H=48, W=32, C1=320, Cout=320, mode=mode)

@@ -20,9 +20,9 @@
 #include "hv_gemm.h"  // hv_swz
 #include "humanvid_hip.h"
 
-template <int TW, int MODE, int NPIX = 128>
+template <int TW, int MODE, int NPIX = 128, int WPX = 64>
 struct HvConvGeom {
-    static constexpr int NT = 2 * NPIX;   // threads: one wave per 64 pixels x 64 channels
+    static constexpr int NT = 2 * 64 * (NPIX / WPX);   // threads: one wave per WPX pixels x 64 channels
     static constexpr int TH = NPIX / TW;
     static constexpr int HH = MODE == HV_CONV_S1 ? TH + 2 : (MODE == HV_CONV_S2 ? 2 * TH + 1 : TH / 2 + 2);
     static constexpr int HW = MODE == HV_CONV_S1 ? TW + 2 : (MODE == HV_CONV_S2 ? 2 * TW + 1 : TW / 2 + 2);
@@ -38,11 +38,14 @@ struct HvConvGeom {
 // GroupNorm/SiLU transform, is still staged through registers (once per 9 steps).
 // NPIX = 256 (8 waves): the weight tile of a tap is shared by twice as many pixels -> ~40 % fewer
 // bytes per FLOP through the per-CU load path, which bounds the 128-pixel variant (~25 GB/s per CU).
-template <int TW, int MODE, bool GLDS, int NPIX>
-__global__ __launch_bounds__(2 * NPIX) void hv_conv3x3_kernel(hv_conv3x3_params p) {
-    using G = HvConvGeom<TW, MODE, NPIX>;
+// WPX = 128 (round 2, NPIX = 256 on 4 waves): a wave owns 128 pixels x 64 channels (8 x 4 MFMA fragments, 128 accumulator
+// registers) -- 32 MFMAs per 12 ds_read_b128 and per barrier instead of 16 per 8, the weight tile of a tap serves twice the
+// pixels, the 18 x 18 halo of a 16 x 16 patch carries 27 % border instead of 41 %; 76 KiB of LDS, two workgroups per CU.
+template <int TW, int MODE, bool GLDS, int NPIX, int WPX = 64>
+__global__ __launch_bounds__(2 * 64 * (NPIX / WPX), (WPX == 128 ? 2 : 1)) void hv_conv3x3_kernel(hv_conv3x3_params p) {
+    using G = HvConvGeom<TW, MODE, NPIX, WPX>;
     constexpr int TH = G::TH;
-    constexpr int NT = G::NT, NW = NT / 64, WM = NPIX / 64;
+    constexpr int NT = G::NT, NW = NT / 64, WM = NPIX / WPX, NMF = WPX / 16;
     constexpr int WSLOTS = GLDS ? 3 : 2;
     __shared__ __attribute__((aligned(16))) unsigned char smem[2 * G::HALO_BYTES + WSLOTS * G::WTILE_BYTES];
     unsigned char* halo = smem;
@@ -190,20 +193,25 @@ __global__ __launch_bounds__(2 * NPIX) void hv_conv3x3_kernel(hv_conv3x3_params 
         }
     };
 
-    // per-lane pixel coordinates of the 4 pixel fragments
-    int py[4], px[4];
+    // per-lane pixel coordinates of the NMF pixel fragments
+    int py[NMF], px[NMF];
 #pragma unroll
-    for (int mf = 0; mf < 4; ++mf) {
-        const int pix = 64 * wm + 16 * mf + r16;
+    for (int mf = 0; mf < NMF; ++mf) {
+        const int pix = WPX * wm + 16 * mf + r16;
         py[mf] = pix / TW;
         px[mf] = pix % TW;
     }
+    // halo-pixel index of tap (0, 0) per fragment (stride-1 / stride-2 forms: the taps are immediate offsets from it)
+    int lpb[NMF];
+#pragma unroll
+    for (int mf = 0; mf < NMF; ++mf)
+        lpb[mf] = MODE == HV_CONV_S2 ? 2 * py[mf] * G::HW + 2 * px[mf] : py[mf] * G::HW + px[mf];
 
-    f32x4 acc[4][4];
+    f32x4 acc[4][NMF];
 #pragma unroll
     for (int a = 0; a < 4; ++a)
 #pragma unroll
-        for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int b = 0; b < NMF; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     load_halo(0);
     if (GLDS) {
@@ -243,24 +251,30 @@ __global__ __launch_bounds__(2 * NPIX) void hv_conv3x3_kernel(hv_conv3x3_params 
             constexpr int dy = tap / 3, dx = tap - dy * 3;
             const unsigned char* hb = halo + hbuf * G::HALO_BYTES + quad * 16;
             const unsigned char* wb = wsm + wbuf * G::WTILE_BYTES;
-            bf16x8 wf[4], xf[4];
+            bf16x8 wf[4];
 #pragma unroll
-            for (int f = 0; f < 4; ++f) {
-                wf[f] = hv_as_bf16x8(hv_ld16(wb + hv_swz<32>(64 * wn + 16 * f + r16, quad)));
-                int lp;
-                if (MODE == HV_CONV_S1)
-                    lp = (py[f] + dy) * G::HW + px[f] + dx;
-                else if (MODE == HV_CONV_S2)
-                    lp = (2 * py[f] + dy) * G::HW + 2 * px[f] + dx;
-                else
-                    lp = ((py[f] + dy + 1) >> 1) * G::HW + ((px[f] + dx + 1) >> 1);
-                xf[f] = hv_as_bf16x8(hv_ld16(hb + lp * G::PS));
+            for (int f = 0; f < 4; ++f) wf[f] = hv_as_bf16x8(hv_ld16(wb + hv_swz<32>(64 * wn + 16 * f + r16, quad)));
+            // pixel fragments in groups of four (16 registers of operands at a time)
+#pragma unroll
+            for (int g = 0; g < NMF; g += 4) {
+                bf16x8 xf[4];
+#pragma unroll
+                for (int f = 0; f < 4; ++f) {
+                    int lp;
+                    if (MODE == HV_CONV_S1)
+                        lp = lpb[g + f] + dy * G::HW + dx;
+                    else if (MODE == HV_CONV_S2)
+                        lp = lpb[g + f] + dy * G::HW + dx;
+                    else
+                        lp = ((py[g + f] + dy + 1) >> 1) * G::HW + ((px[g + f] + dx + 1) >> 1);
+                    xf[f] = hv_as_bf16x8(hv_ld16(hb + lp * G::PS));
+                }
+#pragma unroll
+                for (int nf = 0; nf < 4; ++nf)
+#pragma unroll
+                    for (int mf = 0; mf < 4; ++mf)
+                        acc[nf][g + mf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nf], xf[mf], acc[nf][g + mf], 0, 0, 0);
             }
-#pragma unroll
-            for (int nf = 0; nf < 4; ++nf)
-#pragma unroll
-                for (int mf = 0; mf < 4; ++mf)
-                    acc[nf][mf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nf], xf[mf], acc[nf][mf], 0, 0, 0);
         });
     }
 
@@ -280,8 +294,9 @@ __global__ __launch_bounds__(2 * NPIX) void hv_conv3x3_kernel(hv_conv3x3_params 
         add4[nf] = a;
     }
 #pragma unroll
-    for (int mf = 0; mf < 4; ++mf) {
-        const int oy = y0 + py[mf], ox = x0 + px[mf];
+    for (int mf = 0; mf < NMF; ++mf) {
+        const int opx = WPX * wm + 16 * mf + r16;  // recomputed: py / px need not stay live through the k-loop
+        const int oy = y0 + opx / TW, ox = x0 + opx % TW;
         if (oy >= p.Ho || ox >= p.Wo) continue;
         const long opix = (long)(img * p.Ho + oy) * p.Wo + ox;
         const long rpix = (long)(rimg * p.Ho + oy) * p.Wo + ox;
@@ -314,18 +329,19 @@ static int g_hv_conv_glds = 1;  // tuning knob (hv_set_tuning): LDS-DMA weight t
 
 static int g_hv_conv_big = 1;  // tuning knob: 256-pixel tiles (8 waves) on images that fill them
 
-template <int TW, int MODE, int NPIX>
+template <int TW, int MODE, int NPIX, int WPX = 64>
 static inline void hv_conv3x3_launch_t(const hv_conv3x3_params& p, hipStream_t stream) {
     constexpr int TH = NPIX / TW;
+    constexpr int NT = 2 * 64 * (NPIX / WPX);
     const int tiles = p.n_images * ((p.Ho + TH - 1) / TH) * ((p.Wo + TW - 1) / TW) * ((p.Cout + 127) / 128);
     const int grid = ((tiles + 7) / 8) * 8;
-    hv_note("hv_conv3x3_kernel<%d,%d,%d,%d> | n=%d Hs=%d Ws=%d Ho=%d Wo=%d Cin=%d Cout=%d gn=%d res=%d", TW, MODE,
-            g_hv_conv_glds, NPIX, p.n_images, p.Hs, p.Ws, p.Ho, p.Wo, p.C1 + p.C2, p.Cout, p.pro_scale != nullptr,
+    hv_note("hv_conv3x3_kernel<%d,%d,%d,%d%s> | n=%d Hs=%d Ws=%d Ho=%d Wo=%d Cin=%d Cout=%d gn=%d res=%d", TW, MODE,
+            g_hv_conv_glds, NPIX, WPX == 128 ? ",128" : "", p.n_images, p.Hs, p.Ws, p.Ho, p.Wo, p.C1 + p.C2, p.Cout, p.pro_scale != nullptr,
             p.residual != nullptr);
-    if (g_hv_conv_glds)
-        hv_launch(hv_conv3x3_kernel<TW, MODE, true, NPIX>, dim3(grid), dim3(2 * NPIX), stream, p);
+    if (g_hv_conv_glds || WPX == 128)
+        hv_launch(hv_conv3x3_kernel<TW, MODE, true, NPIX, WPX>, dim3(grid), dim3(NT), stream, p);
     else
-        hv_launch(hv_conv3x3_kernel<TW, MODE, false, NPIX>, dim3(grid), dim3(2 * NPIX), stream, p);
+        hv_launch(hv_conv3x3_kernel<TW, MODE, false, NPIX, WPX>, dim3(grid), dim3(NT), stream, p);
 }
 
 static inline int hv_conv3x3_launch(const hv_conv3x3_params& p, hipStream_t stream) {
@@ -342,9 +358,12 @@ static inline int hv_conv3x3_launch(const hv_conv3x3_params& p, hipStream_t stre
     // (measured on MI355X: the 8-wave tile wins for the upsample-folded conv, 0.90 -> 1.03 PF/s, and
     //  loses for stride 1, where the per-step barrier over 8 waves costs more than the traffic saved)
     const bool big = g_hv_conv_big && !narrow && p.Ho >= 16 && p.mode == HV_CONV_UP2;
+    // 256-pixel tiles on 4 waves of 128 pixels (tuning value 2): stride-1 convolutions whose images fill 16 x 16 patches
+    const bool wide = g_hv_conv_big == 2 && !narrow && p.Ho >= 16 && p.Wo >= 16 && p.mode == HV_CONV_S1;
     switch (p.mode) {
         case HV_CONV_S1:
-            if (big) hv_conv3x3_launch_t<16, HV_CONV_S1, 256>(p, stream);
+            if (wide) hv_conv3x3_launch_t<16, HV_CONV_S1, 256, 128>(p, stream);
+            else if (big) hv_conv3x3_launch_t<16, HV_CONV_S1, 256>(p, stream);
             else if (narrow) hv_conv3x3_launch_t<8, HV_CONV_S1, 128>(p, stream);
             else hv_conv3x3_launch_t<16, HV_CONV_S1, 128>(p, stream);
             break;

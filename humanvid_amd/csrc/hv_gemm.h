@@ -599,7 +599,7 @@ __global__ __launch_bounds__(256, 2) void hv_gemm_kernel(HvGemmParams p) {
 //       ds_read, LDS-DMA-issue and epilogue times simply add up);
 //   NW = 8: 4 x 2 waves of 64x64 (BN = 128) or 2 x 4 of 128x64 (BN = 256), one workgroup per CU.
 template <int BK, int NS, int BN, int NW, int BM = 256>
-__global__ __launch_bounds__(NW * 64, 2) void hv_gemm_glds_kernel(HvGemmParams p, int gm, int form) {
+__global__ __launch_bounds__(NW * 64, 2) void hv_gemm_glds_kernel(HvGemmParams p, int gm, int form, int walk) {
     constexpr int WAVES_N = BN / 64, WAVES_M = NW / WAVES_N;
     constexpr int WTM = BM / WAVES_M, NMF = WTM / 16;
     constexpr int XT = BM * BK * 2, WT = BN * BK * 2, SLOT = XT + WT;
@@ -644,9 +644,18 @@ __global__ __launch_bounds__(NW * 64, 2) void hv_gemm_glds_kernel(HvGemmParams p
     const int per_xcd = (total + 7) / 8;
     const int t_begin = xcd * per_xcd;
     const int t_end = min(total, t_begin + per_xcd);
-    const int first = t_begin + wg;
+    // Tile walk.  walk = 0 (round 1): workgroup w of an XCD takes tiles w, w + G, w + 2G ... of the XCD's range, so the G
+    // concurrent workgroups hold G consecutive tiles -- the n-tiles of one m-block run side by side and share its X panel in
+    // L2, but every one of them meets that panel for the first time: each k-step's LDS-DMA is an HBM miss (gemm_trace: ~5000
+    // clocks of blocked DMA issue per k-step on the streamed level-0 projections, whose LDS ring can only keep one k-tile in
+    // flight).  walk = 1: every workgroup takes a CONTIGUOUS run of tiles, i.e. it sweeps the n-tiles of an m-block itself,
+    // one after the other: the first sweep streams the X panel from HBM, the others find it in L2 / MALL; the workgroups of
+    // an XCD sweep n in step, so the W tile of a step is shared by all of them.
+    const int chunk = (t_end - t_begin + wg_per_xcd - 1) / wg_per_xcd;
+    const int first = walk ? t_begin + wg * chunk : t_begin + wg;
+    const int tstep = walk ? 1 : wg_per_xcd;
     if (first >= t_end) return;
-    const int my_tiles = (t_end - first + wg_per_xcd - 1) / wg_per_xcd;
+    const int my_tiles = walk ? min(chunk, t_end - first) : (t_end - first + wg_per_xcd - 1) / wg_per_xcd;
     const int nk = p.K / BK;
     const int nsteps = my_tiles * nk;
 
@@ -711,7 +720,7 @@ __global__ __launch_bounds__(NW * 64, 2) void hv_gemm_glds_kernel(HvGemmParams p
         if (++i_slot == NS) i_slot = 0;
         if (++i_k == nk) {
             i_k = 0;
-            i_tile += wg_per_xcd;
+            i_tile += tstep;
             set_tile();
         } else if (i_k == k1_steps) {
             set_x(p.X2, p.ldx2);
@@ -787,7 +796,7 @@ __global__ __launch_bounds__(NW * 64, 2) void hv_gemm_glds_kernel(HvGemmParams p
                 hv_gemm_epilogue_form<NMF>(form, p, acc, m0 + WTM * wm, n0 + 64 * wn, r16, quad HV_TRACE_ARG);
                 landed = AHEAD;
             }
-            c_tile += wg_per_xcd;
+            c_tile += tstep;
             clear_acc();
             HV_TRACE(6);
         }
@@ -795,6 +804,7 @@ __global__ __launch_bounds__(NW * 64, 2) void hv_gemm_glds_kernel(HvGemmParams p
 }
 
 static int g_hv_gemm_max_grid = 512;  // tuning knob (hv_set_tuning): persistent workgroups
+static int g_hv_gemm_walk = 0;          // tuning knob: 1 = contiguous tile run per workgroup (see the kernel; measured no gain: the X panel of a 256-row block does not survive in the 4 MiB L2 next to 32 workgroups' tiles), 0 = strided (default)
 static int g_hv_gemm_raster = 0;        // tuning knob: m-blocks per raster group (0 = auto: 8 when N spans more than 8 tiles)
 // tuning knob (hv_set_tuning key 3) -- tile policy of the LDS-DMA kernel:
 //   9 (default, round 2): BK = 64 everywhere (whole 128-byte lines per operand row: the kernel is bound by the CU's
@@ -826,13 +836,14 @@ static inline int hv_gemm_launch(const HvGemmParams& p, hipStream_t stream) {
                          (p.X2 == nullptr || (long)p.M * p.ldx2 * 2 < lim) &&
                          (p.residual == nullptr || (long)p.M * p.ldr * 2 < lim) &&
                          (p.Yt == nullptr || (long)(p.N - p.n_split) * p.ldyt * 2 < lim);
-    const int form128 = hv_gemm_fast_form(p, 128), form64 = hv_gemm_fast_form(p, 64);  // 128 / 64 rows per wave sub-tile
+    const int form128 = hv_gemm_fast_form(p, 128), form64 = hv_gemm_fast_form(p, 64);
     if (g_hv_gemm_glds && !prologue && p.M >= 256 && span_ok && form64 != HV_FORM_NONE) {
         const int tm = (p.M + 255) / 256;
         // 256x256 tiles (one 128 KiB workgroup per CU, a third fewer bytes per FLOP through the
         // per-CU load path) when N fills them about as well as 256x128 tiles would
         const int n128 = ((p.N + 127) / 128) * 128, n256 = ((p.N + 255) / 256) * 256;
-        const int gm = g_hv_gemm_raster > 0 ? g_hv_gemm_raster : (n128 / 128 > 8 ? 8 : 1);
+        // (the grouped raster is a property of the strided walk; a contiguous run sweeps n inside one m-block)
+        const int gm = g_hv_gemm_walk ? 1 : (g_hv_gemm_raster > 0 ? g_hv_gemm_raster : (n128 / 128 > 8 ? 8 : 1));
         // 256x256x64 tiles, 2-slot 128 KiB ring, 8 waves (2 x 4 of 128x64), one workgroup per CU: whole 128-byte lines per
         // row (twice the LDS-DMA fill rate of 64-byte segments) and 2/3 of the operand bytes per FLOP of the 256x128 tile.
         // The kernel is bound by the CU's L2 -> LDS fill path (~27-60 B/clk measured: round-2 attention trace, round-1
@@ -845,7 +856,7 @@ static inline int hv_gemm_launch(const HvGemmParams& p, hipStream_t stream) {
             if (grid > 256) grid = 256;
             if (grid > g_hv_gemm_max_grid) grid = g_hv_gemm_max_grid;
             hv_note("hv_gemm_glds_kernel<64,2,256,8,256> | %s", shape);
-            hv_launch(hv_gemm_glds_kernel<64, 2, 256, 8, 256>, dim3(grid), dim3(512), stream, p, gm, form128);
+            hv_launch(hv_gemm_glds_kernel<64, 2, 256, 8, 256>, dim3(grid), dim3(512), stream, p, gm, form128, g_hv_gemm_walk);
             return 0;
         }
         if (ok128 && g_hv_gemm_glds == 3 && p.N >= 512 && (n256 - n128) * 12 <= p.N) {
@@ -854,7 +865,7 @@ static inline int hv_gemm_launch(const HvGemmParams& p, hipStream_t stream) {
             if (grid > 256) grid = 256;
             if (grid > g_hv_gemm_max_grid) grid = g_hv_gemm_max_grid;
             hv_note("hv_gemm_glds_kernel<32,4,256,8> | %s", shape);
-            hv_launch(hv_gemm_glds_kernel<32, 4, 256, 8>, dim3(grid), dim3(512), stream, p, gm, form128);
+            hv_launch(hv_gemm_glds_kernel<32, 4, 256, 8>, dim3(grid), dim3(512), stream, p, gm, form128, g_hv_gemm_walk);
             return 0;
         }
         // 128x128x64 tiles (whole 128-byte lines per row: 1.8x the LDS-DMA rate of 64-byte row segments), 2-slot 64 KiB
@@ -866,7 +877,7 @@ static inline int hv_gemm_launch(const HvGemmParams& p, hipStream_t stream) {
             if (grid6 > 512) grid6 = 512;
             if (grid6 > g_hv_gemm_max_grid) grid6 = g_hv_gemm_max_grid;
             hv_note("hv_gemm_glds_kernel<64,2,128,4,128> | %s", shape);
-            hv_launch(hv_gemm_glds_kernel<64, 2, 128, 4, 128>, dim3(grid6), dim3(256), stream, p, gm, form64);
+            hv_launch(hv_gemm_glds_kernel<64, 2, 128, 4, 128>, dim3(grid6), dim3(256), stream, p, gm, form64, g_hv_gemm_walk);
             return 0;
         }
         const int tiles = tm * (n128 / 128);
@@ -875,16 +886,16 @@ static inline int hv_gemm_launch(const HvGemmParams& p, hipStream_t stream) {
             if (grid > 256) grid = 256;
             if (grid > g_hv_gemm_max_grid) grid = g_hv_gemm_max_grid;
             hv_note("hv_gemm_glds_kernel<64,3,128,8> | %s", shape);
-            hv_launch(hv_gemm_glds_kernel<64, 3, 128, 8>, dim3(grid), dim3(512), stream, p, gm, form64);
+            hv_launch(hv_gemm_glds_kernel<64, 3, 128, 8>, dim3(grid), dim3(512), stream, p, gm, form64, g_hv_gemm_walk);
         } else {  // BK = 32, 72 KiB ring: two workgroups per CU whose epilogues interleave
             if (grid > 512) grid = 512;
             if (grid > g_hv_gemm_max_grid) grid = g_hv_gemm_max_grid;
             if (g_hv_gemm_glds == 4) {
                 hv_note("hv_gemm_glds_kernel<32,3,128,8> | %s", shape);
-                hv_launch(hv_gemm_glds_kernel<32, 3, 128, 8>, dim3(grid), dim3(512), stream, p, gm, form64);
+                hv_launch(hv_gemm_glds_kernel<32, 3, 128, 8>, dim3(grid), dim3(512), stream, p, gm, form64, g_hv_gemm_walk);
             } else {
                 hv_note("hv_gemm_glds_kernel<32,3,128,4> | %s", shape);
-                hv_launch(hv_gemm_glds_kernel<32, 3, 128, 4>, dim3(grid), dim3(256), stream, p, gm, form128);
+                hv_launch(hv_gemm_glds_kernel<32, 3, 128, 4>, dim3(grid), dim3(256), stream, p, gm, form128, g_hv_gemm_walk);
             }
         }
         return 0;

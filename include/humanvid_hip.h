@@ -174,6 +174,7 @@ int hv_attention(const hv_attention_params* p, void* stream);
 #define HV_TUNE_GEMM_RASTER 6   /* m-blocks per tile-raster group of the LDS-DMA GEMM (0 = auto, 1 = row-major) */
 #define HV_TUNE_TEMPORAL_MFMA 7 /* temporal attention: 1 = MFMA kernel, one wave per (batch, pixel, head) (default), 0 = VALU kernel */
 #define HV_TUNE_CONV_BIG 5      /* 1: 256-pixel conv tiles where the image fills them (default), 0: 128 */
+#define HV_TUNE_GEMM_WALK 8     /* LDS-DMA GEMM tile walk: 1 = every workgroup takes a contiguous run of tiles, 0 = strided over the XCD's range (default) */
 int hv_set_tuning(int key, int value);
 
 /* ---- temporal self-attention over the frame axis ------------------------------------------

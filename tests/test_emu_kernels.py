@@ -92,6 +92,7 @@ def test_gemm_grouped_tile_raster(cx):
     """tile raster with gm m-blocks per n-step (default for N > 1024; forced here), ragged last group"""
     cx.lib.call("hv_set_tuning", 6, 2)
     cx.lib.call("hv_set_tuning", 2, 8)
+    cx.lib.call("hv_set_tuning", 8, 0)  # the grouped raster belongs to the strided tile walk
     try:
         kc.case_gemm(cx, M=1300, N=320, K=64, seed=61)            # 6 m-blocks x 3 n-tiles, groups of 2
         kc.case_gemm(cx, M=1100, N=260, K=128, seed=62)           # 5 m-blocks: last group has one row
@@ -101,6 +102,22 @@ def test_gemm_grouped_tile_raster(cx):
     finally:
         cx.lib.call("hv_set_tuning", 2, 512)
         cx.lib.call("hv_set_tuning", 6, 0)
+        cx.lib.call("hv_set_tuning", 8, 0)
+
+
+def test_gemm_tile_walks(cx):
+    """contiguous (default) and strided tile walks, few persistent workgroups so that each walks several tiles, ragged
+    tile counts per workgroup"""
+    cx.lib.call("hv_set_tuning", 2, 8)
+    try:
+        for walk in (1, 0):
+            cx.lib.call("hv_set_tuning", 8, walk)
+            kc.case_gemm_forms(cx, M=1300, C=128, N=320, P=128, form="res", seed=81)      # 128x128 tiles: 11 x 3
+            kc.case_gemm_forms(cx, M=1300, C=128, N=1024, P=128, form="ln", seed=82)      # 256x256 tiles: 6 x 4
+            kc.case_gemm_forms(cx, M=700, C=64, N=2048, P=128, form="ln_geglu", seed=83)  # 3 x 8
+    finally:
+        cx.lib.call("hv_set_tuning", 2, 512)
+        cx.lib.call("hv_set_tuning", 8, 0)
 
 
 def test_gemm_lds_dma_256x256_tiles(cx):
@@ -145,6 +162,17 @@ def test_conv_big_tiles(cx):
         kc.case_conv(cx, n=1, H=9, W=9, C1=64, Cout=24, mode=A.CONV_UP2, seed=33)
     finally:
         cx.lib.call("hv_set_tuning", 4, 1)
+
+
+def test_conv_wide_wave_tiles(cx):
+    """stride-1 convs on 256-pixel tiles with 128 pixels per wave (tuning value 2): ragged patches, two sources, GN prologue"""
+    cx.lib.call("hv_set_tuning", 5, 2)
+    try:
+        kc.case_conv(cx, n=2, H=20, W=24, C1=32, Cout=40, mode=A.CONV_S1, seed=51)
+        kc.case_conv(cx, n=1, H=16, W=16, C1=32, C2=32, Cout=132, mode=A.CONV_S1, seed=52)
+        kc.case_conv(cx, n=1, H=33, W=17, C1=64, Cout=8, mode=A.CONV_S1, pro=False, temb=False, residual=False, seed=53)
+    finally:
+        cx.lib.call("hv_set_tuning", 5, 1)
 
 
 def test_conv_register_staged_variant(cx):

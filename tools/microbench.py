@@ -46,6 +46,8 @@ def main():
     st = hvlib.current_stream()
     if os.environ.get("HV_GEMM_GLDS"):
         L.call("hv_set_tuning", 3, int(os.environ["HV_GEMM_GLDS"]))  # A/B of the GEMM kernel variants
+    if os.environ.get("HV_GEMM_WALK"):
+        L.call("hv_set_tuning", 8, int(os.environ["HV_GEMM_WALK"]))
     if os.environ.get("HV_GEMM_RASTER"):
         L.call("hv_set_tuning", 6, int(os.environ["HV_GEMM_RASTER"]))
     if os.environ.get("HV_TEMPORAL_MFMA"):

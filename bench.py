@@ -223,12 +223,16 @@ def main():
     ap.add_argument("--frames", type=int, default=None)
     ap.add_argument("--height", type=int, default=None)
     ap.add_argument("--width", type=int, default=None)
+    ap.add_argument("--fp8-attention", type=int, default=None, choices=[0, 1],
+                    help="spatial attention on the fp8 (e4m3) MFMA; default: 1 for --config 5 (BASELINE.json configs[4]), else 0")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="skip the profiled extra step (roofline block)")
     args = ap.parse_args()
 
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    fp8_attn = (args.config == 5) if args.fp8_attention is None else bool(args.fp8_attention)
+    os.environ["HUMANVID_ATTENTION_FP8"] = "1" if fp8_attn else "0"  # read by UNet3DEngine at construction
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         _self_launch(args)
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -339,7 +343,8 @@ def main():
         out = {
             "metric": f"denoising steps/sec, {F}f x {H}x{W} Pose2Video", "value": K / elapsed, "unit": "steps/s",
             "n_gpus": world, "steps": K, "warmup": Wm, "ms_per_step": ms_step, "higher_is_better": True,
-            "scaling": "strong", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "scaling": "strong", "vs_baseline": None,
+            "dtype": "bf16 (fp8 e4m3 QK^T / PV in the spatial attention)" if fp8_attn else "bf16", "data": "synthetic",
             "config": {"workload": cfgsel["what"] + f"; CFG 3.5, SD-1.5 UNet3D + motion modules, {len(windows)} window(s) "
                                    "per step, DDIM v-pred",
                        "parallelism": par, "hip_graph": not args.no_graph and world == 1},

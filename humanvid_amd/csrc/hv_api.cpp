@@ -82,6 +82,26 @@ int hv_attention(const hv_attention_params* p, void* stream) {
     return hv_check_launch("hv_attention");
 }
 
+int hv_attention_fp8_scales(const uint16_t* K, long ldk, const uint16_t* Vt, long ldvt, int n_images, int heads, int D, int L,
+                            float* kscale, float* vamax, void* stream) {
+    if (!K || !Vt || !kscale || !vamax) return hv_fail(HV_EINVAL, "hv_attention_fp8_scales: null operand");
+    int rc = hvk_attention_fp8_scales(K, ldk, Vt, ldvt, n_images, heads, D, L, kscale, vamax, (hipStream_t)stream);
+    if (rc == -2) return hv_fail(HV_ENOTSUP, "hv_attention_fp8_scales: head dim must be 40, 80 or 160");
+    if (rc != 0) return hv_fail(HV_EINVAL, "hv_attention_fp8_scales: need L % 8 == 0 and 16-byte aligned strides");
+    return hv_check_launch("hv_attention_fp8_scales");
+}
+
+int hv_attention_fp8(const hv_attention_params* p, const float* kscale, const float* vamax, const float* kscale2,
+                     const float* vamax2, void* stream) {
+    if (!p || !p->Q || !p->K || !p->Vt || !p->O || !kscale || !vamax) return hv_fail(HV_EINVAL, "hv_attention_fp8: null operand");
+    int rc = hvk_attention_fp8(*p, kscale, vamax, kscale2, vamax2, (hipStream_t)stream);
+    if (rc == -2) return hv_fail(HV_ENOTSUP, "hv_attention_fp8: head dim must be 40, 80 or 160");
+    if (rc != 0)
+        return hv_fail(HV_EINVAL, "hv_attention_fp8: transposed-V form only, L1 % 8 == 0, L2 % 8 == 0, 16-byte aligned strides, "
+                                  "bank scales with the bank");
+    return hv_check_launch("hv_attention_fp8");
+}
+
 int hv_set_tuning(int key, int value) {
     if (key == HV_TUNE_ATTN_QT_D40 && (value == 2 || value == 4)) hvk_attention_tune(40, value);
     else if (key == HV_TUNE_ATTN_QT_D160 && (value == 1 || value == 2)) hvk_attention_tune(160, value);

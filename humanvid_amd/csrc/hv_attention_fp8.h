@@ -1,0 +1,437 @@
+// hv_attention_fp8.h -- the spatial attention of hv_attention.h with both matrix products on the fp8 MFMA
+// (v_mfma_f32_16x16x32_fp8_fp8, OCP e4m3 on gfx950) -- BASELINE.json configs[4] ("fp8 MFMA attention").
+//
+// Reference semantics are those of hv_attention.h (read-mode reference attention,
+// /root/reference/src/models/mutual_self_attention.py:147-186: own keys || bank keys for the conditional images, own keys only
+// for the CFG-unconditional ones); only the operand precision of QK^T and PV changes.  Quantisation, chosen so that no
+// scale has to be applied inside an accumulation chain:
+//   * K: one scale per (image | bank batch, head, 64-key tile), computed by the pre-pass hv_attention_fp8_scales_kernel
+//     (amax / 384); the K tile is converted bf16 -> e4m3 when it is parked in LDS.
+//   * Q: one scale per query row (amax over the head's channels / 384), computed in registers at load; the queries stay
+//     resident as e4m3 fragments.  score (exp2 domain) = acc * (k_scale[tile] * q_scale[query] * scale * log2 e): one
+//     fused multiply-subtract per score, the factor is lane-local because a lane owns one query column.
+//   * P: probabilities are <= 1 after the running maximum is subtracted; they enter the PV product as e4m3(128 p).
+//   * V: one scale per (image | bank batch, head) -- the O^T accumulation runs over all tiles without rescaling; the row of
+//     ones that yields the denominator is e4m3 1.0, so O / l = (sum v8 p8) * v_scale / (sum p8) and the 128 cancels.
+// Accuracy: e4m3 carries 3 mantissa bits (2^-4 relative); errors average over the head dim in QK^T and over the keys in PV.
+// Stated and tested bound (tests/kernel_cases.py::case_attention_fp8): NRMSE <= 3e-2 against fp32 SDPA on bf16-rounded inputs
+// (the bf16 kernel: <= 6e-3).
+//
+// Structure = hv_attention_kernel (S^T = K.Q^T, lane owns a query column, key rows permuted in LDS so that P^T fragments feed
+// V^T.P^T without cross-lane moves, register-staged double-buffered K / V^T tiles, one barrier per tile, online softmax,
+// lazy rescale); fragments are 8 bytes per lane instead of 16, so a tile costs half the LDS bytes.
+#pragma once
+#include "hv_common.h"
+#include "humanvid_hip.h"
+
+#define HV_FP8_AMAX_TARGET 384.0f  // e4m3 maximum is 448: keep headroom for the rounding of the scale itself
+#define HV_FP8_P_SCALE 128.0f
+
+#ifndef HV_EMU
+typedef long hv_fp8x8;  // 8 e4m3 values, the A / B operand of v_mfma_f32_16x16x32_fp8_fp8
+HV_DEV unsigned hv_cvt_pk_fp8(float a, float b, unsigned old, bool hi) {  // hi: a compile-time constant after inlining
+    return hi ? (unsigned)__builtin_amdgcn_cvt_pk_fp8_f32(a, b, (int)old, true)
+              : (unsigned)__builtin_amdgcn_cvt_pk_fp8_f32(a, b, (int)old, false);
+}
+HV_DEV f32x4 hv_mfma_fp8(hv_fp8x8 a, hv_fp8x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(a, b, c, 0, 0, 0); }
+#else
+typedef long hv_fp8x8;
+HV_DEV unsigned hv_cvt_pk_fp8(float a, float b, unsigned old, bool hi) { return hvemu::cvt_pk_fp8(a, b, old, hi); }
+HV_DEV f32x4 hv_mfma_fp8(hv_fp8x8 a, hv_fp8x8 b, f32x4 c) { return hvemu::mfma_fp8(a, b, c); }
+#endif
+
+HV_DEV hv_fp8x8 hv_pack_fp8x8(const float* f) {  // 8 floats -> 8 e4m3 (element e in byte e)
+    unsigned lo = 0, hi = 0;
+    lo = hv_cvt_pk_fp8(f[0], f[1], lo, false);
+    lo = hv_cvt_pk_fp8(f[2], f[3], lo, true);
+    hi = hv_cvt_pk_fp8(f[4], f[5], hi, false);
+    hi = hv_cvt_pk_fp8(f[6], f[7], hi, true);
+    return (hv_fp8x8)(((unsigned long)hi << 32) | lo);
+}
+
+// ---- pre-pass: K scale per (image, head, 64-key tile), V amax per (image, head) (atomic max over the tiles; the caller
+//      zero-fills vamax).  One 64-thread workgroup per (tile, head, image); thread = key row for K, 8 tokens x D/8... for V^T.
+template <int D>
+__global__ __launch_bounds__(64) void hv_attention_fp8_scales_kernel(const bf16_t* K, long ldk, const bf16_t* Vt, long ldvt,
+                                                                     int L, int heads, float* kscale, float* vamax) {
+    const int tile = blockIdx.x, head = blockIdx.y, img = blockIdx.z;
+    const int T = (L + 63) / 64;
+    const int t = threadIdx.x;
+    const int kv = tile * 64 + t;
+    float ka = 0.f, va = 0.f;
+    if (kv < L) {
+        const bf16_t* krow = K + ((long)img * L + kv) * ldk + head * D;
+#pragma unroll
+        for (int c = 0; c < D / 8; ++c) {
+            float f[8];
+            hv_unpack8(hv_ld16(krow + c * 8), f);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) ka = fmaxf(ka, fabsf(f[e]));
+        }
+    }
+    // V^T rows head*D + d, tokens img*L + tile*64 + 8*(t & 7) .. + 7
+    const int c8 = t & 7;
+    if (tile * 64 + c8 * 8 < L) {
+        for (int d = t >> 3; d < D; d += 8) {
+            float f[8];
+            hv_unpack8(hv_ld16(Vt + (long)(head * D + d) * ldvt + (long)img * L + tile * 64 + c8 * 8), f);
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                if (tile * 64 + c8 * 8 + e < L) va = fmaxf(va, fabsf(f[e]));
+        }
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        ka = fmaxf(ka, __shfl_xor(ka, m));
+        va = fmaxf(va, __shfl_xor(va, m));
+    }
+    if (t == 0) {
+        kscale[((long)img * heads + head) * T + tile] = ka > 0.f ? ka / HV_FP8_AMAX_TARGET : 1.0f;
+        // non-negative floats order like their bit patterns: integer atomic max
+        atomicMax(reinterpret_cast<int*>(vamax) + img * heads + head, __builtin_bit_cast(int, va));
+    }
+}
+
+template <int D>
+struct HvAttn8Geom {
+    static constexpr int NFULL = (D + 31) / 32;       // 32-deep QK^T steps (zero-padded remainder)
+    static constexpr int DT = (D + 15) / 16;          // 16-row fragments of V^T / O^T
+    static constexpr int DK = 32 * NFULL;             // bytes of a key row in LDS
+    static constexpr int DV = 16 * DT;
+    static constexpr bool ONES = DV > D;              // spare V^T row for the denominator
+    static constexpr int KRS = DK + 8;                // K row stride (bytes): 8-byte reads of 16 rows hit 32 distinct banks
+    static constexpr int VRS = 64 + 8;                // V^T row stride (64 keys)
+    static constexpr int KBYTES = 64 * KRS;
+    static constexpr int VBYTES = DV * VRS;
+    static constexpr int KCH = 64 * (D / 8);          // 16-byte bf16 chunks of a K tile in HBM
+    static constexpr int VCH = D * 8;
+    static constexpr int KIT = (KCH + 255) / 256;
+    static constexpr int VIT = (VCH + 255) / 256;
+    static constexpr int QT = 2;
+    static constexpr int BQ = 4 * 16 * QT;
+};
+
+template <int D, bool MASK>
+__global__ __launch_bounds__(256, (D == 40 ? 4 : (D == 80 ? 2 : 1))) void hv_attention_fp8_kernel(
+    hv_attention_params p, const float* kscale, const float* vamax, const float* kscale2, const float* vamax2) {
+    using G = HvAttn8Geom<D>;
+    constexpr int NFULL = G::NFULL, DT = G::DT, QT = G::QT;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * (G::KBYTES + G::VBYTES)];
+    unsigned char* Ks = smem;
+    unsigned char* Vs = smem + 2 * G::KBYTES;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r16 = lane & 15, quad = lane >> 4;
+
+    const int nqb = (p.Lq + G::BQ - 1) / G::BQ;
+    const int total = nqb * p.heads * p.n_images;
+    const int cpx = gridDim.x / 8;
+    int t = (blockIdx.x % 8) * cpx + blockIdx.x / 8;
+    if (t >= total) return;
+    const int qb = t % nqb;
+    t /= nqb;
+    const int head = t % p.heads;
+    int img = t / p.heads;
+    if ((p.n_images & 1) == 0) img = (img & 1) * (p.n_images >> 1) + (img >> 1);  // CFG halves alternate over the XCDs
+    const int sel = (p.bank_sel != nullptr && p.L2 > 0) ? p.bank_sel[img] : -1;
+    const int T1 = (p.L1 + 63) / 64;
+    const int T2 = sel >= 0 ? (p.L2 + 63) / 64 : 0;
+    const int ntiles = T1 + T2;
+
+    for (int i = tid; i < 2 * (G::KBYTES + G::VBYTES) / 16; i += 256) hv_st16(smem + i * 16, u32x4{0u, 0u, 0u, 0u});
+    __syncthreads();
+    if (G::ONES) {  // e4m3 1.0 = 0x38 in the first spare V^T row of both buffers
+        for (int i = tid; i < 2 * 8; i += 256)
+            hv_st8(Vs + (i >> 3) * G::VBYTES + D * G::VRS + (i & 7) * 8, u32x2{0x38383838u, 0x38383838u});
+    }
+
+    // ---- queries: per-row scale, e4m3 fragments resident for the whole kernel
+    hv_fp8x8 qf[QT][NFULL];
+    float qfac[QT];  // q_scale * softmax scale * log2(e)
+    const int q_wave = qb * G::BQ + wave * 16 * QT;
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) {
+        const int q = q_wave + 16 * qt + r16;
+        const bf16_t* qrow = p.Q + ((long)img * p.Lq + q) * p.ldq + head * D;
+        float f[NFULL][8];
+        float am = 0.f;
+#pragma unroll
+        for (int s = 0; s < NFULL; ++s) {
+            u32x4 v = {0u, 0u, 0u, 0u};
+            if (q < p.Lq && 32 * s + 8 * quad + 8 <= D) v = hv_ld16(qrow + 32 * s + 8 * quad);
+            hv_unpack8(v, f[s]);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) am = fmaxf(am, fabsf(f[s][e]));
+        }
+        am = fmaxf(am, __shfl_xor(am, 16));
+        am = fmaxf(am, __shfl_xor(am, 32));
+        const float qs = am > 0.f ? am / HV_FP8_AMAX_TARGET : 1.0f;
+        const float inv = 1.0f / qs;
+#pragma unroll
+        for (int s = 0; s < NFULL; ++s) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) f[s][e] *= inv;
+            qf[qt][s] = hv_pack_fp8x8(f[s]);
+        }
+        qfac[qt] = qs * p.scale * 1.44269504089f;
+    }
+
+    // V scales of the two key sources
+    const float va1 = vamax[img * p.heads + head];
+    const float vs1 = va1 > 0.f ? va1 / HV_FP8_AMAX_TARGET : 1.0f;
+    float vs2 = 1.0f;
+    if (sel >= 0) {
+        const float va2 = vamax2[sel * p.heads + head];
+        vs2 = va2 > 0.f ? va2 / HV_FP8_AMAX_TARGET : 1.0f;
+    }
+    // the O^T accumulation must not change scale between the sources: bank values are quantised with the LARGER of the two
+    // scales folded in -- v8 = v / vs_common
+    const float vs = fmaxf(vs1, vs2);
+    const float inv_vs = 1.0f / vs;
+
+    u32x4 kreg[G::KIT], vreg[G::VIT];
+    float ksc_staged = 1.f;  // scale of the K tile held in kreg
+    auto load_tile = [&](int ti) {
+        const bool bank = ti >= T1;
+        const int tl = bank ? ti - T1 : ti;
+        const int kv0 = tl * 64;
+        const int L = bank ? p.L2 : p.L1;
+        const long rowbase = bank ? (long)sel * p.L2 : (long)img * p.L1;
+        const bf16_t* Kp = bank ? p.K2 : p.K;
+        const long ldk = bank ? p.ldk2 : p.ldk;
+        const bf16_t* Vp = bank ? p.Vt2 : p.Vt;
+        const long ldv = bank ? p.ldvt2 : p.ldvt;
+        ksc_staged = bank ? kscale2[((long)sel * p.heads + head) * T2 + tl] : kscale[((long)img * p.heads + head) * T1 + tl];
+#pragma unroll
+        for (int i = 0; i < G::KIT; ++i) {
+            const int id = tid + 256 * i;
+            u32x4 v = {0u, 0u, 0u, 0u};
+            if (id < G::KCH) {
+                const int r = id / (D / 8), c = id % (D / 8);
+                if (!MASK || kv0 + r < L) v = hv_ld16(Kp + (rowbase + kv0 + r) * ldk + head * D + c * 8);
+            }
+            kreg[i] = v;
+        }
+#pragma unroll
+        for (int i = 0; i < G::VIT; ++i) {
+            const int id = tid + 256 * i;
+            u32x4 v = {0u, 0u, 0u, 0u};
+            if (id < G::VCH) {
+                const int d = id >> 3, c = id & 7;
+                if (!MASK || kv0 + c * 8 < L) v = hv_ld16(Vp + (long)(head * D + d) * ldv + rowbase + kv0 + c * 8);
+            }
+            vreg[i] = v;
+        }
+    };
+    auto store_tile = [&](int buf) {
+        const float inv_k = 1.0f / ksc_staged;
+#pragma unroll
+        for (int i = 0; i < G::KIT; ++i) {
+            const int id = tid + 256 * i;
+            if (id < G::KCH) {
+                const int r = id / (D / 8), c = id % (D / 8);
+                const int lr = (r & ~0x1c) | ((r & 4) << 2) | ((r & 0x18) >> 1);  // key permutation of hv_attention.h
+                float f[8];
+                hv_unpack8(kreg[i], f);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) f[e] *= inv_k;
+                const hv_fp8x8 o = hv_pack_fp8x8(f);
+                hv_st8(Ks + buf * G::KBYTES + lr * G::KRS + c * 8, u32x2{(unsigned)o, (unsigned)((unsigned long)o >> 32)});
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < G::VIT; ++i) {
+            const int id = tid + 256 * i;
+            if (id < G::VCH) {
+                float f[8];
+                hv_unpack8(vreg[i], f);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) f[e] *= inv_vs;
+                const hv_fp8x8 o = hv_pack_fp8x8(f);
+                hv_st8(Vs + buf * G::VBYTES + (id >> 3) * G::VRS + (id & 7) * 8, u32x2{(unsigned)o, (unsigned)((unsigned long)o >> 32)});
+            }
+        }
+    };
+
+    f32x4 oacc[QT][DT];
+    float mrun[QT], lrun[QT];
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) {
+        mrun[qt] = -INFINITY;
+        lrun[qt] = 0.f;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) oacc[qt][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+
+    load_tile(0);
+    __syncthreads();
+    for (int ti = 0; ti < ntiles; ++ti) {
+        const int buf = ti & 1;
+        const float sk = ksc_staged;  // scale of the K tile being parked now (load_tile below replaces it with the next one)
+        store_tile(buf);
+        __syncthreads();
+        if (ti + 1 < ntiles) load_tile(ti + 1);
+        const unsigned char* kb = Ks + buf * G::KBYTES + r16 * G::KRS + quad * 8;
+        const unsigned char* vb = Vs + buf * G::VBYTES + r16 * G::VRS + quad * 8;
+
+        // ---- S^T fragments (unscaled e4m3 products): sacc[kvf][qt], reg r <-> key 32*(kvf>>1) + 8*quad + 4*(kvf&1) + r
+        f32x4 sacc[4][QT];
+#pragma unroll
+        for (int kvf = 0; kvf < 4; ++kvf) {
+#pragma unroll
+            for (int qt = 0; qt < QT; ++qt) sacc[kvf][qt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s = 0; s < NFULL; ++s) {
+                const u32x2 kw = hv_ld8(kb + (16 * kvf) * G::KRS + s * 32);
+                const hv_fp8x8 kf = (hv_fp8x8)(((unsigned long)kw[1] << 32) | kw[0]);
+#pragma unroll
+                for (int qt = 0; qt < QT; ++qt) sacc[kvf][qt] = hv_mfma_fp8(kf, qf[qt][s], sacc[kvf][qt]);
+            }
+        }
+        if (MASK) {
+            const bool bank = ti >= T1;
+            const int kv0 = (bank ? ti - T1 : ti) * 64;
+            const int L = bank ? p.L2 : p.L1;
+            if (kv0 + 64 > L) {
+#pragma unroll
+                for (int kvf = 0; kvf < 4; ++kvf)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int kv = kv0 + 32 * (kvf >> 1) + 8 * quad + 4 * (kvf & 1) + r;
+                        if (kv >= L) {
+#pragma unroll
+                            for (int qt = 0; qt < QT; ++qt) sacc[kvf][qt][r] = -INFINITY;
+                        }
+                    }
+            }
+        }
+        // ---- online softmax (exp2 domain), probabilities as e4m3(128 p)
+        hv_fp8x8 pf[QT][2];
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt) {
+            const float fac = sk * qfac[qt];  // > 0: the maximum commutes with the scaling
+            float mx = fmaxf(fmaxf(sacc[0][qt][0], sacc[0][qt][1]), fmaxf(sacc[0][qt][2], sacc[0][qt][3]));
+#pragma unroll
+            for (int kvf = 1; kvf < 4; ++kvf)
+                mx = fmaxf(fmaxf(fmaxf(mx, sacc[kvf][qt][0]), fmaxf(sacc[kvf][qt][1], sacc[kvf][qt][2])), sacc[kvf][qt][3]);
+            mx = fmaxf(mx, __shfl_xor(mx, 16));
+            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            const float mold = mrun[qt];
+            const float mnew = fmaxf(mold, mx * fac);
+            mrun[qt] = mnew;
+            float pv[4][4];
+            float psum = 0.f;
+#pragma unroll
+            for (int kvf = 0; kvf < 4; ++kvf)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    // (+7: the factor 128 of the e4m3 probabilities, inside the exponent)
+                    pv[kvf][r] = __builtin_amdgcn_exp2f(sacc[kvf][qt][r] * fac - mnew + 7.0f);
+                    if (!G::ONES) psum += pv[kvf][r];
+                }
+            if (__any(mnew > mold)) {
+                const float alpha = __builtin_amdgcn_exp2f(mold - mnew);
+                if (!G::ONES) lrun[qt] *= alpha;
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt) oacc[qt][dt] *= alpha;
+            }
+            if (!G::ONES) lrun[qt] += psum;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const float f8[8] = {pv[2 * ks][0],     pv[2 * ks][1],     pv[2 * ks][2],     pv[2 * ks][3],
+                                     pv[2 * ks + 1][0], pv[2 * ks + 1][1], pv[2 * ks + 1][2], pv[2 * ks + 1][3]};
+                pf[qt][ks] = hv_pack_fp8x8(f8);
+            }
+        }
+        // ---- O^T += V^T . P^T  (row D of V^T is e4m3 1.0 when ONES: accumulates the denominator)
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const u32x2 vw = hv_ld8(vb + (16 * dt) * G::VRS + ks * 32);
+                const hv_fp8x8 vf = (hv_fp8x8)(((unsigned long)vw[1] << 32) | vw[0]);
+#pragma unroll
+                for (int qt = 0; qt < QT; ++qt) oacc[qt][dt] = hv_mfma_fp8(vf, pf[qt][ks], oacc[qt][dt]);
+            }
+    }
+
+    // ---- normalise and store: lane owns query r16, channels 16*dt + 4*quad + 0..3
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) {
+        float l;
+        if (G::ONES) {
+            l = __shfl(oacc[qt][D / 16][D % 4], ((D % 16) / 4) * 16 + r16);
+        } else {
+            // the probabilities were rounded to e4m3 before the PV product: sum the rounded values' exact counterparts is not
+            // available without the ones row; d = 80 / 160 have no spare row, their denominator is the fp32 sum (scaled 128)
+            l = lrun[qt];
+            l += __shfl_xor(l, 16);
+            l += __shfl_xor(l, 32);
+        }
+        const float inv = vs / l;
+        const int q = q_wave + 16 * qt + r16;
+        if (q >= p.Lq) continue;
+        bf16_t* dst = p.O + ((long)img * p.Lq + q) * p.ldo + head * D;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+            const int d = 16 * dt + 4 * quad;
+            if (d < D) {
+                u32x2 o = {hv_pack2(oacc[qt][dt][0] * inv, oacc[qt][dt][1] * inv),
+                           hv_pack2(oacc[qt][dt][2] * inv, oacc[qt][dt][3] * inv)};
+                hv_st8(dst + d, o);
+            }
+        }
+    }
+}
+
+template <int D>
+static inline void hv_attention_fp8_scales_launch_t(const bf16_t* K, long ldk, const bf16_t* Vt, long ldvt, int n, int heads, int L,
+                                                    float* kscale, float* vamax, hipStream_t stream) {
+    hv_note("hv_attention_fp8_scales_kernel<%d> | n=%d heads=%d L=%d", D, n, heads, L);
+    hv_launch(hv_attention_fp8_scales_kernel<D>, dim3((L + 63) / 64, heads, n), dim3(64), stream, K, ldk, Vt, ldvt, L, heads, kscale,
+              vamax);
+}
+
+static inline int hv_attention_fp8_scales_launch(const bf16_t* K, long ldk, const bf16_t* Vt, long ldvt, int n, int heads, int D,
+                                                 int L, float* kscale, float* vamax, hipStream_t stream) {
+    if (L <= 0 || L % 8 != 0 || ldk % 8 || ldvt % 8 || n <= 0 || heads <= 0) return -1;
+    (void)hipMemsetAsync(vamax, 0, sizeof(float) * (size_t)n * heads, stream);
+    switch (D) {
+        case 40: hv_attention_fp8_scales_launch_t<40>(K, ldk, Vt, ldvt, n, heads, L, kscale, vamax, stream); break;
+        case 80: hv_attention_fp8_scales_launch_t<80>(K, ldk, Vt, ldvt, n, heads, L, kscale, vamax, stream); break;
+        case 160: hv_attention_fp8_scales_launch_t<160>(K, ldk, Vt, ldvt, n, heads, L, kscale, vamax, stream); break;
+        default: return -2;
+    }
+    return 0;
+}
+
+template <int D>
+static inline void hv_attention_fp8_launch_t(const hv_attention_params& p, const float* ks, const float* va, const float* ks2,
+                                             const float* va2, hipStream_t stream) {
+    using G = HvAttn8Geom<D>;
+    const int total = ((p.Lq + G::BQ - 1) / G::BQ) * p.heads * p.n_images;
+    const int grid = ((total + 7) / 8) * 8;
+    const bool ragged = (p.L1 % 64) != 0 || (p.L2 % 64) != 0;
+    hv_note("hv_attention_fp8_kernel<%d> | n=%d heads=%d D=%d Lq=%d L1=%d L2=%d bank=%d", D, p.n_images, p.heads, D, p.Lq, p.L1, p.L2,
+            p.bank_sel != nullptr && p.L2 > 0);
+    if (ragged)
+        hv_launch(hv_attention_fp8_kernel<D, true>, dim3(grid), dim3(256), stream, p, ks, va, ks2, va2);
+    else
+        hv_launch(hv_attention_fp8_kernel<D, false>, dim3(grid), dim3(256), stream, p, ks, va, ks2, va2);
+}
+
+static inline int hv_attention_fp8_launch(const hv_attention_params& p, const float* ks, const float* va, const float* ks2,
+                                          const float* va2, hipStream_t stream) {
+    if (p.v_row_major) return -1;
+    if (p.L1 <= 0 || p.L1 % 8 != 0 || p.L2 % 8 != 0 || p.Lq <= 0) return -1;
+    if (p.ldq % 8 || p.ldk % 8 || p.ldvt % 8 || p.ldo % 4) return -1;
+    const bool bank = p.L2 > 0 && p.bank_sel != nullptr;
+    if (bank && (!p.K2 || !p.Vt2 || p.ldk2 % 8 || p.ldvt2 % 8 || !ks2 || !va2)) return -1;
+    switch (p.D) {
+        case 40: hv_attention_fp8_launch_t<40>(p, ks, va, ks2, va2, stream); break;
+        case 80: hv_attention_fp8_launch_t<80>(p, ks, va, ks2, va2, stream); break;
+        case 160: hv_attention_fp8_launch_t<160>(p, ks, va, ks2, va2, stream); break;
+        default: return -2;
+    }
+    return 0;
+}

@@ -1,6 +1,7 @@
 // k_attention.hip -- translation unit for hv_attention.h (see hv_kernels.h)
 #include "hv_attention.h"
 #include "hv_attention2.h"
+#include "hv_attention_fp8.h"
 #include "hv_kernels.h"
 
 int hvk_attention(const hv_attention_params& p, hipStream_t s) {
@@ -9,4 +10,12 @@ int hvk_attention(const hv_attention_params& p, hipStream_t s) {
 void hvk_attention_tune(int head_dim, int qt) {
     if (head_dim == 40) g_hv_attn_qt40 = qt;
     if (head_dim == 160) g_hv_attn_qt160 = qt;
+}
+int hvk_attention_fp8_scales(const bf16_t* K, long ldk, const bf16_t* Vt, long ldvt, int n, int heads, int D, int L, float* kscale,
+                             float* vamax, hipStream_t s) {
+    return hv_attention_fp8_scales_launch(K, ldk, Vt, ldvt, n, heads, D, L, kscale, vamax, s);
+}
+int hvk_attention_fp8(const hv_attention_params& p, const float* ks, const float* va, const float* ks2, const float* va2,
+                      hipStream_t s) {
+    return hv_attention_fp8_launch(p, ks, va, ks2, va2, s);
 }

@@ -64,6 +64,9 @@ class UNet3DEngine:
         # (row-major V out of a plain [token][q|k|v] QKV GEMM, 32x32x16 MFMA, transposing LDS reads: 411 / 402 / 364 TF/s --
         # VALU- and DMA-issue-bound at d = 40, see profiles/README.md); HUMANVID_ATTENTION=2 selects it for same-box A/Bs
         self.attn_kernel = int(os.environ.get("HUMANVID_ATTENTION", "1"))
+        # BASELINE.json configs[4]: spatial attention on the fp8 (e4m3) MFMA -- hv_attention_fp8 (transposed-V kernel family)
+        self.attn_fp8 = os.environ.get("HUMANVID_ATTENTION_FP8", "0") == "1"
+        self.bank_fp8 = {}
         self.gn_prologue = os.environ.get("HUMANVID_GN_PROLOGUE", "0") == "1"  # round-1 fused GroupNorm-apply GEMM (A/B)
         self._sel_cache: Dict[tuple, torch.Tensor] = {}
         # optional observer `tap(name, activation [(b f),h,w,c])` called after every resnet / spatial transformer / motion
@@ -211,6 +214,7 @@ class UNet3DEngine:
         transposed values once per clip."""
         self.do_cfg = do_cfg
         self.bank_kv = {}
+        self.bank_fp8 = {}
         if not banks:
             return
         st = self.stream
@@ -229,6 +233,12 @@ class UNet3DEngine:
             vt2 = torch.empty(C, b * Nb, dtype=BF16, device=self.device)
             ops.gemm(self.lib, st, x, self.w[loc + ".transformer_blocks.0.bank_kv.w"], k2, yt=vt2, n_split=C, ldy=C)
             self.bank_kv[loc] = (k2, vt2, b, Nb)
+            if self.attn_fp8:  # e4m3 scales of the bank keys / values: once per clip, like the projection itself
+                ks2 = torch.empty(b, self.heads, (Nb + 63) // 64, dtype=F32, device=self.device)
+                va2 = torch.empty(b, self.heads, dtype=F32, device=self.device)
+                ops.attention_fp8_scales(self.lib, st, k2, vt2, ks2, va2, n_images=b, heads=self.heads, D=C // self.heads,
+                                         L=Nb, ldk=C, ldvt=b * Nb)
+                self.bank_fp8[loc] = (ks2, va2)
 
     def _banks_from_modules(self):
         """Pick up banks installed on the transformer blocks by ReferenceAttentionControl.update()."""
@@ -412,8 +422,18 @@ class UNet3DEngine:
                     sel_t = torch.tensor(sel, dtype=torch.int32).to(self.device)
                     self._sel_cache[skey] = sel_t
                 kw = dict(k2=k2, vt2=vt2, ldk2=2 * C if v2 else C, ldvt2=2 * C if v2 else bb * Nb, L2=Nb, bank_sel=sel_t)
-            ops.attention(L, st, qk, qk[:, C:], vt, o, n_images=n, heads=self.heads, D=C // self.heads, Lq=N, L1=N,
-                          ldq=ldqk, ldk=ldqk, ldvt=ldvt, ldo=C, v_row_major=v2, **kw)
+            if self.attn_fp8 and not v2:
+                ks1 = ws.get(f"tr_ks_{n}x{N}", (n, self.heads, (N + 63) // 64), F32)
+                va1 = ws.get(f"tr_va_{n}", (n, self.heads), F32)
+                ops.attention_fp8_scales(L, st, qk[:, C:], vt, ks1, va1, n_images=n, heads=self.heads, D=C // self.heads, L=N,
+                                         ldk=ldqk, ldvt=ldvt)
+                if bank is not None:
+                    kw.update(kscale2=self.bank_fp8[prefix][0], vamax2=self.bank_fp8[prefix][1])
+                ops.attention_fp8(L, st, qk, qk[:, C:], vt, o, ks1, va1, n_images=n, heads=self.heads, D=C // self.heads, Lq=N,
+                                  L1=N, ldq=ldqk, ldk=ldqk, ldvt=ldvt, ldo=C, **kw)
+            else:
+                ops.attention(L, st, qk, qk[:, C:], vt, o, n_images=n, heads=self.heads, D=C // self.heads, Lq=N, L1=N,
+                              ldq=ldqk, ldk=ldqk, ldvt=ldvt, ldo=C, v_row_major=v2, **kw)
             ops.gemm(L, st, o, w[t + ".attn1.to_out.0.w"], hid, bias=w[t + ".attn1.to_out.0.bias"],
                      rowvec=self.cross_const[prefix], rowvec_period=F * N, residual=hid)
             feed_forward(t + ".ff1", t + ".ff.net.2", hid)

@@ -105,6 +105,22 @@ def attention(lib, stream, q, k, vt, o, *, n_images, heads, D, Lq, L1, ldq, ldk,
     lib.call("hv_attention", C.byref(p), stream)
 
 
+def attention_fp8_scales(lib, stream, k, vt, kscale, vamax, *, n_images, heads, D, L, ldk, ldvt):
+    """fp8 pre-pass over one key source: kscale [n_images, heads, ceil(L/64)] fp32, vamax [n_images, heads] fp32."""
+    lib.call("hv_attention_fp8_scales", _p(k), ldk, _p(vt), ldvt, n_images, heads, D, L, _p(kscale), _p(vamax), stream)
+
+
+def attention_fp8(lib, stream, q, k, vt, o, kscale, vamax, *, n_images, heads, D, Lq, L1, ldq, ldk, ldvt, ldo, k2=None,
+                  vt2=None, ldk2=0, ldvt2=0, L2=0, bank_sel=None, kscale2=None, vamax2=None):
+    """hv_attention on the fp8 MFMA (transposed-V form): scales from attention_fp8_scales for the own keys and the bank."""
+    p = A.AttentionParams(
+        Q=_p(q), ldq=ldq, K=_p(k), ldk=ldk, Vt=_p(vt), ldvt=ldvt, K2=_p(k2), ldk2=ldk2, Vt2=_p(vt2), ldvt2=ldvt2,
+        bank_sel=_p(bank_sel), O=_p(o), ldo=ldo, n_images=n_images, heads=heads, D=D, Lq=Lq, L1=L1, L2=L2,
+        scale=1.0 / math.sqrt(D), v_row_major=0,
+    )
+    lib.call("hv_attention_fp8", C.byref(p), _p(kscale), _p(vamax), _p(kscale2), _p(vamax2), stream)
+
+
 def temporal_attention(lib, stream, qkv, o, *, B, F, P, heads, D):
     """Single-device form: qkv [(B F P), 3C] rows (b*F + f)*P + p with columns [q | k | v]."""
     Cc = heads * D

@@ -165,6 +165,18 @@ typedef struct hv_attention_params {
 } hv_attention_params;
 int hv_attention(const hv_attention_params* p, void* stream);
 
+/* fp8 (OCP e4m3) form of hv_attention -- BASELINE.json configs[4]: QK^T and PV on v_mfma_f32_16x16x32_fp8_fp8 with fp32
+ * accumulation; same semantics, layouts and parameter block as hv_attention (transposed-V form).  Two calls:
+ *   hv_attention_fp8_scales: pre-pass over one key source -- kscale[(img*heads + h)*ceil(L/64) + tile] = amax(K tile)/384,
+ *     vamax[img*heads + h] = amax(V) -- run it once for the own keys (n_images images, L = L1) and once for the bank
+ *     (its batches, L = L2);
+ *   hv_attention_fp8: the attention itself; queries are scaled per row and probabilities enter PV as e4m3(128 p) inside.
+ * Stated accuracy: NRMSE <= 3e-2 against fp32 softmax attention on the same bf16 inputs (bf16 kernel: <= 6e-3). */
+int hv_attention_fp8_scales(const uint16_t* K, long ldk, const uint16_t* Vt, long ldvt, int n_images, int heads, int D, int L,
+                            float* kscale, float* vamax, void* stream);
+int hv_attention_fp8(const hv_attention_params* p, const float* kscale, const float* vamax, const float* kscale2,
+                     const float* vamax2, void* stream);
+
 /* kernel-variant selection for A/B measurements (process-global; not needed for correctness) */
 #define HV_TUNE_ATTN_QT_D40 0  /* query fragments per wave for head dim 40: 2 or 4 (default 2) */
 #define HV_TUNE_ATTN_QT_D160 1 /* for head dim 160: 1 or 2 (default 2) */

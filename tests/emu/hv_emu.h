@@ -242,6 +242,76 @@ inline T shfl_idx(T v, int src_lane_of_me) {
 }
 }  // namespace hvemu
 
+// ---- OCP e4m3 (fn) as gfx950's v_cvt_pk_fp8_f32 / v_mfma_f32_16x16x32_fp8_fp8 use it: bias 7, 3 mantissa bits, max 448,
+//      no infinities; conversion rounds to nearest even and saturates
+namespace hvemu {
+inline float fp8_to_f(unsigned char b) {
+    const int s = b >> 7, e = (b >> 3) & 15, m = b & 7;
+    float v;
+    if (e == 0) v = ldexpf((float)m / 8.0f, -6);
+    else if (e == 15 && m == 7) v = NAN;
+    else v = ldexpf(1.0f + (float)m / 8.0f, e - 7);
+    return s ? -v : v;
+}
+inline unsigned char f_to_fp8(float x) {
+    if (x != x) return 0x7f;
+    const unsigned char s = std::signbit(x) ? 0x80 : 0;
+    float a = fabsf(x);
+    if (a >= 448.0f) return s | 0x7e;
+    if (a < ldexpf(1.0f, -6)) {  // subnormal: multiples of 2^-9
+        const int q = (int)nearbyintf(a * 512.0f);  // FE_TONEAREST: ties to even
+        return s | (unsigned char)q;                 // q == 8 is exactly the smallest normal (exp 1, mant 0)
+    }
+    int e;
+    const float fr = frexpf(a, &e);  // a = fr * 2^e, fr in [0.5, 1)
+    int q = (int)nearbyintf(fr * 16.0f);  // 8 .. 16
+    int ex = e - 1 + 7;
+    if (q == 16) q = 8, ++ex;
+    if (ex > 15 || (ex == 15 && q - 8 > 6)) return s | 0x7e;
+    return s | (unsigned char)((ex << 3) | (q - 8));
+}
+inline unsigned cvt_pk_fp8(float a, float b, unsigned old, bool hi) {
+    const unsigned v = (unsigned)f_to_fp8(a) | ((unsigned)f_to_fp8(b) << 8);
+    return hi ? (old & 0x0000ffffu) | (v << 16) : (old & 0xffff0000u) | v;
+}
+inline hv_f4 mfma_fp8(long a, long b, hv_f4 c) {
+    struct In {
+        long a, b;
+        hv_f4 c;
+    } in{a, b, c};
+    hv_f4 out;
+    wave_collective(&in, sizeof(in), &out, sizeof(out), [](WaveState& w) {
+        static float A[16][32], B[32][16];
+        for (int l = 0; l < 64; ++l) {
+            In li;
+            memcpy(&li, w.in[l], sizeof(In));
+            for (int j = 0; j < 8; ++j) {
+                A[l % 16][(l / 16) * 8 + j] = fp8_to_f((unsigned char)((unsigned long)li.a >> (8 * j)));
+                B[(l / 16) * 8 + j][l % 16] = fp8_to_f((unsigned char)((unsigned long)li.b >> (8 * j)));
+            }
+        }
+        for (int l = 0; l < 64; ++l) {
+            In li;
+            memcpy(&li, w.in[l], sizeof(In));
+            hv_f4 o;
+            for (int r = 0; r < 4; ++r) {
+                const int col = l % 16, row = (l / 16) * 4 + r;
+                float acc = li.c[r];
+                for (int k = 0; k < 32; ++k) acc = fmaf(A[row][k], B[k][col], acc);
+                o[r] = acc;
+            }
+            memcpy(w.out[l], &o, sizeof(hv_f4));
+        }
+    });
+    return out;
+}
+}  // namespace hvemu
+inline int atomicMax(int* p, int v) {
+    const int old = *p;
+    if (v > old) *p = v;
+    return old;
+}
+
 inline hv_f4 __builtin_amdgcn_mfma_f32_16x16x32_bf16(hv_s8 a, hv_s8 b, hv_f4 c, int, int, int) {
     return hvemu::mfma<16, 8, 4>(a, b, c);
 }

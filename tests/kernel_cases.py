@@ -310,7 +310,8 @@ def case_groupnorm(cx: Ctx, n=3, H=6, W=10, C1=320, C2=0, groups=32, seed=5, off
 
 
 # ----------------------------------------------------------------------------------------- attention
-def case_attention(cx: Ctx, D=40, n_img=4, Lq=72, Lb=40, seed=6, check=None, q_stride=1, row_major=False, spike=False):
+def case_attention(cx: Ctx, D=40, n_img=4, Lq=72, Lb=40, seed=6, check=None, q_stride=1, row_major=False, spike=False,
+                   fp8=False):
     """images [0, n/2) are CFG-unconditional (own keys only); the rest append bank batch 1.
     check / q_stride: images and query rows the CPU reference is evaluated on (the kernel runs everything).
     spike: keys in LATER tiles (own key 70+, bank key 3) are made strongly aligned with a few queries, so that those
@@ -353,13 +354,35 @@ def case_attention(cx: Ctx, D=40, n_img=4, Lq=72, Lb=40, seed=6, check=None, q_s
         vt = cx.bf(v.reshape(n_img * Lq, Cc).t())  # [C][n*Lq]
         k2 = cx.bf(kb.reshape(2 * Lb, Cc))
         vt2 = cx.bf(vb.reshape(2 * Lb, Cc).t())
-        ops.attention(cx.lib, cx.stream, qkv, qkv[:, Cc:], vt, o, n_images=n_img, heads=H, D=D, Lq=Lq, L1=Lq,
-                      ldq=2 * Cc, ldk=2 * Cc, ldvt=n_img * Lq, ldo=Cc, k2=k2, vt2=vt2, ldk2=Cc, ldvt2=2 * Lb, L2=Lb,
-                      bank_sel=cx.dev(sel))
+        kw = dict(n_images=n_img, heads=H, D=D, Lq=Lq, L1=Lq, ldq=2 * Cc, ldk=2 * Cc, ldvt=n_img * Lq, ldo=Cc, k2=k2, vt2=vt2,
+                  ldk2=Cc, ldvt2=2 * Lb, L2=Lb, bank_sel=cx.dev(sel))
+        if fp8:  # e4m3 QK^T / PV: scale pre-passes over the own keys and the bank, then the fp8 kernel
+            T1, T2 = (Lq + 63) // 64, (Lb + 63) // 64
+            ks1 = torch.zeros(n_img, H, T1, device=cx.device)
+            va1 = torch.zeros(n_img, H, device=cx.device)
+            ks2 = torch.zeros(2, H, T2, device=cx.device)
+            va2 = torch.zeros(2, H, device=cx.device)
+            ops.attention_fp8_scales(cx.lib, cx.stream, qkv[:, Cc:], vt, ks1, va1, n_images=n_img, heads=H, D=D, L=Lq,
+                                     ldk=2 * Cc, ldvt=n_img * Lq)
+            ops.attention_fp8_scales(cx.lib, cx.stream, k2, vt2, ks2, va2, n_images=2, heads=H, D=D, L=Lb, ldk=Cc, ldvt=2 * Lb)
+            ops.attention_fp8(cx.lib, cx.stream, qkv, qkv[:, Cc:], vt, o, ks1, va1, kscale2=ks2, vamax2=va2, **kw)
+            cx.sync()
+            amax = r(k).view(n_img, Lq, H, D)[:, :min(Lq, 64)].abs().amax(dim=(1, 3))  # first tile of every (image, head)
+            assert nrmse(ks1[:, :, 0], amax / 384.0) < 1e-6, "fp8 K scale"
+            assert nrmse(va1, r(v).view(n_img, Lq, H, D).abs().amax(dim=(1, 3))) < 1e-6, "fp8 V amax"
+        else:
+            ops.attention(cx.lib, cx.stream, qkv, qkv[:, Cc:], vt, o, **kw)
     cx.sync()
     assert torch.isfinite(o.float()).all()
     e = nrmse(o.view(n_img, Lq, Cc)[idx][:, ::q_stride], ref)
-    assert e < 6e-3, f"attention D={D} nrmse {e}"  # P is rounded to bf16 before P.V (as SDPA kernels do)
+    # bf16: P is rounded to bf16 before P.V (as SDPA kernels do).
+    # fp8: all four operands carry e4m3's 3 mantissa bits (rms rounding error 2^-4 / sqrt(3) = 3.6e-2 each).  On i.i.d. random
+    # q / k / v the output is an average of independent values, so relative probability errors show up undiminished in it:
+    # expected ~ sqrt(2 * 0.036^2 [QK^T] + 0.036^2 [P] + 0.036^2 [V]) ~ 7e-2 worst case, measured 4-5e-2; the bound on the
+    # DENOISER's output with fp8 attention (residual stream, structured activations) is the one that matters and is stated
+    # and tested separately (tests/test_gpu_fullwidth.py::test_fp8_attention_forward: <= 3e-2 against the fp32 oracle).
+    tol = 8e-2 if fp8 else 6e-3
+    assert e < tol, f"attention D={D} fp8={fp8} nrmse {e}"
     return e
 
 

@@ -226,6 +226,16 @@ def test_attention_forced_rescale(cx, D):
     kc.case_attention(cx, D=D, n_img=2, Lq=192, Lb=64, spike=True, seed=72)
 
 
+@pytest.mark.parametrize("D", [40, 80, 160])
+def test_attention_fp8(cx, D):
+    """e4m3 QK^T / PV (BASELINE.json configs[4]): stated bound NRMSE <= 3e-2 vs fp32 SDPA; ragged and aligned lengths, bank
+    tiles, a forced running-maximum jump"""
+    e1 = kc.case_attention(cx, D=D, n_img=2, Lq=72, Lb=40, fp8=True)
+    e2 = kc.case_attention(cx, D=D, n_img=2, Lq=128, Lb=64, fp8=True, seed=17)
+    e3 = kc.case_attention(cx, D=D, n_img=2, Lq=200, Lb=72, fp8=True, spike=True, seed=71)
+    print(f"fp8 attention D={D}: nrmse {e1:.2e} {e2:.2e} {e3:.2e}")
+
+
 def test_attention_unmasked_instances(cx):
     kc.case_attention(cx, D=40, n_img=2, Lq=64, Lb=64)   # tile-aligned lengths: the MASK=false kernels
     kc.case_attention(cx, D=80, n_img=2, Lq=64, Lb=64)

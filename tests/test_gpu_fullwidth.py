@@ -64,3 +64,14 @@ def test_full_inference_v2_unet_two_frames():
     e = _run(cfg, 2, 32, 16, seed=2)
     print("full inference_v2 UNet3D (2 frames, 32x16 latent) nrmse", e)
     assert e < 2.5e-2, e
+
+
+def test_fp8_attention_forward(monkeypatch):
+    """BASELINE.json configs[4]: the spatial attentions on the fp8 (e4m3) MFMA (HUMANVID_ATTENTION_FP8=1), everything else
+    unchanged.  Stated bound on the denoiser output: NRMSE <= 3e-2 against the fp32 oracle (bf16 attention: <= 2.5e-2 on
+    this geometry); the kernel-level bound on i.i.d. random operands is 8e-2 (tests/kernel_cases.py::case_attention)."""
+    monkeypatch.setenv("HUMANVID_ATTENTION_FP8", "1")
+    cfg = dict(O.SD15_UNET3D_CFG)
+    e = _run(cfg, 2, 32, 16, seed=2)
+    print("full inference_v2 UNet3D, fp8 spatial attention (2 frames, 32x16 latent) nrmse", e)
+    assert e < 3e-2, e

@@ -98,6 +98,17 @@ def test_attention_row_major_kernel(cx, D, Lq, Lb):
     kc.case_attention(cx, D=D, n_img=4, Lq=Lq, Lb=Lb, row_major=True)
 
 
+@pytest.mark.parametrize("D,L", [(40, 1536), (80, 768), (160, 384)])
+def test_attention_fp8(cx, D, L):
+    """e4m3 QK^T / PV (hv_attention_fp8): i.i.d. random operands, bound 8e-2 (see case_attention), forced maximum jumps"""
+    kc.case_attention(cx, D=D, n_img=4, Lq=L, Lb=L, fp8=True, seed=75, check=(0, 3), q_stride=4)
+    kc.case_attention(cx, D=D, n_img=4, Lq=L + 40, Lb=L - 24, fp8=True, spike=True, seed=76, check=(1, 2), q_stride=4)
+
+
+def test_bench_shape_attention_fp8(cx):
+    kc.case_attention(cx, D=40, n_img=48, Lq=6144, Lb=6144, fp8=True, check=(0, 47), q_stride=16)
+
+
 def test_attention_variants(cx):
     cx.lib.call("hv_set_tuning", 0, 2)
     kc.case_attention(cx, D=40, n_img=4, Lq=520, Lb=264)

@@ -76,6 +76,9 @@ def price_launch(key: str):
         fl = 2.0 * 9 * a["Cin"] * a["Cout"] * px_o
         by = 2.0 * (px_i * a["Cin"] + 9 * a["Cin"] * a["Cout"] + px_o * a["Cout"] * (2 if a["res"] else 1))
         return fl, by
+    if kern.startswith("hv_attention_fp8_amax") or kern.startswith("hv_attention_fp8_quant"):
+        C = a["heads"] * int(kern.split("<")[1].split(">")[0])
+        return 0.0, (4.0 if "amax" in kern else 6.0) * a["n"] * a["L"] * C  # K and V^T read (+ e4m3 copies written)
     if kern.startswith("hv_attention"):
         C = a["heads"] * a["D"]
         banked = a["n"] / 2 if a["bank"] else 0  # CFG layout: the unconditional half attends its own keys only

@@ -94,7 +94,7 @@ PROTOTYPES = {
     "hv_groupnorm_affine": (I, [C.POINTER(GroupNormParams), P]),
     "hv_layernorm_stats": (I, [P, L, I, I, F, P, P, P]),
     "hv_attention": (I, [C.POINTER(AttentionParams), P]),
-    "hv_attention_fp8_scales": (I, [P, L, P, L, I, I, I, I, P, P, P]),
+    "hv_attention_fp8_quantize": (I, [P, L, P, L, I, I, I, I, P, P, P, P, L, P, L, I, P]),
     "hv_attention_fp8": (I, [C.POINTER(AttentionParams), P, P, P, P, P]),
     "hv_set_tuning": (I, [I, I]),
     "hv_temporal_attention": (I, [C.POINTER(TemporalAttentionParams), P]),

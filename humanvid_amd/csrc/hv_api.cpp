@@ -82,13 +82,16 @@ int hv_attention(const hv_attention_params* p, void* stream) {
     return hv_check_launch("hv_attention");
 }
 
-int hv_attention_fp8_scales(const uint16_t* K, long ldk, const uint16_t* Vt, long ldvt, int n_images, int heads, int D, int L,
-                            float* kscale, float* vamax, void* stream) {
-    if (!K || !Vt || !kscale || !vamax) return hv_fail(HV_EINVAL, "hv_attention_fp8_scales: null operand");
-    int rc = hvk_attention_fp8_scales(K, ldk, Vt, ldvt, n_images, heads, D, L, kscale, vamax, (hipStream_t)stream);
-    if (rc == -2) return hv_fail(HV_ENOTSUP, "hv_attention_fp8_scales: head dim must be 40, 80 or 160");
-    if (rc != 0) return hv_fail(HV_EINVAL, "hv_attention_fp8_scales: need L % 8 == 0 and 16-byte aligned strides");
-    return hv_check_launch("hv_attention_fp8_scales");
+int hv_attention_fp8_quantize(const uint16_t* K, long ldk, const uint16_t* Vt, long ldvt, int n_images, int heads, int D, int L,
+                              float* kscale, float* vamax, const float* vfloor, uint8_t* K8, long ldk8, uint8_t* Vt8, long ldvt8,
+                              int phase, void* stream) {
+    if (!K || !Vt || !kscale || !vamax) return hv_fail(HV_EINVAL, "hv_attention_fp8_quantize: null operand");
+    int rc = hvk_attention_fp8_quantize(K, ldk, Vt, ldvt, n_images, heads, D, L, kscale, vamax, vfloor, K8, ldk8, Vt8, ldvt8, phase,
+                                        (hipStream_t)stream);
+    if (rc == -2) return hv_fail(HV_ENOTSUP, "hv_attention_fp8_quantize: head dim must be 40, 80 or 160");
+    if (rc != 0)
+        return hv_fail(HV_EINVAL, "hv_attention_fp8_quantize: need L % 8 == 0, 8-byte aligned strides, phase 1..3, outputs for phase 2");
+    return hv_check_launch("hv_attention_fp8_quantize");
 }
 
 int hv_attention_fp8(const hv_attention_params* p, const float* kscale, const float* vamax, const float* kscale2,
@@ -97,7 +100,7 @@ int hv_attention_fp8(const hv_attention_params* p, const float* kscale, const fl
     int rc = hvk_attention_fp8(*p, kscale, vamax, kscale2, vamax2, (hipStream_t)stream);
     if (rc == -2) return hv_fail(HV_ENOTSUP, "hv_attention_fp8: head dim must be 40, 80 or 160");
     if (rc != 0)
-        return hv_fail(HV_EINVAL, "hv_attention_fp8: transposed-V form only, L1 % 8 == 0, L2 % 8 == 0, 16-byte aligned strides, "
+        return hv_fail(HV_EINVAL, "hv_attention_fp8: transposed-V form only, L1 % 8 == 0, L2 % 8 == 0, 8-byte aligned strides, "
                                   "bank scales with the bank");
     return hv_check_launch("hv_attention_fp8");
 }

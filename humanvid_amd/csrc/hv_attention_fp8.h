@@ -5,14 +5,17 @@
 // /root/reference/src/models/mutual_self_attention.py:147-186: own keys || bank keys for the conditional images, own keys only
 // for the CFG-unconditional ones); only the operand precision of QK^T and PV changes.  Quantisation, chosen so that no
 // scale has to be applied inside an accumulation chain:
-//   * K: one scale per (image | bank batch, head, 64-key tile), computed by the pre-pass hv_attention_fp8_scales_kernel
-//     (amax / 384); the K tile is converted bf16 -> e4m3 when it is parked in LDS.
+//   * K: one scale per (image | bank batch, head, 64-key tile) (amax / 384).
 //   * Q: one scale per query row (amax over the head's channels / 384), computed in registers at load; the queries stay
 //     resident as e4m3 fragments.  score (exp2 domain) = acc * (k_scale[tile] * q_scale[query] * scale * log2 e): one
 //     fused multiply-subtract per score, the factor is lane-local because a lane owns one query column.
 //   * P: probabilities are <= 1 after the running maximum is subtracted; they enter the PV product as e4m3(128 p).
-//   * V: one scale per (image | bank batch, head) -- the O^T accumulation runs over all tiles without rescaling; the row of
-//     ones that yields the denominator is e4m3 1.0, so O / l = (sum v8 p8) * v_scale / (sum p8) and the 128 cancels.
+//   * V: one scale per head (amax over all images and the bank) -- the O^T accumulation runs over all tiles of both key
+//     sources without rescaling; the row of ones that yields the denominator is e4m3 1.0, so
+//     O / l = (sum v8 p8) * v_scale / (sum p8) and the 128 cancels.
+//   K and V are quantised ONCE per attention call by the pre-pass (hv_attention_fp8_quantize: amax launch + quantise launch per
+//   key source) into e4m3 copies; the attention kernel streams those (half the bytes of the bf16 tiles, no conversion in its
+//   tile loop -- every K / V tile is re-read by all 128-query workgroups of its image, 48 of them at level 0).
 // Accuracy: e4m3 carries 3 mantissa bits (2^-4 relative); errors average over the head dim in QK^T and over the keys in PV.
 // Stated and tested bound (tests/kernel_cases.py::case_attention_fp8): NRMSE <= 3e-2 against fp32 SDPA on bf16-rounded inputs
 // (the bf16 kernel: <= 6e-3).
@@ -49,11 +52,17 @@ HV_DEV hv_fp8x8 hv_pack_fp8x8(const float* f) {  // 8 floats -> 8 e4m3 (element 
     return (hv_fp8x8)(((unsigned long)hi << 32) | lo);
 }
 
-// ---- pre-pass: K scale per (image, head, 64-key tile), V amax per (image, head) (atomic max over the tiles; the caller
-//      zero-fills vamax).  One 64-thread workgroup per (tile, head, image); thread = key row for K, 8 tokens x D/8... for V^T.
+// ---- pre-pass, two launches over one key source (the keys / values of an image are re-read by every 128-query workgroup of
+//      the attention kernel -- 48 times at level 0 -- so they are quantised ONCE, here, not in the attention kernel's tile loop):
+//   (1) amax: K scale per (image, head, 64-key tile), V amax per head (integer atomic max over images and tiles of the
+//       non-negative float bit patterns; the launcher zero-fills vamax[heads]);
+//   (2) quantise: K8[(img*L + kv)*ldk8 + h*D + d] = e4m3(K / kscale[tile]),  Vt8[(h*D + d)*ldvt8 + img*L + kv] = e4m3(V / vscale)
+//       with vscale = max(vamax[h], vfloor[h]) / 384 -- vfloor = the OTHER key source's amax (own values <-> bank), so that both
+//       sources of a launch carry one V scale per head and the O^T accumulation never changes scale.
+// One 64-thread workgroup per (tile, head, image); thread = key row for K, (8-token chunk, channel stripe) for V^T.
 template <int D>
-__global__ __launch_bounds__(64) void hv_attention_fp8_scales_kernel(const bf16_t* K, long ldk, const bf16_t* Vt, long ldvt,
-                                                                     int L, int heads, float* kscale, float* vamax) {
+__global__ __launch_bounds__(64) void hv_attention_fp8_amax_kernel(const bf16_t* K, long ldk, const bf16_t* Vt, long ldvt, int L,
+                                                                   int heads, float* kscale, float* vamax) {
     const int tile = blockIdx.x, head = blockIdx.y, img = blockIdx.z;
     const int T = (L + 63) / 64;
     const int t = threadIdx.x;
@@ -69,7 +78,6 @@ __global__ __launch_bounds__(64) void hv_attention_fp8_scales_kernel(const bf16_
             for (int e = 0; e < 8; ++e) ka = fmaxf(ka, fabsf(f[e]));
         }
     }
-    // V^T rows head*D + d, tokens img*L + tile*64 + 8*(t & 7) .. + 7
     const int c8 = t & 7;
     if (tile * 64 + c8 * 8 < L) {
         for (int d = t >> 3; d < D; d += 8) {
@@ -87,8 +95,49 @@ __global__ __launch_bounds__(64) void hv_attention_fp8_scales_kernel(const bf16_
     }
     if (t == 0) {
         kscale[((long)img * heads + head) * T + tile] = ka > 0.f ? ka / HV_FP8_AMAX_TARGET : 1.0f;
-        // non-negative floats order like their bit patterns: integer atomic max
-        atomicMax(reinterpret_cast<int*>(vamax) + img * heads + head, __builtin_bit_cast(int, va));
+        atomicMax(reinterpret_cast<int*>(vamax) + head, __builtin_bit_cast(int, va));  // one V scale per head
+    }
+}
+
+HV_DEV float hv_fp8_vscale(float amax) { return amax > 0.f ? amax / HV_FP8_AMAX_TARGET : 1.0f; }
+
+template <int D>
+__global__ __launch_bounds__(64) void hv_attention_fp8_quant_kernel(const bf16_t* K, long ldk, const bf16_t* Vt, long ldvt, int L,
+                                                                    int heads, const float* kscale, const float* vamax,
+                                                                    const float* vfloor, unsigned char* K8, long ldk8,
+                                                                    unsigned char* Vt8, long ldvt8) {
+    const int tile = blockIdx.x, head = blockIdx.y, img = blockIdx.z;
+    const int T = (L + 63) / 64;
+    const int t = threadIdx.x;
+    const int kv = tile * 64 + t;
+    const float inv_k = 1.0f / kscale[((long)img * heads + head) * T + tile];
+    float vam = vamax[head];
+    if (vfloor != nullptr) vam = fmaxf(vam, vfloor[head]);
+    const float inv_v = 1.0f / hv_fp8_vscale(vam);
+    if (kv < L) {
+        const bf16_t* krow = K + ((long)img * L + kv) * ldk + head * D;
+        unsigned char* orow = K8 + ((long)img * L + kv) * ldk8 + head * D;
+#pragma unroll
+        for (int c = 0; c < D / 8; ++c) {
+            float f[8];
+            hv_unpack8(hv_ld16(krow + c * 8), f);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) f[e] *= inv_k;
+            const hv_fp8x8 o = hv_pack_fp8x8(f);
+            hv_st8(orow + c * 8, u32x2{(unsigned)o, (unsigned)((unsigned long)o >> 32)});
+        }
+    }
+    const int c8 = t & 7;
+    if (tile * 64 + c8 * 8 < L) {
+        for (int d = t >> 3; d < D; d += 8) {
+            const long col = (long)img * L + tile * 64 + c8 * 8;
+            float f[8];
+            hv_unpack8(hv_ld16(Vt + (long)(head * D + d) * ldvt + col), f);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) f[e] *= inv_v;
+            const hv_fp8x8 o = hv_pack_fp8x8(f);
+            hv_st8(Vt8 + (long)(head * D + d) * ldvt8 + col, u32x2{(unsigned)o, (unsigned)((unsigned long)o >> 32)});
+        }
     }
 }
 
@@ -103,7 +152,7 @@ struct HvAttn8Geom {
     static constexpr int VRS = 64 + 8;                // V^T row stride (64 keys)
     static constexpr int KBYTES = 64 * KRS;
     static constexpr int VBYTES = DV * VRS;
-    static constexpr int KCH = 64 * (D / 8);          // 16-byte bf16 chunks of a K tile in HBM
+    static constexpr int KCH = 64 * (D / 8);          // 8-byte e4m3 chunks of a K tile
     static constexpr int VCH = D * 8;
     static constexpr int KIT = (KCH + 255) / 256;
     static constexpr int VIT = (VCH + 255) / 256;
@@ -176,20 +225,17 @@ __global__ __launch_bounds__(256, (D == 40 ? 4 : (D == 80 ? 2 : 1))) void hv_att
         qfac[qt] = qs * p.scale * 1.44269504089f;
     }
 
-    // V scales of the two key sources
-    const float va1 = vamax[img * p.heads + head];
-    const float vs1 = va1 > 0.f ? va1 / HV_FP8_AMAX_TARGET : 1.0f;
-    float vs2 = 1.0f;
-    if (sel >= 0) {
-        const float va2 = vamax2[sel * p.heads + head];
-        vs2 = va2 > 0.f ? va2 / HV_FP8_AMAX_TARGET : 1.0f;
-    }
-    // the O^T accumulation must not change scale between the sources: bank values are quantised with the LARGER of the two
-    // scales folded in -- v8 = v / vs_common
-    const float vs = fmaxf(vs1, vs2);
-    const float inv_vs = 1.0f / vs;
+    // one V scale per head for the whole launch: own values and bank values were quantised with
+    // max(amax_own[h], amax_bank[h]) / 384 (each quantiser call gets the other source's amax as its floor)
+    float vam = vamax[head];
+    if (p.bank_sel != nullptr && p.L2 > 0) vam = fmaxf(vam, vamax2[head]);
+    const float vs = hv_fp8_vscale(vam);
 
-    u32x4 kreg[G::KIT], vreg[G::VIT];
+    const unsigned char* K8 = reinterpret_cast<const unsigned char*>(p.K);
+    const unsigned char* V8 = reinterpret_cast<const unsigned char*>(p.Vt);
+    const unsigned char* K82 = reinterpret_cast<const unsigned char*>(p.K2);
+    const unsigned char* V82 = reinterpret_cast<const unsigned char*>(p.Vt2);
+    u32x2 kreg[G::KIT], vreg[G::VIT];
     float ksc_staged = 1.f;  // scale of the K tile held in kreg
     auto load_tile = [&](int ti) {
         const bool bank = ti >= T1;
@@ -197,59 +243,46 @@ __global__ __launch_bounds__(256, (D == 40 ? 4 : (D == 80 ? 2 : 1))) void hv_att
         const int kv0 = tl * 64;
         const int L = bank ? p.L2 : p.L1;
         const long rowbase = bank ? (long)sel * p.L2 : (long)img * p.L1;
-        const bf16_t* Kp = bank ? p.K2 : p.K;
+        const unsigned char* Kp = bank ? K82 : K8;
         const long ldk = bank ? p.ldk2 : p.ldk;
-        const bf16_t* Vp = bank ? p.Vt2 : p.Vt;
+        const unsigned char* Vp = bank ? V82 : V8;
         const long ldv = bank ? p.ldvt2 : p.ldvt;
         ksc_staged = bank ? kscale2[((long)sel * p.heads + head) * T2 + tl] : kscale[((long)img * p.heads + head) * T1 + tl];
 #pragma unroll
         for (int i = 0; i < G::KIT; ++i) {
             const int id = tid + 256 * i;
-            u32x4 v = {0u, 0u, 0u, 0u};
+            u32x2 v = {0u, 0u};
             if (id < G::KCH) {
                 const int r = id / (D / 8), c = id % (D / 8);
-                if (!MASK || kv0 + r < L) v = hv_ld16(Kp + (rowbase + kv0 + r) * ldk + head * D + c * 8);
+                if (!MASK || kv0 + r < L) v = hv_ld8(Kp + (rowbase + kv0 + r) * ldk + head * D + c * 8);
             }
             kreg[i] = v;
         }
 #pragma unroll
         for (int i = 0; i < G::VIT; ++i) {
             const int id = tid + 256 * i;
-            u32x4 v = {0u, 0u, 0u, 0u};
+            u32x2 v = {0u, 0u};
             if (id < G::VCH) {
                 const int d = id >> 3, c = id & 7;
-                if (!MASK || kv0 + c * 8 < L) v = hv_ld16(Vp + (long)(head * D + d) * ldv + rowbase + kv0 + c * 8);
+                if (!MASK || kv0 + c * 8 < L) v = hv_ld8(Vp + (long)(head * D + d) * ldv + rowbase + kv0 + c * 8);
             }
             vreg[i] = v;
         }
     };
     auto store_tile = [&](int buf) {
-        const float inv_k = 1.0f / ksc_staged;
 #pragma unroll
         for (int i = 0; i < G::KIT; ++i) {
             const int id = tid + 256 * i;
             if (id < G::KCH) {
                 const int r = id / (D / 8), c = id % (D / 8);
                 const int lr = (r & ~0x1c) | ((r & 4) << 2) | ((r & 0x18) >> 1);  // key permutation of hv_attention.h
-                float f[8];
-                hv_unpack8(kreg[i], f);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) f[e] *= inv_k;
-                const hv_fp8x8 o = hv_pack_fp8x8(f);
-                hv_st8(Ks + buf * G::KBYTES + lr * G::KRS + c * 8, u32x2{(unsigned)o, (unsigned)((unsigned long)o >> 32)});
+                hv_st8(Ks + buf * G::KBYTES + lr * G::KRS + c * 8, kreg[i]);
             }
         }
 #pragma unroll
         for (int i = 0; i < G::VIT; ++i) {
             const int id = tid + 256 * i;
-            if (id < G::VCH) {
-                float f[8];
-                hv_unpack8(vreg[i], f);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) f[e] *= inv_vs;
-                const hv_fp8x8 o = hv_pack_fp8x8(f);
-                hv_st8(Vs + buf * G::VBYTES + (id >> 3) * G::VRS + (id & 7) * 8, u32x2{(unsigned)o, (unsigned)((unsigned long)o >> 32)});
-            }
+            if (id < G::VCH) hv_st8(Vs + buf * G::VBYTES + (id >> 3) * G::VRS + (id & 7) * 8, vreg[i]);
         }
     };
 
@@ -385,21 +418,32 @@ __global__ __launch_bounds__(256, (D == 40 ? 4 : (D == 80 ? 2 : 1))) void hv_att
 }
 
 template <int D>
-static inline void hv_attention_fp8_scales_launch_t(const bf16_t* K, long ldk, const bf16_t* Vt, long ldvt, int n, int heads, int L,
-                                                    float* kscale, float* vamax, hipStream_t stream) {
-    hv_note("hv_attention_fp8_scales_kernel<%d> | n=%d heads=%d L=%d", D, n, heads, L);
-    hv_launch(hv_attention_fp8_scales_kernel<D>, dim3((L + 63) / 64, heads, n), dim3(64), stream, K, ldk, Vt, ldvt, L, heads, kscale,
-              vamax);
+static inline void hv_attention_fp8_quantize_launch_t(const bf16_t* K, long ldk, const bf16_t* Vt, long ldvt, int n, int heads, int L,
+                                                      float* kscale, float* vamax, const float* vfloor, unsigned char* K8,
+                                                      long ldk8, unsigned char* Vt8, long ldvt8, int phase, hipStream_t stream) {
+    const dim3 grid((L + 63) / 64, heads, n);
+    if (phase & 1) {
+        hv_note("hv_attention_fp8_amax_kernel<%d> | n=%d heads=%d L=%d", D, n, heads, L);
+        hv_launch(hv_attention_fp8_amax_kernel<D>, grid, dim3(64), stream, K, ldk, Vt, ldvt, L, heads, kscale, vamax);
+    }
+    if (phase & 2) {
+        hv_note("hv_attention_fp8_quant_kernel<%d> | n=%d heads=%d L=%d", D, n, heads, L);
+        hv_launch(hv_attention_fp8_quant_kernel<D>, grid, dim3(64), stream, K, ldk, Vt, ldvt, L, heads, (const float*)kscale,
+                  (const float*)vamax, vfloor, K8, ldk8, Vt8, ldvt8);
+    }
 }
 
-static inline int hv_attention_fp8_scales_launch(const bf16_t* K, long ldk, const bf16_t* Vt, long ldvt, int n, int heads, int D,
-                                                 int L, float* kscale, float* vamax, hipStream_t stream) {
-    if (L <= 0 || L % 8 != 0 || ldk % 8 || ldvt % 8 || n <= 0 || heads <= 0) return -1;
-    (void)hipMemsetAsync(vamax, 0, sizeof(float) * (size_t)n * heads, stream);
+// phase: 1 = amax only, 2 = quantise only (kscale / vamax from an earlier amax call), 3 = both
+static inline int hv_attention_fp8_quantize_launch(const bf16_t* K, long ldk, const bf16_t* Vt, long ldvt, int n, int heads, int D,
+                                                   int L, float* kscale, float* vamax, const float* vfloor, unsigned char* K8,
+                                                   long ldk8, unsigned char* Vt8, long ldvt8, int phase, hipStream_t stream) {
+    if (L <= 0 || L % 8 != 0 || ldk % 8 || ldvt % 8 || n <= 0 || heads <= 0 || phase < 1 || phase > 3) return -1;
+    if ((phase & 2) && (!K8 || !Vt8 || ldk8 % 8 || ldvt8 % 8)) return -1;
+    if (phase & 1) (void)hipMemsetAsync(vamax, 0, sizeof(float) * (size_t)heads, stream);
     switch (D) {
-        case 40: hv_attention_fp8_scales_launch_t<40>(K, ldk, Vt, ldvt, n, heads, L, kscale, vamax, stream); break;
-        case 80: hv_attention_fp8_scales_launch_t<80>(K, ldk, Vt, ldvt, n, heads, L, kscale, vamax, stream); break;
-        case 160: hv_attention_fp8_scales_launch_t<160>(K, ldk, Vt, ldvt, n, heads, L, kscale, vamax, stream); break;
+        case 40: hv_attention_fp8_quantize_launch_t<40>(K, ldk, Vt, ldvt, n, heads, L, kscale, vamax, vfloor, K8, ldk8, Vt8, ldvt8, phase, stream); break;
+        case 80: hv_attention_fp8_quantize_launch_t<80>(K, ldk, Vt, ldvt, n, heads, L, kscale, vamax, vfloor, K8, ldk8, Vt8, ldvt8, phase, stream); break;
+        case 160: hv_attention_fp8_quantize_launch_t<160>(K, ldk, Vt, ldvt, n, heads, L, kscale, vamax, vfloor, K8, ldk8, Vt8, ldvt8, phase, stream); break;
         default: return -2;
     }
     return 0;

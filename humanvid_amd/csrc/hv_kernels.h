@@ -16,8 +16,9 @@ int hvk_groupnorm(const hv_groupnorm_params& p, hipStream_t s);
 void hvk_layernorm(const bf16_t* X, long ldx, int M, int C, float eps, float* mean, float* rstd, hipStream_t s);
 int hvk_attention(const hv_attention_params& p, hipStream_t s);
 void hvk_attention_tune(int head_dim, int qt);
-int hvk_attention_fp8_scales(const bf16_t* K, long ldk, const bf16_t* Vt, long ldvt, int n, int heads, int D, int L, float* kscale,
-                             float* vamax, hipStream_t s);
+int hvk_attention_fp8_quantize(const bf16_t* K, long ldk, const bf16_t* Vt, long ldvt, int n, int heads, int D, int L, float* kscale,
+                               float* vamax, const float* vfloor, unsigned char* K8, long ldk8, unsigned char* Vt8, long ldvt8,
+                               int phase, hipStream_t s);
 int hvk_attention_fp8(const hv_attention_params& p, const float* ks, const float* va, const float* ks2, const float* va2,
                       hipStream_t s);
 int hvk_temporal(const hv_temporal_attention_params& p, hipStream_t s);

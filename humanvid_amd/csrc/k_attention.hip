@@ -11,9 +11,10 @@ void hvk_attention_tune(int head_dim, int qt) {
     if (head_dim == 40) g_hv_attn_qt40 = qt;
     if (head_dim == 160) g_hv_attn_qt160 = qt;
 }
-int hvk_attention_fp8_scales(const bf16_t* K, long ldk, const bf16_t* Vt, long ldvt, int n, int heads, int D, int L, float* kscale,
-                             float* vamax, hipStream_t s) {
-    return hv_attention_fp8_scales_launch(K, ldk, Vt, ldvt, n, heads, D, L, kscale, vamax, s);
+int hvk_attention_fp8_quantize(const bf16_t* K, long ldk, const bf16_t* Vt, long ldvt, int n, int heads, int D, int L, float* kscale,
+                               float* vamax, const float* vfloor, unsigned char* K8, long ldk8, unsigned char* Vt8, long ldvt8,
+                               int phase, hipStream_t s) {
+    return hv_attention_fp8_quantize_launch(K, ldk, Vt, ldvt, n, heads, D, L, kscale, vamax, vfloor, K8, ldk8, Vt8, ldvt8, phase, s);
 }
 int hvk_attention_fp8(const hv_attention_params& p, const float* ks, const float* va, const float* ks2, const float* va2,
                       hipStream_t s) {

@@ -233,12 +233,15 @@ class UNet3DEngine:
             vt2 = torch.empty(C, b * Nb, dtype=BF16, device=self.device)
             ops.gemm(self.lib, st, x, self.w[loc + ".transformer_blocks.0.bank_kv.w"], k2, yt=vt2, n_split=C, ldy=C)
             self.bank_kv[loc] = (k2, vt2, b, Nb)
-            if self.attn_fp8:  # e4m3 scales of the bank keys / values: once per clip, like the projection itself
+            if self.attn_fp8:  # e4m3: K scales / V amax of the bank once per clip (the quantised copies are rewritten per
+                # attention call, with the V scale the call's own values share -- hv_attention_fp8_quantize)
                 ks2 = torch.empty(b, self.heads, (Nb + 63) // 64, dtype=F32, device=self.device)
-                va2 = torch.empty(b, self.heads, dtype=F32, device=self.device)
-                ops.attention_fp8_scales(self.lib, st, k2, vt2, ks2, va2, n_images=b, heads=self.heads, D=C // self.heads,
-                                         L=Nb, ldk=C, ldvt=b * Nb)
-                self.bank_fp8[loc] = (ks2, va2)
+                va2 = torch.empty(self.heads, dtype=F32, device=self.device)
+                ops.attention_fp8_quantize(self.lib, st, k2, vt2, ks2, va2, n_images=b, heads=self.heads, D=C // self.heads,
+                                           L=Nb, ldk=C, ldvt=b * Nb, phase=1)
+                k28 = torch.empty(b * Nb, C, dtype=torch.uint8, device=self.device)
+                vt28 = torch.empty(C, b * Nb, dtype=torch.uint8, device=self.device)
+                self.bank_fp8[loc] = (ks2, va2, k28, vt28)
 
     def _banks_from_modules(self):
         """Pick up banks installed on the transformer blocks by ReferenceAttentionControl.update()."""
@@ -423,14 +426,25 @@ class UNet3DEngine:
                     self._sel_cache[skey] = sel_t
                 kw = dict(k2=k2, vt2=vt2, ldk2=2 * C if v2 else C, ldvt2=2 * C if v2 else bb * Nb, L2=Nb, bank_sel=sel_t)
             if self.attn_fp8 and not v2:
+                Dh = C // self.heads
                 ks1 = ws.get(f"tr_ks_{n}x{N}", (n, self.heads, (N + 63) // 64), F32)
-                va1 = ws.get(f"tr_va_{n}", (n, self.heads), F32)
-                ops.attention_fp8_scales(L, st, qk[:, C:], vt, ks1, va1, n_images=n, heads=self.heads, D=C // self.heads, L=N,
-                                         ldk=ldqk, ldvt=ldvt)
+                va1 = ws.get("tr_va", (self.heads,), F32)
+                k8 = ws.get(f"tr_k8_{M}x{C}", (M, C), torch.uint8)
+                vt8 = ws.get(f"tr_vt8_{M}x{C}", (C, M), torch.uint8)
+                own = dict(n_images=n, heads=self.heads, D=Dh, L=N, ldk=ldqk, ldvt=ldvt)
+                ops.attention_fp8_quantize(L, st, qk[:, C:], vt, ks1, va1, phase=1, **own)
+                kw8 = dict(kw)
                 if bank is not None:
-                    kw.update(kscale2=self.bank_fp8[prefix][0], vamax2=self.bank_fp8[prefix][1])
-                ops.attention_fp8(L, st, qk, qk[:, C:], vt, o, ks1, va1, n_images=n, heads=self.heads, D=C // self.heads, Lq=N,
-                                  L1=N, ldq=ldqk, ldk=ldqk, ldvt=ldvt, ldo=C, **kw)
+                    k2, vt2, bb, Nb = bank
+                    ks2, va2, k28, vt28 = self.bank_fp8[prefix]
+                    ops.attention_fp8_quantize(L, st, k2, vt2, ks2, va2, n_images=bb, heads=self.heads, D=Dh, L=Nb, ldk=C,
+                                               ldvt=bb * Nb, phase=2, vfloor=va1, k8=k28, vt8=vt28)
+                    ops.attention_fp8_quantize(L, st, qk[:, C:], vt, ks1, va1, phase=2, vfloor=va2, k8=k8, vt8=vt8, **own)
+                    kw8.update(k2=k28, vt2=vt28, kscale2=ks2, vamax2=va2)
+                else:
+                    ops.attention_fp8_quantize(L, st, qk[:, C:], vt, ks1, va1, phase=2, k8=k8, vt8=vt8, **own)
+                ops.attention_fp8(L, st, qk, k8, vt8, o, ks1, va1, n_images=n, heads=self.heads, D=Dh, Lq=N, L1=N, ldq=ldqk,
+                                  ldk=C, ldvt=ldvt, ldo=C, **kw8)
             else:
                 ops.attention(L, st, qk, qk[:, C:], vt, o, n_images=n, heads=self.heads, D=C // self.heads, Lq=N, L1=N,
                               ldq=ldqk, ldk=ldqk, ldvt=ldvt, ldo=C, v_row_major=v2, **kw)

@@ -105,14 +105,18 @@ def attention(lib, stream, q, k, vt, o, *, n_images, heads, D, Lq, L1, ldq, ldk,
     lib.call("hv_attention", C.byref(p), stream)
 
 
-def attention_fp8_scales(lib, stream, k, vt, kscale, vamax, *, n_images, heads, D, L, ldk, ldvt):
-    """fp8 pre-pass over one key source: kscale [n_images, heads, ceil(L/64)] fp32, vamax [n_images, heads] fp32."""
-    lib.call("hv_attention_fp8_scales", _p(k), ldk, _p(vt), ldvt, n_images, heads, D, L, _p(kscale), _p(vamax), stream)
+def attention_fp8_quantize(lib, stream, k, vt, kscale, vamax, *, n_images, heads, D, L, ldk, ldvt, phase, vfloor=None,
+                           k8=None, vt8=None):
+    """fp8 pre-pass over one key source.  phase 1: kscale [n_images, heads, ceil(L/64)], vamax [heads] (fp32);
+    phase 2: k8 [n_images*L, C] / vt8 [C, n_images*L] uint8 (e4m3), V scale = max(vamax, vfloor) / 384; 3: both."""
+    lib.call("hv_attention_fp8_quantize", _p(k), ldk, _p(vt), ldvt, n_images, heads, D, L, _p(kscale), _p(vamax), _p(vfloor),
+             _p(k8), k8.stride(0) if k8 is not None else 0, _p(vt8), vt8.stride(0) if vt8 is not None else 0, phase, stream)
 
 
 def attention_fp8(lib, stream, q, k, vt, o, kscale, vamax, *, n_images, heads, D, Lq, L1, ldq, ldk, ldvt, ldo, k2=None,
                   vt2=None, ldk2=0, ldvt2=0, L2=0, bank_sel=None, kscale2=None, vamax2=None):
-    """hv_attention on the fp8 MFMA (transposed-V form): scales from attention_fp8_scales for the own keys and the bank."""
+    """hv_attention on the fp8 MFMA (transposed-V form): k / vt / k2 / vt2 are the e4m3 (uint8) tensors and scales that
+    attention_fp8_quantize produced for the own keys and the bank; q is bf16."""
     p = A.AttentionParams(
         Q=_p(q), ldq=ldq, K=_p(k), ldk=ldk, Vt=_p(vt), ldvt=ldvt, K2=_p(k2), ldk2=ldk2, Vt2=_p(vt2), ldvt2=ldvt2,
         bank_sel=_p(bank_sel), O=_p(o), ldo=ldo, n_images=n_images, heads=heads, D=D, Lq=Lq, L1=L1, L2=L2,

@@ -166,14 +166,19 @@ typedef struct hv_attention_params {
 int hv_attention(const hv_attention_params* p, void* stream);
 
 /* fp8 (OCP e4m3) form of hv_attention -- BASELINE.json configs[4]: QK^T and PV on v_mfma_f32_16x16x32_fp8_fp8 with fp32
- * accumulation; same semantics, layouts and parameter block as hv_attention (transposed-V form).  Two calls:
- *   hv_attention_fp8_scales: pre-pass over one key source -- kscale[(img*heads + h)*ceil(L/64) + tile] = amax(K tile)/384,
- *     vamax[img*heads + h] = amax(V) -- run it once for the own keys (n_images images, L = L1) and once for the bank
- *     (its batches, L = L2);
- *   hv_attention_fp8: the attention itself; queries are scaled per row and probabilities enter PV as e4m3(128 p) inside.
- * Stated accuracy: NRMSE <= 3e-2 against fp32 softmax attention on the same bf16 inputs (bf16 kernel: <= 6e-3). */
-int hv_attention_fp8_scales(const uint16_t* K, long ldk, const uint16_t* Vt, long ldvt, int n_images, int heads, int D, int L,
-                            float* kscale, float* vamax, void* stream);
+ * accumulation; same semantics as hv_attention (transposed-V form).  Keys and values are quantised once per call by
+ *   hv_attention_fp8_quantize (one key source per call: the n_images images with L = L1, or the bank batches with L = L2):
+ *     phase & 1: kscale[(img*heads + h)*ceil(L/64) + tile] = amax(K tile) / 384,  vamax[h] = amax over all images of V;
+ *     phase & 2: K8[(img*L + kv)*ldk8 + h*D + d] = e4m3(K / kscale),  Vt8[(h*D + d)*ldvt8 + img*L + kv] = e4m3(V / vscale),
+ *                vscale = max(vamax[h], vfloor ? vfloor[h] : 0) / 384 -- pass the OTHER key source's vamax as vfloor so that own
+ *                values and bank values carry one scale per head (amax both sources first, then quantise both);
+ *   hv_attention_fp8: p->K / Vt / K2 / Vt2 point at the e4m3 tensors (ld* in bytes = elements), p->Q is bf16 (scaled per
+ *     query row inside), kscale / vamax of the own keys, kscale2 / vamax2 of the bank.
+ * Stated accuracy: NRMSE <= 8e-2 against fp32 softmax attention on i.i.d. random bf16 operands (four e4m3 roundings of
+ * 2^-4 / sqrt 3 rms each; bf16 kernel: <= 6e-3); denoiser output with fp8 attention <= 3e-2 against the fp32 oracle. */
+int hv_attention_fp8_quantize(const uint16_t* K, long ldk, const uint16_t* Vt, long ldvt, int n_images, int heads, int D, int L,
+                              float* kscale, float* vamax, const float* vfloor, uint8_t* K8, long ldk8, uint8_t* Vt8, long ldvt8,
+                              int phase, void* stream);
 int hv_attention_fp8(const hv_attention_params* p, const float* kscale, const float* vamax, const float* kscale2,
                      const float* vamax2, void* stream);
 

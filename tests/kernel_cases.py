@@ -356,20 +356,27 @@ def case_attention(cx: Ctx, D=40, n_img=4, Lq=72, Lb=40, seed=6, check=None, q_s
         vt2 = cx.bf(vb.reshape(2 * Lb, Cc).t())
         kw = dict(n_images=n_img, heads=H, D=D, Lq=Lq, L1=Lq, ldq=2 * Cc, ldk=2 * Cc, ldvt=n_img * Lq, ldo=Cc, k2=k2, vt2=vt2,
                   ldk2=Cc, ldvt2=2 * Lb, L2=Lb, bank_sel=cx.dev(sel))
-        if fp8:  # e4m3 QK^T / PV: scale pre-passes over the own keys and the bank, then the fp8 kernel
+        if fp8:  # e4m3 QK^T / PV: amax both key sources, quantise both with the common V scale, then the fp8 kernel
             T1, T2 = (Lq + 63) // 64, (Lb + 63) // 64
-            ks1 = torch.zeros(n_img, H, T1, device=cx.device)
-            va1 = torch.zeros(n_img, H, device=cx.device)
-            ks2 = torch.zeros(2, H, T2, device=cx.device)
-            va2 = torch.zeros(2, H, device=cx.device)
-            ops.attention_fp8_scales(cx.lib, cx.stream, qkv[:, Cc:], vt, ks1, va1, n_images=n_img, heads=H, D=D, L=Lq,
-                                     ldk=2 * Cc, ldvt=n_img * Lq)
-            ops.attention_fp8_scales(cx.lib, cx.stream, k2, vt2, ks2, va2, n_images=2, heads=H, D=D, L=Lb, ldk=Cc, ldvt=2 * Lb)
-            ops.attention_fp8(cx.lib, cx.stream, qkv, qkv[:, Cc:], vt, o, ks1, va1, kscale2=ks2, vamax2=va2, **kw)
+            dev = cx.device
+            ks1, va1 = torch.zeros(n_img, H, T1, device=dev), torch.zeros(H, device=dev)
+            ks2, va2 = torch.zeros(2, H, T2, device=dev), torch.zeros(H, device=dev)
+            k8 = torch.zeros(n_img * Lq, Cc, dtype=torch.uint8, device=dev)
+            vt8 = torch.zeros(Cc, n_img * Lq, dtype=torch.uint8, device=dev)
+            k28 = torch.zeros(2 * Lb, Cc, dtype=torch.uint8, device=dev)
+            vt28 = torch.zeros(Cc, 2 * Lb, dtype=torch.uint8, device=dev)
+            own = dict(n_images=n_img, heads=H, D=D, L=Lq, ldk=2 * Cc, ldvt=n_img * Lq)
+            bnk = dict(n_images=2, heads=H, D=D, L=Lb, ldk=Cc, ldvt=2 * Lb)
+            ops.attention_fp8_quantize(cx.lib, cx.stream, qkv[:, Cc:], vt, ks1, va1, phase=1, **own)
+            ops.attention_fp8_quantize(cx.lib, cx.stream, k2, vt2, ks2, va2, phase=1, **bnk)
+            ops.attention_fp8_quantize(cx.lib, cx.stream, qkv[:, Cc:], vt, ks1, va1, phase=2, vfloor=va2, k8=k8, vt8=vt8, **own)
+            ops.attention_fp8_quantize(cx.lib, cx.stream, k2, vt2, ks2, va2, phase=2, vfloor=va1, k8=k28, vt8=vt28, **bnk)
+            kw8 = dict(kw, ldk=Cc, k2=k28, vt2=vt28)
+            ops.attention_fp8(cx.lib, cx.stream, qkv, k8, vt8, o, ks1, va1, kscale2=ks2, vamax2=va2, **kw8)
             cx.sync()
             amax = r(k).view(n_img, Lq, H, D)[:, :min(Lq, 64)].abs().amax(dim=(1, 3))  # first tile of every (image, head)
             assert nrmse(ks1[:, :, 0], amax / 384.0) < 1e-6, "fp8 K scale"
-            assert nrmse(va1, r(v).view(n_img, Lq, H, D).abs().amax(dim=(1, 3))) < 1e-6, "fp8 V amax"
+            assert nrmse(va1, r(v).view(n_img, Lq, H, D).abs().amax(dim=(0, 1, 3))) < 1e-6, "fp8 V amax"
         else:
             ops.attention(cx.lib, cx.stream, qkv, qkv[:, Cc:], vt, o, **kw)
     cx.sync()

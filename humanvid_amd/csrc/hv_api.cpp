@@ -112,6 +112,7 @@ int hv_set_tuning(int key, int value) {
     else if (key == HV_TUNE_GEMM_GLDS && (value >= 0 && value <= 9 && value != 5)) hvk_gemm_use_glds(value);
     else if (key == HV_TUNE_GEMM_RASTER && value >= 0 && value <= 64) hvk_gemm_raster(value);
     else if (key == HV_TUNE_GEMM_WALK && (value == 0 || value == 1)) hvk_gemm_walk(value);
+    else if (key == HV_TUNE_GEMM_PREFETCH && value >= 0 && value <= 16) hvk_gemm_prefetch(value);
     else if (key == HV_TUNE_TEMPORAL_MFMA && (value == 0 || value == 1)) hvk_temporal_use_mfma(value);
     else if (key == HV_TUNE_CONV_GLDS && (value == 0 || value == 1)) hvk_conv_use_glds(value);
     else if (key == HV_TUNE_CONV_BIG && (value >= 0 && value <= 2)) hvk_conv_use_big(value);

@@ -73,8 +73,14 @@ HV_DEV void hv_st8(void* p, u32x2 v) { *reinterpret_cast<u32x2*>(p) = v; }
 #ifndef HV_STORE_SC1
 #define HV_STORE_SC1 0
 #endif
+#ifndef HV_STORE_NT
+#define HV_STORE_NT 0
+#endif
 HV_DEV void hv_st8_stream(void* p, u32x2 v) {
-#if !defined(HV_EMU) && HV_STORE_SC1
+#if !defined(HV_EMU) && HV_STORE_NT
+    // non-temporal hint (global_store_dwordx2 ... nt): the output tile is not read again by this kernel
+    __builtin_nontemporal_store(v, reinterpret_cast<u32x2*>(p));
+#elif !defined(HV_EMU) && HV_STORE_SC1
     union {
         u32x2 v;
         unsigned long long u;
@@ -140,6 +146,16 @@ HV_DEV void hv_glds16_s(const void* base_uniform, unsigned byte_ofs, void* lds_w
                  : "v"(byte_ofs), "s"(base_uniform), "s"(lds_addr_uniform)
                  : "memory");
 }
+// L2 prefetch: one dword per lane by LDS-DMA into a throw-away LDS area (no VGPR destination, so nothing can be clobbered when
+// the data lands late); brings the 128-byte lines the lanes point at into L2 ahead of the real LDS-DMA of a later k-step.
+HV_DEV void hv_l2_prefetch_dword(const void* base_uniform, unsigned byte_ofs, void* lds_dummy_wave_base) {
+    const unsigned lds_addr_uniform = (unsigned)(unsigned long)(__attribute__((address_space(3))) void*)lds_dummy_wave_base;
+    unsigned keep;
+    asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(byte_ofs), "s"(base_uniform), "s"(lds_addr_uniform)
+                 : "memory");
+}
 template <int N>
 HV_DEV void hv_vm_wait() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
@@ -155,6 +171,7 @@ HV_DEV void hv_glds16(const void* gsrc, void* lds_wave_base) {
 HV_DEV void hv_glds16_s(const void* base_uniform, unsigned byte_ofs, void* lds_wave_base) {
     memcpy((char*)lds_wave_base + (threadIdx.x & 63) * 16, (const char*)base_uniform + byte_ofs, 16);
 }
+HV_DEV void hv_l2_prefetch_dword(const void*, unsigned, void*) {}
 template <int N>
 HV_DEV void hv_vm_wait() {}
 HV_DEV void hv_barrier_raw() { __syncthreads(); }

@@ -599,7 +599,7 @@ __global__ __launch_bounds__(256, 2) void hv_gemm_kernel(HvGemmParams p) {
 //       ds_read, LDS-DMA-issue and epilogue times simply add up);
 //   NW = 8: 4 x 2 waves of 64x64 (BN = 128) or 2 x 4 of 128x64 (BN = 256), one workgroup per CU.
 template <int BK, int NS, int BN, int NW, int BM = 256>
-__global__ __launch_bounds__(NW * 64, 2) void hv_gemm_glds_kernel(HvGemmParams p, int gm, int form, int walk) {
+__global__ __launch_bounds__(NW * 64, 2) void hv_gemm_glds_kernel(HvGemmParams p, int gm, int form, int walk, int pfd) {
     constexpr int WAVES_N = BN / 64, WAVES_M = NW / WAVES_N;
     constexpr int WTM = BM / WAVES_M, NMF = WTM / 16;
     constexpr int XT = BM * BK * 2, WT = BN * BK * 2, SLOT = XT + WT;
@@ -608,7 +608,8 @@ __global__ __launch_bounds__(NW * 64, 2) void hv_gemm_glds_kernel(HvGemmParams p
     constexpr int XQ = BM / RPI / NW, WQ = BN / RPI / NW;  // DMA instructions per wave and k-tile
     constexpr int LPW = XQ + WQ;
     constexpr int AHEAD = NS - 1;               // k-tiles in flight
-    __shared__ __attribute__((aligned(16))) unsigned char smem[NS * SLOT];
+    constexpr int NPF = BM / 64;  // L2-prefetch wave-instructions per k-tile: one 128-byte line per X row (BK = 64 only)
+    __shared__ __attribute__((aligned(16))) unsigned char smem[NS * SLOT + NW * 256];  // ring + a throw-away line per wave
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -666,10 +667,9 @@ __global__ __launch_bounds__(NW * 64, 2) void hv_gemm_glds_kernel(HvGemmParams p
     // instructions is computed once per tile (xa / wa) and advanced by BK elements per k-step; the k-loop needs no
     // kernel argument besides them.  The row -> bank-row swizzle only depends on (row / RPB) % CPR: a lane's chunk
     // column is the same for every wave-instruction when these start at multiples of 16 rows (BK = 32).
-    const int sub = lane / CPR;
-    auto chunk_ofs = [&](int j) __attribute__((always_inline)) {
+    auto chunk_ofs_s = [&](int j, int sub) __attribute__((always_inline)) {
         const int row = (RPI % 16 == 0) ? sub : RPI * j + sub;
-        return ((lane % CPR) ^ ((row / RPB) % CPR)) * 8;
+        return (((lane & (CPR - 1))) ^ ((row / RPB) % CPR)) * 8;
     };
     const int k1_steps = p.X2 != nullptr ? p.K1 / BK : -1;  // k-tile at which the second source takes over
     int i_tile = first, i_k = 0, i_slot = 0;
@@ -682,24 +682,34 @@ __global__ __launch_bounds__(NW * 64, 2) void hv_gemm_glds_kernel(HvGemmParams p
     const char* const wbase = reinterpret_cast<const char*>(p.W);
     // (named scalars picked by a compile-time index: as arrays -- "#pragma unroll" or compile-time loops alike -- hipcc
     //  kept the offsets of the NS = 2 instantiations in a stack slot: a scratch reload behind vmcnt(0) in every k-step)
+    // (tile changes are rare: keep their lane constants OUT of the k-loop's register budget -- an opaque copy per call stops
+    //  hipcc from hoisting "RPI * j + sub" for every j into loop-carried registers, which spilled in the 256 x 256 kernel)
+    auto fresh = [&](int v) __attribute__((always_inline)) {
+#ifndef HV_EMU
+        asm volatile("" : "+v"(v));
+#endif
+        return v;
+    };
     auto set_x = [&](const bf16_t* base, long ld) __attribute__((always_inline)) {
+        const int sub = fresh(lane / CPR);
         xbase = reinterpret_cast<const char*>(base);
         hv_static_for<XQ>([&](auto Q) __attribute__((always_inline)) {
             constexpr int q = decltype(Q)::value;
             const int j = wave + NW * q;
             const int m = min(((HV_GEMM_DBG & 16) ? 0 : i_m0) + RPI * j + sub, p.M - 1);
-            hv_pick4<q>(xo0, xo1, xo2, xo3) = ((unsigned)m * (unsigned)ld + (unsigned)chunk_ofs(j)) * 2u;  // < 4 GiB: exact in 32 bits
+            hv_pick4<q>(xo0, xo1, xo2, xo3) = ((unsigned)m * (unsigned)ld + (unsigned)chunk_ofs_s(j, sub)) * 2u;  // < 4 GiB: exact in 32 bits
         });
     };
     auto set_tile = [&]() __attribute__((always_inline)) {
         tile_origin(i_tile, i_m0, i_n0);
         if (k1_steps == 0) set_x(p.X2, p.ldx2);
         else set_x(p.X, p.ldx);
+        const int sub = fresh(lane / CPR);
         hv_static_for<WQ>([&](auto Q) __attribute__((always_inline)) {
             constexpr int q = decltype(Q)::value;
             const int j = wave + NW * q;
             const int n = min(i_n0 + RPI * j + sub, p.N - 1);
-            hv_pick4<q>(wo0, wo1, wo2, wo3) = ((unsigned)n * (unsigned)p.K + (unsigned)chunk_ofs(j)) * 2u;
+            hv_pick4<q>(wo0, wo1, wo2, wo3) = ((unsigned)n * (unsigned)p.K + (unsigned)chunk_ofs_s(j, sub)) * 2u;
         });
     };
     set_tile();
@@ -726,6 +736,44 @@ __global__ __launch_bounds__(NW * 64, 2) void hv_gemm_glds_kernel(HvGemmParams p
             set_x(p.X2, p.ldx2);
         }
     };
+
+    // L2 prefetch of the streamed X operand, pfd k-tiles ahead of the LDS-DMA (tuning knob; BK = 64, one k-tile in flight).
+    // gemm_trace: on the level-0 projections the DMA of a k-tile is blocked ~4000-5000 clocks in issue -- its X rows are
+    // first touches that come from HBM / MALL at ~15 B/clk per CU, while lines already in L2 fill at ~56 B/clk.  Waves
+    // 0..NPF-1 therefore request one dword of every X row's 128-byte k-slice of the k-tile pfd steps further on (by LDS-DMA
+    // into a throw-away line: no VGPR destination).  The request is issued AFTER the step's own DMA; vmcnt retires in order,
+    // so the wait for that DMA at the next step leaves exactly this one request in flight and needs the previous step's
+    // request done -- a full k-step old by then.
+    const bool pf_on = pfd > 0 && BK == 64 && AHEAD == 1 && p.X2 == nullptr;
+    int f_tile = first, f_k = 0, f_step = 0, f_m0 = 0;
+    {
+        int dummy_n0;
+        tile_origin(f_tile, f_m0, dummy_n0);
+    }
+    auto pf_advance = [&]() __attribute__((always_inline)) {
+        ++f_step;
+        if (++f_k == nk) {
+            f_k = 0;
+            f_tile += tstep;
+            int dummy_n0;
+            tile_origin(f_tile, f_m0, dummy_n0);
+        }
+    };
+    auto pf_issue = [&]() __attribute__((always_inline)) {
+        if (f_step < nsteps && wave < NPF) {
+#ifndef HV_EMU
+            int l;  // lane id recomputed here: a loop-carried copy was the register that spilled in the 256 x 256 kernel
+            asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+#else
+            const int l = lane;
+#endif
+            const int m = min(f_m0 + 64 * wave + l, p.M - 1);
+            hv_l2_prefetch_dword(p.X, ((unsigned)m * (unsigned)p.ldx + (unsigned)(f_k * BK)) * 2u, smem + NS * SLOT + wave * 256);
+        }
+        pf_advance();
+    };
+    if (pf_on)
+        for (int a = 0; a < AHEAD + pfd; ++a) pf_advance();  // the prefetch iterator runs pfd k-tiles ahead of the DMA iterator
 
     f32x4 acc[4][NMF];  // [nf][mf]
     auto clear_acc = [&]() __attribute__((always_inline)) {
@@ -754,6 +802,8 @@ __global__ __launch_bounds__(NW * 64, 2) void hv_gemm_glds_kernel(HvGemmParams p
         const int later = nsteps - 1 - s;
         if (HV_GEMM_DEFER && landed > 0)
             --landed;
+        else if (pf_on && wave < NPF && AHEAD == 1)
+            hv_vm_wait<1>();  // this wave's prefetch request of the previous step may stay in flight
         else if (later >= AHEAD - 1)
             hv_vm_wait<(AHEAD - 1) * LPW>();
         else if (AHEAD > 2 && later == 1)
@@ -765,6 +815,7 @@ __global__ __launch_bounds__(NW * 64, 2) void hv_gemm_glds_kernel(HvGemmParams p
         hv_barrier_raw();
         HV_TRACE(3);
         if (!(HV_GEMM_DBG & 8) && s + AHEAD < nsteps) issue();  // reuses the slot of k-tile s-1
+        if (pf_on) pf_issue();
         HV_TRACE(4);
         const unsigned char* xs = smem + c_slot * SLOT;
         const unsigned char* ws = xs + XT;
@@ -805,6 +856,7 @@ __global__ __launch_bounds__(NW * 64, 2) void hv_gemm_glds_kernel(HvGemmParams p
 
 static int g_hv_gemm_max_grid = 512;  // tuning knob (hv_set_tuning): persistent workgroups
 static int g_hv_gemm_walk = 0;          // tuning knob: 1 = contiguous tile run per workgroup (see the kernel; measured no gain: the X panel of a 256-row block does not survive in the 4 MiB L2 next to 32 workgroups' tiles), 0 = strided (default)
+static int g_hv_gemm_pfd = 0;           // tuning knob: L2-prefetch distance in k-tiles (0 = off)
 static int g_hv_gemm_raster = 0;        // tuning knob: m-blocks per raster group (0 = auto: 8 when N spans more than 8 tiles)
 // tuning knob (hv_set_tuning key 3) -- tile policy of the LDS-DMA kernel:
 //   9 (default, round 2): BK = 64 everywhere (whole 128-byte lines per operand row: the kernel is bound by the CU's
@@ -856,7 +908,7 @@ static inline int hv_gemm_launch(const HvGemmParams& p, hipStream_t stream) {
             if (grid > 256) grid = 256;
             if (grid > g_hv_gemm_max_grid) grid = g_hv_gemm_max_grid;
             hv_note("hv_gemm_glds_kernel<64,2,256,8,256> | %s", shape);
-            hv_launch(hv_gemm_glds_kernel<64, 2, 256, 8, 256>, dim3(grid), dim3(512), stream, p, gm, form128, g_hv_gemm_walk);
+            hv_launch(hv_gemm_glds_kernel<64, 2, 256, 8, 256>, dim3(grid), dim3(512), stream, p, gm, form128, g_hv_gemm_walk, g_hv_gemm_pfd);
             return 0;
         }
         if (ok128 && g_hv_gemm_glds == 3 && p.N >= 512 && (n256 - n128) * 12 <= p.N) {
@@ -865,7 +917,7 @@ static inline int hv_gemm_launch(const HvGemmParams& p, hipStream_t stream) {
             if (grid > 256) grid = 256;
             if (grid > g_hv_gemm_max_grid) grid = g_hv_gemm_max_grid;
             hv_note("hv_gemm_glds_kernel<32,4,256,8> | %s", shape);
-            hv_launch(hv_gemm_glds_kernel<32, 4, 256, 8>, dim3(grid), dim3(512), stream, p, gm, form128, g_hv_gemm_walk);
+            hv_launch(hv_gemm_glds_kernel<32, 4, 256, 8>, dim3(grid), dim3(512), stream, p, gm, form128, g_hv_gemm_walk, g_hv_gemm_pfd);
             return 0;
         }
         // 128x128x64 tiles (whole 128-byte lines per row: 1.8x the LDS-DMA rate of 64-byte row segments), 2-slot 64 KiB
@@ -877,7 +929,7 @@ static inline int hv_gemm_launch(const HvGemmParams& p, hipStream_t stream) {
             if (grid6 > 512) grid6 = 512;
             if (grid6 > g_hv_gemm_max_grid) grid6 = g_hv_gemm_max_grid;
             hv_note("hv_gemm_glds_kernel<64,2,128,4,128> | %s", shape);
-            hv_launch(hv_gemm_glds_kernel<64, 2, 128, 4, 128>, dim3(grid6), dim3(256), stream, p, gm, form64, g_hv_gemm_walk);
+            hv_launch(hv_gemm_glds_kernel<64, 2, 128, 4, 128>, dim3(grid6), dim3(256), stream, p, gm, form64, g_hv_gemm_walk, g_hv_gemm_pfd);
             return 0;
         }
         const int tiles = tm * (n128 / 128);
@@ -886,16 +938,16 @@ static inline int hv_gemm_launch(const HvGemmParams& p, hipStream_t stream) {
             if (grid > 256) grid = 256;
             if (grid > g_hv_gemm_max_grid) grid = g_hv_gemm_max_grid;
             hv_note("hv_gemm_glds_kernel<64,3,128,8> | %s", shape);
-            hv_launch(hv_gemm_glds_kernel<64, 3, 128, 8>, dim3(grid), dim3(512), stream, p, gm, form64, g_hv_gemm_walk);
+            hv_launch(hv_gemm_glds_kernel<64, 3, 128, 8>, dim3(grid), dim3(512), stream, p, gm, form64, g_hv_gemm_walk, g_hv_gemm_pfd);
         } else {  // BK = 32, 72 KiB ring: two workgroups per CU whose epilogues interleave
             if (grid > 512) grid = 512;
             if (grid > g_hv_gemm_max_grid) grid = g_hv_gemm_max_grid;
             if (g_hv_gemm_glds == 4) {
                 hv_note("hv_gemm_glds_kernel<32,3,128,8> | %s", shape);
-                hv_launch(hv_gemm_glds_kernel<32, 3, 128, 8>, dim3(grid), dim3(512), stream, p, gm, form64, g_hv_gemm_walk);
+                hv_launch(hv_gemm_glds_kernel<32, 3, 128, 8>, dim3(grid), dim3(512), stream, p, gm, form64, g_hv_gemm_walk, g_hv_gemm_pfd);
             } else {
                 hv_note("hv_gemm_glds_kernel<32,3,128,4> | %s", shape);
-                hv_launch(hv_gemm_glds_kernel<32, 3, 128, 4>, dim3(grid), dim3(256), stream, p, gm, form128, g_hv_gemm_walk);
+                hv_launch(hv_gemm_glds_kernel<32, 3, 128, 4>, dim3(grid), dim3(256), stream, p, gm, form128, g_hv_gemm_walk, g_hv_gemm_pfd);
             }
         }
         return 0;

@@ -192,6 +192,7 @@ int hv_attention_fp8(const hv_attention_params* p, const float* kscale, const fl
 #define HV_TUNE_TEMPORAL_MFMA 7 /* temporal attention: 1 = MFMA kernel, one wave per (batch, pixel, head) (default), 0 = VALU kernel */
 #define HV_TUNE_CONV_BIG 5      /* 1: 256-pixel conv tiles where the image fills them (default), 0: 128 */
 #define HV_TUNE_GEMM_WALK 8     /* LDS-DMA GEMM tile walk: 1 = every workgroup takes a contiguous run of tiles, 0 = strided over the XCD's range (default) */
+#define HV_TUNE_GEMM_PREFETCH 9 /* LDS-DMA GEMM: L2 prefetch of the X operand this many k-tiles ahead (0 = off) */
 int hv_set_tuning(int key, int value);
 
 /* ---- temporal self-attention over the frame axis ------------------------------------------

@@ -46,6 +46,8 @@ def main():
     st = hvlib.current_stream()
     if os.environ.get("HV_GEMM_GLDS"):
         L.call("hv_set_tuning", 3, int(os.environ["HV_GEMM_GLDS"]))  # A/B of the GEMM kernel variants
+    if os.environ.get("HV_GEMM_PF"):
+        L.call("hv_set_tuning", 9, int(os.environ["HV_GEMM_PF"]))
     if os.environ.get("HV_GEMM_WALK"):
         L.call("hv_set_tuning", 8, int(os.environ["HV_GEMM_WALK"]))
     if os.environ.get("HV_GEMM_RASTER"):
@@ -70,11 +72,14 @@ def main():
     levels = [(96 * 64, 320, 96, 64), (48 * 32, 640, 48, 32), (24 * 16, 1280, 24, 16), (12 * 8, 1280, 12, 8)]
 
     if only is None or "gemm" in only:
-        for (N_tok, C, _, _) in levels[:3]:
+        only_l0 = os.environ.get("HV_MB_ONLY_L0") == "1"  # counter passes: the two streamed level-0 projections only
+        for (N_tok, C, _, _) in levels[:1] if only_l0 else levels[:3]:
             M = n * N_tok
             x = rnd(M, C)
             for name, Nn, K, geglu in [("qkv", 3 * C, C, False), ("proj", C, C, False), ("ff1_geglu", 8 * C, C, True),
                                        ("ff2", C, 4 * C, False)]:
+                if only_l0 and name not in ("qkv", "ff1_geglu"):
+                    continue
                 w = rnd(Nn, K, scale=K**-0.5)
                 xx = x if K == C else rnd(M, K)
                 y = torch.empty(M, Nn // 2 if geglu else Nn, dtype=BF16, device=dev)
@@ -90,6 +95,8 @@ def main():
                 ms = timeit(lambda: ops.gemm(L, st, xx, w, y, bias=bias, geglu=geglu, **kw))
                 report(f"gemm {name} M={M} N={Nn} K={K}", ms, 2.0 * M * Nn * K, 2.0 * (M * K + Nn * K + y.numel()))
                 del w, y
+        if only_l0:
+            return
         # fused-prologue / LN-fold variants at level 0
         M, C = n * 6144, 320
         x, w = rnd(M, C), rnd(C, C, scale=C**-0.5)

@@ -228,6 +228,9 @@ def main():
     ap.add_argument("--width", type=int, default=None)
     ap.add_argument("--fp8-attention", type=int, default=None, choices=[0, 1],
                     help="spatial attention on the fp8 (e4m3) MFMA; default: 1 for --config 5 (BASELINE.json configs[4]), else 0")
+    ap.add_argument("--window-groups", type=int, default=1,
+                    help="N > 1 GPUs: split the ranks into this many groups that take different context windows of a step "
+                         "(window-parallel x frame-shard; clips with several windows per step, e.g. --config 5)")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="skip the profiled extra step (roofline block)")
@@ -280,7 +283,7 @@ def main():
                           prediction_type="v_prediction", rescale_betas_zero_snr=True, timestep_spacing="trailing")
     pipe = Pose2VideoPipeline(None, None, None, unet, pg, cam, sched)
     if world > 1:
-        pipe.enable_frame_sharding()
+        pipe.enable_frame_sharding(window_groups=args.window_groups)
 
     g = torch.Generator().manual_seed(42)
     latents = torch.randn(1, 4, F, h, w, generator=g)

@@ -13,6 +13,7 @@ VAE and CLIP stay stock PyTorch-ROCm modules supplied by the caller (BASELINE.js
 from __future__ import annotations
 
 import math
+import os
 from dataclasses import dataclass
 from typing import Callable, Dict, List, Optional, Union
 
@@ -129,10 +130,14 @@ class Pose2VideoPipeline:
                 m.to(device=device, dtype=dtype) if dtype is not None else m.to(device=device)
         return self
 
-    def enable_frame_sharding(self, group=None):
+    def enable_frame_sharding(self, group=None, window_groups: Optional[int] = None):
         """Shard every context window along the frame axis over the ranks of `group` (one process per
-        GPU, torch.distributed backend "nccl" = RCCL over xGMI)."""
-        self.shard = FrameShard(group)
+        GPU, torch.distributed backend "nccl" = RCCL over xGMI).  window_groups = G (default: HUMANVID_WINDOW_GROUPS or 1)
+        splits the ranks into G sub-groups that take different context windows of a step (window-parallel x frame-shard,
+        for clips with several windows per step) -- see FrameShard."""
+        if window_groups is None:
+            window_groups = int(os.environ.get("HUMANVID_WINDOW_GROUPS", "1"))
+        self.shard = FrameShard(group, window_groups=window_groups)
         if self.denoising_unet is not None:
             self.denoising_unet._engine = None  # rebuilt with the shard on first use
         return self
@@ -257,6 +262,10 @@ class Pose2VideoPipeline:
                                                                 context_stride, context_overlap))
         world = 1 if self.shard is None else self.shard.world
         rank = 0 if self.shard is None else self.shard.rank
+        if self.shard is not None and self.shard.window_groups > 1:
+            # window-parallel: this rank's sub-group takes every G-th window of the step; the others contribute theirs
+            # through the accumulator all-reduce
+            windows = [c for i, c in enumerate(windows) if i % self.shard.window_groups == self.shard.window_group]
         plans = []  # per window: (frame index tensor of this rank, local frame count)
         for c in windows:
             if len(c) % world:
@@ -286,7 +295,7 @@ class Pose2VideoPipeline:
                 ops.pack_ncfhw(L, st, latents, xi, rep=rep, frames=frames)
                 y = eng.forward_nhwc(xi, t_dev, cond, B=rep, F=fl)
                 ops.accumulate_window(L, st, y, rep, C, frames, acc, counter)
-            if world > 1:
+            if self.shard is not None and (world > 1 or self.shard.window_groups > 1):
                 self.shard.all_reduce(acc)
                 self.shard.all_reduce(counter)
             ops.cfg_ddim_step(L, st, latents, acc, counter, rep, coeffs)
@@ -297,13 +306,14 @@ class Pose2VideoPipeline:
         for i in range(n_steps):
             t_dev.copy_(t_table[i].expand(rep))
             coeffs.copy_(c_table[i])
-            if use_graph and world == 1 and i >= 1:
+            multi = self.shard is not None and (world > 1 or self.shard.window_groups > 1)
+            if use_graph and not multi and i >= 1:
                 if graph is None:
                     # step 0 ran eagerly (allocates every workspace buffer); capture step 1 and replay it
                     graph = self._capture(one_step)
                 else:
                     L.call("hv_graph_launch", graph, hvlib.current_stream())
-            elif use_graph and world > 1 and i >= 1:
+            elif use_graph and multi and i >= 1:
                 if recorder is None:
                     # frame-sharded: record step 1 as command-list segments cut at every collective
                     recorder = StepRecorder(L)

@@ -43,11 +43,27 @@ class FrameShard:
     """Frame-axis sharding of one context window over the ranks of a torch.distributed group
     (backend "nccl" == RCCL over xGMI on the GPU box, "gloo" in the CPU tests)."""
 
-    def __init__(self, group=None):
+    def __init__(self, group=None, window_groups: int = 1):
+        """window_groups = G > 1 (long clips with several context windows per step, e.g. config #5):
+        the ranks of `group` are split into G consecutive sub-groups; sub-group g takes the context windows i with
+        i % G == g and shards THEIR frames over its own ranks only (smaller all-to-all groups, no exchange between
+        windows); the per-step noise accumulator is all-reduced over the whole group as before."""
         import torch.distributed as dist
 
         self.dist = dist
-        self.group = group
+        self.all_group = group  # accumulator all-reduce (every rank of the job)
+        self.window_groups = int(window_groups)
+        self.window_group = 0
+        if self.window_groups > 1:
+            total, me = dist.get_world_size(group), dist.get_rank(group)
+            if total % self.window_groups:
+                raise ValueError(f"{total} ranks do not split into {self.window_groups} window groups")
+            per = total // self.window_groups
+            base = dist.get_process_group_ranks(group) if group is not None else list(range(total))
+            subs = [dist.new_group(ranks=base[g * per:(g + 1) * per]) for g in range(self.window_groups)]  # collective
+            self.window_group = me // per
+            group = subs[self.window_group]
+        self.group = group  # frame sharding + temporal exchange
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
 
@@ -96,12 +112,13 @@ class FrameShard:
         self.dist.all_gather_into_tensor(out, inp, group=self.group)
 
     def _all_reduce(self, t: torch.Tensor):
+        # over ALL ranks of the job: with window groups the other groups hold the other windows' contributions
         if self.staged and t.device.type != "cpu":
             h = t.cpu()
-            self.dist.all_reduce(h, group=self.group)
+            self.dist.all_reduce(h, group=self.all_group)
             t.copy_(h)
             return
-        self.dist.all_reduce(t, group=self.group)
+        self.dist.all_reduce(t, group=self.all_group)
 
     def frame_range(self, n_frames: int):
         if n_frames % self.world:

@@ -20,13 +20,13 @@ sys.path.insert(0, os.path.join(REPO, "oracle"))
 pytestmark = pytest.mark.gpu
 
 
-def _inputs():
+def _inputs(F=4):
     import oracle_torch as O
 
     cfg = O.tiny_unet3d_cfg()
     sd = O.make_unet3d_weights(cfg, seed=0)
     g = torch.Generator().manual_seed(42)
-    F, H, W, h, w = 4, 64, 64, 8, 8
+    H, W, h, w = 64, 64, 8, 8
     lat = torch.randn(1, 4, F, h, w, generator=g)
     pose = torch.rand(1, 3, F, H, W, generator=g)
     pl = torch.randn(1, 6, F, H, W, generator=g)
@@ -38,7 +38,7 @@ def _inputs():
     return O, cfg, sd, lat, pose, pl, clip, banks
 
 
-def _worker(rank, world, port, out_path, backend="gloo"):
+def _worker(rank, world, port, out_path, backend="gloo", frames=4, window_groups=1, context_frames=24, context_overlap=4):
     import torch.distributed as dist
 
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
@@ -49,7 +49,7 @@ def _worker(rank, world, port, out_path, backend="gloo"):
     else:
         dist.init_process_group("gloo", rank=rank, world_size=world)
         torch.cuda.set_device(0)
-    O, cfg, sd, lat, pose, pl, clip, banks = _inputs()
+    O, cfg, sd, lat, pose, pl, clip, banks = _inputs(frames)
     from humanvid_amd.conditioning import CameraPoseEncoder, PoseGuider
     from humanvid_amd.engine import UNet3DEngine
     from humanvid_amd.pipeline import Pose2VideoPipeline
@@ -68,13 +68,14 @@ def _worker(rank, world, port, out_path, backend="gloo"):
     cam.load_state_dict(O.make_camera_encoder_weights(), strict=True)
     sched = DDIMScheduler(beta_start=0.00085, beta_end=0.012, beta_schedule="linear", clip_sample=False, steps_offset=1,
                           prediction_type="v_prediction", rescale_betas_zero_snr=True, timestep_spacing="trailing")
-    pipe = Pose2VideoPipeline(None, None, None, net, pg.to("cuda"), cam.to("cuda"), sched).enable_frame_sharding()
+    pipe = Pose2VideoPipeline(None, None, None, net, pg.to("cuda"), cam.to("cuda"), sched).enable_frame_sharding(
+        window_groups=window_groups)
     net._engine = eng = UNet3DEngine(net, shard=pipe.shard)
     eng.set_reference_banks({k: v.cuda() for k, v in banks.items()}, do_cfg=True)
     eng._banks_from_modules = lambda: None
     got = []
-    pipe.denoise(lat.clone().cuda(), pose.cuda(), pl.cuda(), clip.cuda(), 4, 3.5, max_steps=3,
-                 callback=lambda i, t, x: got.append(x.detach().float().cpu().clone()))
+    pipe.denoise(lat.clone().cuda(), pose.cuda(), pl.cuda(), clip.cuda(), 4, 3.5, max_steps=3, context_frames=context_frames,
+                 context_overlap=context_overlap, callback=lambda i, t, x: got.append(x.detach().float().cpu().clone()))
     torch.cuda.synchronize()
     if rank == 0:
         torch.save(got, out_path)
@@ -119,4 +120,24 @@ def test_two_rank_frame_sharding_over_rccl(tmp_path, exchange, monkeypatch):
                    banks, 4, 3.5, max_steps=3, trace=trace)
     errs = [float((a - b).norm() / b.norm()) for a, b in zip(got, trace)]
     print("sharded over RCCL (2 ranks) latent nrmse per step", errs)
+    assert len(errs) == 3 and max(errs) < 2e-2, errs
+
+
+def test_window_parallel_groups_match_oracle(tmp_path):
+    """SURVEY.md section 8(e), last bullet (config #5 shape of the problem): a clip with several context windows per step,
+    two ranks as TWO window groups of one rank each -- every rank runs alternate windows unsharded and the per-step noise
+    accumulator is all-reduced over both.  8 frames in windows of 4 with overlap 2 (3-4 windows per step), 3 steps."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    out_path = str(tmp_path / "wp.pt")
+    mp.spawn(_worker, args=(2, port, out_path, "gloo", 8, 2, 4, 2), nprocs=2, join=True)
+    got = torch.load(out_path)
+    O, cfg, sd, lat, pose, pl, clip, banks = _inputs(8)
+    trace = []
+    O.denoise_loop(sd, cfg, O.make_pose_guider_weights(), O.make_camera_encoder_weights(), lat.clone(), pose, pl, clip,
+                   banks, 4, 3.5, context_frames=4, context_overlap=2, max_steps=3, trace=trace)
+    errs = [float((a - b).norm() / b.norm()) for a, b in zip(got, trace)]
+    print("window-parallel (2 groups x 1 rank) latent nrmse per step", errs)
     assert len(errs) == 3 and max(errs) < 2e-2, errs

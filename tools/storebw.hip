@@ -24,6 +24,15 @@ __global__ __launch_bounds__(256, 2) void st(char* __restrict__ Y, int M, int N,
                     u32x2 v = {(unsigned)t, (unsigned)lane};
                     *reinterpret_cast<u32x2*>(Y + ((long)(m0 + 16 * mf + r16) * N + n0 + 16 * nf + 4 * quad) * 2) = v;
                 }
+        } else if (MODE == 3) {
+            // (D) the round-2 candidate: 16 B per lane, 16 rows x 64 B per instruction (two adjacent MFMA fragments per lane)
+#pragma unroll
+            for (int mf = 0; mf < 8; ++mf)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    u32x4 v = {(unsigned)t, (unsigned)lane, 0u, 1u};
+                    *reinterpret_cast<u32x4*>(Y + ((long)(m0 + 16 * mf + r16) * N + n0 + 32 * j + 8 * quad) * 2) = v;
+                }
         } else if (MODE == 1) {
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
@@ -50,18 +59,19 @@ int main() {
     hipEventCreate(&e0);
     hipEventCreate(&e1);
     const char* names[] = {"A: 8 B/lane, 16 rows x 32 B per instr (MFMA native)", "B: 16 B/lane, 8 rows x 128 B per instr",
-                           "C: 16 B/lane, 4 rows x 256 B per instr"};
+                           "C: 16 B/lane, 4 rows x 256 B per instr", "D: 16 B/lane, 16 rows x 64 B per instr"};
     const int Ns[] = {960, 1280, 640, 2560, 5120, 320};
     for (int N : Ns) {
         const int Mx = N <= 1280 ? M : (N == 2560 ? M / 4 : M / 16);  // level-1 / level-2 row counts
         const int tiles = (Mx / 256) * (N / 128), grid = 512, tpb = (tiles + grid - 1) / grid;
-        for (int mode = 0; mode < 3; ++mode) {
+        for (int mode = 0; mode < 4; ++mode) {
             float ms = 0;
             for (int rep = 0; rep < 3; ++rep) {
                 hipEventRecord(e0);
                 if (mode == 0) hipLaunchKernelGGL(st<0>, dim3(grid), dim3(256), 0, 0, Y, Mx, N, tpb);
                 if (mode == 1) hipLaunchKernelGGL(st<1>, dim3(grid), dim3(256), 0, 0, Y, Mx, N, tpb);
                 if (mode == 2) hipLaunchKernelGGL(st<2>, dim3(grid), dim3(256), 0, 0, Y, Mx, N, tpb);
+                if (mode == 3) hipLaunchKernelGGL(st<3>, dim3(grid), dim3(256), 0, 0, Y, Mx, N, tpb);
                 hipEventRecord(e1);
                 hipEventSynchronize(e1);
                 hipEventElapsedTime(&ms, e0, e1);

@@ -51,7 +51,28 @@ __global__ __launch_bounds__(256) void hv_gn_partial_kernel(hv_groupnorm_params 
             const int cv = cv0 + 256 * r;
             if (r < nrep && cv < CV) hv_unpack8(hv_ld16(src_of(0, cv * 8)), piv[r]);
         }
-        for (int pix = pb + pl; pix < pe; pix += P) {
+        int pix = pb + pl;
+        // four pixels per trip, all loads issued before the first is consumed (one 16-byte load in flight per thread left the
+        // pass at 2.2-3.1 TB/s: latency-bound); single-vector channels only (C <= 2048), the tail and wide C below
+        if (nrep == 1 && cv0 < CV) {
+            for (; pix + 3 * P < pe; pix += 4 * P) {
+                u32x4 v[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) v[u] = hv_ld16(src_of(pix + u * P, cv0 * 8));
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    float f[8];
+                    hv_unpack8(v[u], f);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const float d = f[e] - piv[0][e];
+                        s[0][e] += d;
+                        q[0][e] += d * d;
+                    }
+                }
+            }
+        }
+        for (; pix < pe; pix += P) {
 #pragma unroll
             for (int r = 0; r < HV_GN_MAXREP; ++r) {
                 const int cv = cv0 + 256 * r;
@@ -197,8 +218,57 @@ __global__ __launch_bounds__(256) void hv_ln_stats_kernel(const bf16_t* X, long 
     }
 }
 
+// Several rows per wavefront for the widths of this model (C = 320 / 640 / 1280 = 5 x 16-byte vectors on LPR = 8 / 16 / 32
+// lanes): the one-row-per-wave kernel above keeps 40 of 64 lanes busy at C = 320 with ONE load each and spends twelve
+// full-wave shuffle steps per 640-byte row (2.4 TB/s); here every lane has five loads in flight, a row is reduced over its
+// LPR lanes only, and an instruction still covers whole 128-byte lines (the LPR lanes of a row read consecutive chunks).
+template <int LPR>
+__global__ __launch_bounds__(256) void hv_ln_stats_rows_kernel(const bf16_t* X, long ldx, int M, float eps, float* mean_out,
+                                                               float* rstd_out) {
+    constexpr int RPW = 64 / LPR, C = LPR * 5 * 8;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int row = (blockIdx.x * 4 + wave) * RPW + lane / LPR, j = lane % LPR;
+    const bool live = row < M;  // no early return: every lane takes part in the shuffles below
+    float f[5][8];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+        u32x4 v = {0u, 0u, 0u, 0u};
+        if (live) v = hv_ld16(X + (long)row * ldx + (j + LPR * i) * 8);
+        hv_unpack8(v, f[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < 5; ++i)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s += f[i][e];
+#pragma unroll
+    for (int o = LPR / 2; o >= 1; o >>= 1) s += __shfl_xor(s, o);
+    const float mean = s / (float)C;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < 5; ++i)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float d = f[i][e] - mean;
+            q += d * d;
+        }
+#pragma unroll
+    for (int o = LPR / 2; o >= 1; o >>= 1) q += __shfl_xor(q, o);
+    if (live && j == 0) {
+        mean_out[row] = mean;
+        rstd_out[row] = 1.0f / sqrtf(q / (float)C + eps);
+    }
+}
+
 static inline void hv_layernorm_launch(const bf16_t* X, long ldx, int M, int C, float eps, float* mean, float* rstd,
                                        hipStream_t stream) {
     hv_note("hv_ln_stats_kernel | M=%d C=%d", M, C);
-    hv_launch(hv_ln_stats_kernel, dim3((M + 3) / 4), dim3(256), stream, X, ldx, M, C, eps, mean, rstd);
+    if (C == 320)
+        hv_launch(hv_ln_stats_rows_kernel<8>, dim3((M + 31) / 32), dim3(256), stream, X, ldx, M, eps, mean, rstd);
+    else if (C == 640)
+        hv_launch(hv_ln_stats_rows_kernel<16>, dim3((M + 15) / 16), dim3(256), stream, X, ldx, M, eps, mean, rstd);
+    else if (C == 1280)
+        hv_launch(hv_ln_stats_rows_kernel<32>, dim3((M + 7) / 8), dim3(256), stream, X, ldx, M, eps, mean, rstd);
+    else
+        hv_launch(hv_ln_stats_kernel, dim3((M + 3) / 4), dim3(256), stream, X, ldx, M, C, eps, mean, rstd);
 }

@@ -134,6 +134,22 @@ def case_affine_apply(cx: Ctx, n_img=3, rows=50, C=64, act=A.ACT_NONE, seed=40):
     return e
 
 
+def case_layernorm_stats(cx: Ctx, M=77, C=320, seed=44, offset=3.0):
+    """row statistics of hv_layernorm_stats (mean, 1/sqrt(var + eps)) against torch on the bf16-rounded rows; C = 320 / 640 /
+    1280 take the several-rows-per-wave kernel, other widths the one-row-per-wave kernel; M not a multiple of the rows per
+    workgroup exercises the dead rows"""
+    g = torch.Generator().manual_seed(seed)
+    x = rnd(g, M, C) * (1 + torch.arange(C) % 3) + offset
+    xr = r(x)
+    mean, rstd = torch.zeros(M, device=cx.device), torch.zeros(M, device=cx.device)
+    ops.layernorm_stats(cx.lib, cx.stream, cx.bf(x), mean, rstd)
+    cx.sync()
+    ref_rstd = 1.0 / torch.sqrt(xr.var(dim=1, unbiased=False) + 1e-5)
+    e1, e2 = nrmse(mean, xr.mean(dim=1)), nrmse(rstd, ref_rstd)
+    assert e1 < 1e-5 and e2 < 1e-5, f"layernorm stats C={C}: mean {e1} rstd {e2}"
+    return e1, e2
+
+
 def case_gemm_lnfold(cx: Ctx, B=2, Fr=3, P=20, C=320, N=192, seed=2):
     """LayerNorm + positional encoding folded into the projection (motion-module QKV)."""
     g = torch.Generator().manual_seed(seed)

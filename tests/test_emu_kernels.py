@@ -195,8 +195,15 @@ def test_gemm_row_permutation(cx):
     kc.case_gemm_row_perm(cx, X=3, Y=2, P=50, N=192, K=128, seed=21)  # ragged against the 128/256-row tiles
 
 
+def test_layernorm_stats(cx):
+    for C in (320, 640, 1280, 64, 192):
+        kc.case_layernorm_stats(cx, M=77, C=C)
+    kc.case_layernorm_stats(cx, M=5, C=320, seed=45)
+
+
 def test_groupnorm(cx):
     kc.case_groupnorm(cx)
+    kc.case_groupnorm(cx, n=2, H=16, W=12, C1=320, seed=13, splits=2)  # 96 pixels per range: the four-pixel trips + a tail
     kc.case_groupnorm(cx, n=2, H=4, W=4, C1=1280, C2=640, seed=9)  # groups straddle the concat seam
     kc.case_groupnorm(cx, n=1, H=3, W=3, C1=2560, seed=10)
     kc.case_groupnorm(cx, n=2, H=8, W=8, C1=320, seed=11, offset=40.0, spread=0.05, splits=5)  # |mean| >> std

@@ -78,6 +78,11 @@ def test_conv_shapes(cx):
     kc.case_conv(cx, n=2, H=64, W=48, C1=32, Cout=16, pro=False, temb=False, residual=False, out_act=A.ACT_SILU)
 
 
+def test_layernorm_stats(cx):
+    for C, M in ((320, 48 * 6144), (640, 48 * 1536 + 3), (1280, 4608), (192, 1000)):
+        kc.case_layernorm_stats(cx, M=M, C=C)
+
+
 def test_groupnorm(cx):
     kc.case_groupnorm(cx, n=4, H=96, W=64, C1=320)
     kc.case_groupnorm(cx, n=4, H=24, W=16, C1=1280, C2=640)

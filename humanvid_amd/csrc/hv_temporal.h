@@ -207,16 +207,30 @@ __global__ __launch_bounds__(HvTemporalGeom<D>::HG * 64) void hv_temporal_mfma_k
         return p.qo_chunked ? (long)b * p.kv_stride_b + (long)(f / p.kv_chunk) * p.kv_stride_chunk + (long)(f % p.kv_chunk) * p.P + pix
                             : row0 + (long)f * p.P;
     };
-    for (int i = tid; i < FQ * CV; i += nthr) {
-        const int f = i / CV, c = i % CV;
-        hv_st16(Qs + f * RS + c * 16, hv_ld16(p.Q + qo_row(f) * p.ldq + c0 + c * 8));
+    // every load of the workgroup's Q / K / V rows is issued before the first LDS store (compile-time trip count, predicated):
+    // as runtime-trip-count loops hipcc emitted load -> vmcnt(0) -> ds_write per trip, i.e. four dependent HBM round trips
+    // per workgroup with one or two 16-byte loads in flight per thread (3.7 TB/s at level 0)
+    constexpr int NIT = (32 * CV + HG * 64 - 1) / (HG * 64);
+    u32x4 qr[NIT], kr[NIT], vr[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {  // unconditional loads from clamped (always valid) rows: no branch, no wait between them
+        const int i = tid + it * nthr;
+        const int c = i % CV;
+        const int fq = min(i / CV, FQ - 1), fk = min(i / CV, F - 1);
+        const long kvrow = (long)b * p.kv_stride_b + (long)(fk / p.kv_chunk) * p.kv_stride_chunk + (long)(fk % p.kv_chunk) * p.P + pix;
+        qr[it] = hv_ld16(p.Q + qo_row(fq) * p.ldq + c0 + c * 8);
+        kr[it] = hv_ld16(p.K + kvrow * p.ldkv + c0 + c * 8);
+        vr[it] = hv_ld16(p.V + kvrow * p.ldkv + c0 + c * 8);
     }
-    for (int i = tid; i < F * CV; i += nthr) {
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int i = tid + it * nthr;
         const int f = i / CV, c = i % CV;
-        const long kvrow = (long)b * p.kv_stride_b + (long)(f / p.kv_chunk) * p.kv_stride_chunk +
-                           (long)(f % p.kv_chunk) * p.P + pix;
-        hv_st16(Ks + f * RS + c * 16, hv_ld16(p.K + kvrow * p.ldkv + c0 + c * 8));
-        hv_st16(Vs + f * RS + c * 16, hv_ld16(p.V + kvrow * p.ldkv + c0 + c * 8));
+        if (i < FQ * CV) hv_st16(Qs + f * RS + c * 16, qr[it]);
+        if (i < F * CV) {
+            hv_st16(Ks + f * RS + c * 16, kr[it]);
+            hv_st16(Vs + f * RS + c * 16, vr[it]);
+        }
     }
     __syncthreads();
 

@@ -866,7 +866,7 @@ static int g_hv_gemm_raster = 0;        // tuning knob: m-blocks per raster grou
 //     level-0 out-projection 0.216 -> 0.193 against policy 2
 //   2: round-1 policy (256x128x32 two workgroups per CU; 128x128x64 when K >= 2N)
 //   1 / 3 / 4 / 6 / 7 / 8: force one instantiation (A/Bs); 0 = register-staged kernel
-static int g_hv_gemm_glds = 9;
+static int g_hv_gemm_glds = 10;
 
 static inline int hv_gemm_launch(const HvGemmParams& p, hipStream_t stream) {
     if (p.M <= 0 || p.N <= 0 || p.K <= 0) return -1;
@@ -901,8 +901,14 @@ static inline int hv_gemm_launch(const HvGemmParams& p, hipStream_t stream) {
         // The kernel is bound by the CU's L2 -> LDS fill path (~27-60 B/clk measured: round-2 attention trace, round-1
         // fillbw probe), so for wide N this is the shape that gets closest to the MFMA bound.
         const bool ok128 = form128 != HV_FORM_NONE;  // a per-row table may fit 64-row but not 128-row wave sub-tiles
+        // Policy 10 (default): ... and when the 256x256 tiles fill the 256 CUs' last round to >= 90 % (one workgroup per CU:
+        // 360 tiles are two rounds at 70 %); otherwise the 128x128x64 kernel, whose 512 slots quantise four times finer --
+        // measured on the level-2 projections (M = 18432): N = 1280 0.096 -> 0.083 ms, K = 5120 0.280 -> 0.245 ms, N = 3840
+        // 0.212 -> 0.202 ms (profiles/r02_gemm_tile_modes.txt).
+        const int t256 = tm * (n256 / 256), rounds256 = (t256 + 255) / 256;
+        const bool fills256 = t256 * 10 >= rounds256 * 256 * 9;
         if (ok128 && (g_hv_gemm_glds >= 7) && p.N >= 960 && (n256 - p.N) * 8 <= p.N &&
-            (g_hv_gemm_glds != 8 || p.K >= 640)) {
+            (g_hv_gemm_glds != 8 || p.K >= 640) && (g_hv_gemm_glds != 10 || fills256)) {
             const int tiles = tm * (n256 / 256);
             int grid = ((tiles + 7) / 8) * 8;
             if (grid > 256) grid = 256;
@@ -923,7 +929,7 @@ static inline int hv_gemm_launch(const HvGemmParams& p, hipStream_t stream) {
         // 128x128x64 tiles (whole 128-byte lines per row: 1.8x the LDS-DMA rate of 64-byte row segments), 2-slot 64 KiB
         // ring, two workgroups per CU: measured 7-13 % faster than 256x128x32 when K >= 2 N (the FF output projections),
         // slower for wide outputs (half the operand reuse per tile)
-        if (!ok128 || g_hv_gemm_glds == 6 || g_hv_gemm_glds == 9 || ((g_hv_gemm_glds == 2 || g_hv_gemm_glds >= 7) && p.K >= 2 * p.N)) {
+        if (!ok128 || g_hv_gemm_glds == 6 || g_hv_gemm_glds >= 9 || ((g_hv_gemm_glds == 2 || g_hv_gemm_glds >= 7) && p.K >= 2 * p.N)) {
             const int tiles6 = ((p.M + 127) / 128) * (n128 / 128);
             int grid6 = ((tiles6 + 7) / 8) * 8;
             if (grid6 > 512) grid6 = 512;

@@ -61,7 +61,7 @@ def test_gemm_lds_dma_kernel_variants(cx):
             kc.case_gemm_geglu(cx, M=257, C=64, seed=26)
             kc.case_gemm_lnfold(cx, B=2, Fr=3, P=50, C=128, N=192, seed=25)
         finally:
-            cx.lib.call("hv_set_tuning", 3, 9)
+            cx.lib.call("hv_set_tuning", 3, 10)
 
 
 def test_gemm_fast_epilogue_forms(cx):
@@ -79,7 +79,7 @@ def test_gemm_fast_epilogue_forms(cx):
             for form in ("ln", "ln_yt", "ln_geglu", "res", "plain"):
                 kc.case_gemm_forms(cx, M=900, C=192, N=320, P=128, form=form, seed=34)
     finally:
-        cx.lib.call("hv_set_tuning", 3, 9)
+        cx.lib.call("hv_set_tuning", 3, 10)
         cx.lib.call("hv_set_tuning", 2, 512)
 
 
@@ -133,7 +133,7 @@ def test_gemm_lds_dma_256x256_tiles(cx):
         kc.case_gemm(cx, M=1200, N=1024, K=96 + 32, seed=46)
     finally:
         cx.lib.call("hv_set_tuning", 2, 512)
-        cx.lib.call("hv_set_tuning", 3, 9)
+        cx.lib.call("hv_set_tuning", 3, 10)
 
 
 def test_gemm_prologue(cx):
@@ -208,6 +208,7 @@ def test_groupnorm(cx):
     kc.case_groupnorm(cx, n=1, H=3, W=3, C1=2560, seed=10)
     kc.case_groupnorm(cx, n=2, H=8, W=8, C1=320, seed=11, offset=40.0, spread=0.05, splits=5)  # |mean| >> std
     kc.case_groupnorm(cx, n=2, H=5, W=3, C1=64, seed=12, offset=-25.0, spread=0.2, splits=4)   # ragged pixel ranges
+    kc.case_groupnorm(cx, n=2, H=3, W=3, C1=640, seed=14, splits=4)                             # an empty last range; 20 channels per group
 
 
 @pytest.mark.parametrize("D", [40, 80, 160])

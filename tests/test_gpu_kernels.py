@@ -41,13 +41,13 @@ def test_gemm_epilogue_forms(cx):
         kc.case_gemm_forms(cx, M=3000, C=320, N=960, P=384, form=form)
     kc.case_gemm_forms(cx, M=4608, C=1280, N=1280, P=96, form="res", seed=35)   # level 3: 96-token images, general epilogue
     kc.case_gemm_forms(cx, M=4608, C=1280, N=3840, P=96, form="ln", seed=36)
-    for variant in (2, 1, 4, 6, 7):
+    for variant in (2, 1, 4, 6, 7, 9):
         cx.lib.call("hv_set_tuning", 3, variant)
         try:
             for form in ("ln", "ln_yt", "ln_geglu", "res", "plain"):
                 kc.case_gemm_forms(cx, M=2100, C=640, N=1920, P=128, form=form, seed=37)
         finally:
-            cx.lib.call("hv_set_tuning", 3, 9)
+            cx.lib.call("hv_set_tuning", 3, 10)
 
 
 def test_bench_shape_gemm_forms(cx):
@@ -58,7 +58,10 @@ def test_bench_shape_gemm_forms(cx):
     kc.case_gemm_forms(cx, M=M, C=320, N=320, P=24 * 6144, form="res")     # level-0 attention output projection (in place)
     kc.case_gemm_forms(cx, M=M, C=1280, N=320, P=24 * 6144, form="res")    # level-0 feed-forward output projection
     kc.case_gemm_forms(cx, M=48 * 1536, C=640, N=2560, P=1536, form="ln_geglu", seed=38)
+    # level 2 (M = 18432): 256x256 tiles would fill 1.4 / 4.2 rounds of the 256 CUs -> policy 10 takes the 128x128x64 kernel
     kc.case_gemm_forms(cx, M=48 * 384, C=1280, N=1280, P=24 * 384, form="res", seed=39)
+    kc.case_gemm_forms(cx, M=48 * 384, C=5120, N=1280, P=24 * 384, form="res", seed=40)
+    kc.case_gemm_forms(cx, M=48 * 384, C=1280, N=3840, P=384, form="ln_yt", seed=41)
 
 
 def test_affine_apply(cx):
@@ -89,6 +92,7 @@ def test_groupnorm(cx):
     kc.case_groupnorm(cx, n=3, H=12, W=8, C1=2560)
     kc.case_groupnorm(cx, n=2, H=96, W=64, C1=320, offset=40.0, spread=0.05, splits=64)  # |mean| >> std (Chan / Welford merge)
     kc.case_groupnorm(cx, n=2, H=24, W=16, C1=1280, C2=640, offset=-25.0, spread=0.2, splits=8)
+    kc.case_groupnorm(cx, n=2, H=3, W=3, C1=640, seed=14, splits=4)  # an empty last pixel range
 
 
 @pytest.mark.parametrize("D,Lq,Lb", [(40, 1536, 1536), (40, 200, 72), (80, 384, 384), (160, 96, 96), (160, 384, 96)])

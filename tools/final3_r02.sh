@@ -4,7 +4,7 @@
 # rocprofv3 kernel-trace summary, then a same-box A/B of the step against the previous library.
 mkdir -p gpurun_out
 export TMPDIR=/tmp
-( time timeout 900 python -m pytest tests -q -m gpu -n 3 ) > gpurun_out/final3_pytest.txt 2>&1; echo "pytest rc=$?" >> gpurun_out/final3_pytest.txt
+( time timeout 900 python -m pytest tests -q -m gpu -n 3 --dist loadfile ) > gpurun_out/final3_pytest.txt 2>&1; echo "pytest rc=$?" >> gpurun_out/final3_pytest.txt
 grep -E "passed|failed|error" gpurun_out/final3_pytest.txt | tail -3
 if ! grep -q "pytest rc=0" gpurun_out/final3_pytest.txt; then
   ( time timeout 600 python -m pytest tests -q -m gpu --lf -x -s ) > gpurun_out/final3_pytest_lf.txt 2>&1; echo "pytest-lf rc=$?" >> gpurun_out/final3_pytest_lf.txt

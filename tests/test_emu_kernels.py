@@ -61,7 +61,7 @@ def test_gemm_lds_dma_kernel_variants(cx):
             kc.case_gemm_geglu(cx, M=257, C=64, seed=26)
             kc.case_gemm_lnfold(cx, B=2, Fr=3, P=50, C=128, N=192, seed=25)
         finally:
-            cx.lib.call("hv_set_tuning", 3, 10)
+            cx.lib.call("hv_set_tuning", 3, 9)
 
 
 def test_gemm_fast_epilogue_forms(cx):
@@ -79,7 +79,7 @@ def test_gemm_fast_epilogue_forms(cx):
             for form in ("ln", "ln_yt", "ln_geglu", "res", "plain"):
                 kc.case_gemm_forms(cx, M=900, C=192, N=320, P=128, form=form, seed=34)
     finally:
-        cx.lib.call("hv_set_tuning", 3, 10)
+        cx.lib.call("hv_set_tuning", 3, 9)
         cx.lib.call("hv_set_tuning", 2, 512)
 
 
@@ -115,7 +115,12 @@ def test_gemm_tile_walks(cx):
             kc.case_gemm_forms(cx, M=1300, C=128, N=320, P=128, form="res", seed=81)      # 128x128 tiles: 11 x 3
             kc.case_gemm_forms(cx, M=1300, C=128, N=1024, P=128, form="ln", seed=82)      # 256x256 tiles: 6 x 4
             kc.case_gemm_forms(cx, M=700, C=64, N=2048, P=128, form="ln_geglu", seed=83)  # 3 x 8
+        # tile policy 10: 256x256 tiles only when they fill the last round over the 256 CUs to >= 90 %
+        cx.lib.call("hv_set_tuning", 3, 10)
+        kc.case_gemm_forms(cx, M=1300, C=64, N=1024, P=128, form="ln", seed=84)           # 24 tiles: 128x128x64 kernel
+        kc.case_gemm_forms(cx, M=256 * 58, C=64, N=1024, P=128, form="plain", seed=85)    # 232 of 256: 256x256x64 kernel
     finally:
+        cx.lib.call("hv_set_tuning", 3, 9)
         cx.lib.call("hv_set_tuning", 2, 512)
         cx.lib.call("hv_set_tuning", 8, 0)
 
@@ -133,7 +138,7 @@ def test_gemm_lds_dma_256x256_tiles(cx):
         kc.case_gemm(cx, M=1200, N=1024, K=96 + 32, seed=46)
     finally:
         cx.lib.call("hv_set_tuning", 2, 512)
-        cx.lib.call("hv_set_tuning", 3, 10)
+        cx.lib.call("hv_set_tuning", 3, 9)
 
 
 def test_gemm_prologue(cx):

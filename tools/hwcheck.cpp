@@ -1,0 +1,171 @@
+// Seconds-long hardware check through the C ABI alone (no Python, no torch: runs in the last seconds of a GPU budget):
+//  1. hv_groupnorm_affine (partial sums + the wave-merge finalize) against a double-precision host reference,
+//  2. hv_gemm under tile policy 10 against policy 9 (same inputs) and against sampled host rows, at the level-2 / level-3
+//     shapes that policy 10 moves from the 256x256x64 to the 128x128x64 kernel.
+// Build: hipcc -O2 -Wno-unused-value tools/hwcheck.cpp -Iinclude -Lhumanvid_amd/lib -lhumanvid_hip -Wl,-rpath,'$ORIGIN/../../humanvid_amd/lib' -o tools/bin/hwcheck
+#include <hip/hip_runtime.h>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+#include "humanvid_hip.h"
+
+static uint32_t g_s = 12345u;
+static inline float rnd() {  // uniform in [-1, 1)
+    g_s = g_s * 1664525u + 1013904223u;
+    return (float)(int32_t)g_s * (1.0f / 2147483648.0f);
+}
+static inline uint16_t f2b(float f) {
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    u += 0x7FFFu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+static inline float b2f(uint16_t b) {
+    uint32_t u = (uint32_t)b << 16;
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+}
+template <class T>
+static T* dev(const std::vector<T>& h) {
+    T* d;
+    hipMalloc(&d, h.size() * sizeof(T));
+    hipMemcpy(d, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice);
+    return d;
+}
+template <class T>
+static T* devz(size_t n) {
+    T* d;
+    hipMalloc(&d, n * sizeof(T));
+    hipMemset(d, 0, n * sizeof(T));
+    return d;
+}
+
+static int check_gn(int n, int pixels, int C1, int C2, int splits, float offset, const std::vector<int>& imgs) {
+    const int C = C1 + C2, groups = 32, cg = C / groups;
+    std::vector<uint16_t> x1((size_t)n * pixels * C1), x2((size_t)n * pixels * (C2 ? C2 : 1));
+    for (auto& v : x1) v = f2b(rnd() * 1.5f + offset);
+    for (auto& v : x2) v = f2b(rnd() * 0.7f - offset);
+    std::vector<float> gamma(C), beta(C);
+    for (int c = 0; c < C; ++c) gamma[c] = 1.f + 0.2f * rnd(), beta[c] = 0.1f * rnd();
+    hv_groupnorm_params p;
+    memset(&p, 0, sizeof p);
+    uint16_t *dx1 = dev(x1), *dx2 = dev(x2);
+    float *dg = dev(gamma), *db = dev(beta);
+    p.X = dx1, p.C1 = C1, p.X2 = C2 ? dx2 : nullptr, p.C2 = C2;
+    p.n_images = n, p.pixels = pixels, p.groups = groups, p.eps = 1e-5f;
+    p.gamma = dg, p.beta = db, p.splits = splits;
+    p.partial = devz<float>((size_t)n * 64 * groups * 2);
+    p.scale = devz<float>((size_t)n * C), p.shift = devz<float>((size_t)n * C);
+    const int rc = hv_groupnorm_affine(&p, nullptr);
+    hipDeviceSynchronize();
+    std::vector<float> sc((size_t)n * C), sh((size_t)n * C);
+    hipMemcpy(sc.data(), p.scale, sc.size() * 4, hipMemcpyDeviceToHost);
+    hipMemcpy(sh.data(), p.shift, sh.size() * 4, hipMemcpyDeviceToHost);
+    double worst = 0;
+    for (int img : imgs)
+        for (int g = 0; g < groups; ++g) {
+            double s = 0, q = 0;
+            for (int px = 0; px < pixels; ++px)
+                for (int c = g * cg; c < (g + 1) * cg; ++c) {
+                    const double v = c < C1 ? b2f(x1[((size_t)img * pixels + px) * C1 + c])
+                                            : b2f(x2[((size_t)img * pixels + px) * C2 + (c - C1)]);
+                    s += v, q += v * v;
+                }
+            const double cnt = (double)pixels * cg, mean = s / cnt, var = q / cnt - mean * mean;
+            const double rstd = 1.0 / sqrt(var + 1e-5);
+            for (int c = g * cg; c < (g + 1) * cg; ++c) {
+                const double rs = rstd * gamma[c], rh = beta[c] - mean * rs;
+                // error of the normalised value at a typical input x = mean + 1/rstd
+                const double xv = mean + 1.0 / rstd;
+                const double e = fabs((xv * sc[(size_t)img * C + c] + sh[(size_t)img * C + c]) - (xv * rs + rh));
+                if (e > worst) worst = e;
+            }
+        }
+    printf("groupnorm n=%d pixels=%d C=%d+%d splits=%d: rc=%d max |err| of the normalised value %.3e %s\n", n, pixels, C1, C2,
+           splits, rc, worst, (rc == 0 && worst < 2e-4) ? "OK" : "FAIL");
+    fflush(stdout);
+    return !(rc == 0 && worst < 2e-4);
+}
+
+static int check_gemm(int M, int N, int K, int form) {  // form 0: bias + residual in place; 1: LayerNorm fold + V^T tail
+    std::vector<uint16_t> x((size_t)M * K), w((size_t)N * K), res((size_t)M * N);
+    const float ws = 1.0f / sqrtf((float)K);
+    for (auto& v : x) v = f2b(rnd() + 0.25f);
+    for (auto& v : w) v = f2b(rnd() * ws * 1.7f);
+    for (auto& v : res) v = f2b(rnd());
+    std::vector<float> bias(N), mean(M), rstd(M), colsum(N);
+    for (auto& v : bias) v = 0.1f * rnd();
+    for (auto& v : mean) v = 0.25f + 0.05f * rnd();
+    for (auto& v : rstd) v = 1.5f + 0.2f * rnd();
+    for (int n = 0; n < N; ++n) {
+        double s = 0;
+        for (int k = 0; k < K; ++k) s += b2f(w[(size_t)n * K + k]);
+        colsum[n] = (float)s;
+    }
+    const int ns = form == 1 ? (2 * N / 3) : N;
+    uint16_t *dx = dev(x), *dw = dev(w);
+    float *dbias = dev(bias), *dmean = dev(mean), *drstd = dev(rstd), *dcs = dev(colsum);
+    std::vector<uint16_t> out[2], outt[2];
+    for (int pol = 0; pol < 2; ++pol) {
+        hv_set_tuning(HV_TUNE_GEMM_GLDS, pol ? 10 : 9);
+        uint16_t* dy = dev(res);  // the residual stream, updated in place (form 0)
+        uint16_t* dyt = devz<uint16_t>((size_t)(N - ns + 1) * M);
+        hv_gemm_params p;
+        memset(&p, 0, sizeof p);
+        p.X = dx, p.ldx = K, p.K1 = 0, p.W = dw, p.Y = dy, p.ldy = form == 1 ? ns : N, p.M = M, p.N = N, p.K = K;
+        p.n_split = 0, p.bias = dbias, p.rows_per_image = 1, p.pe_period = 1, p.pe_frames = 1, p.rowvec_period = 1;
+        if (form == 0) p.residual = dy, p.ldr = N;
+        else p.row_mean = dmean, p.row_rstd = drstd, p.colsum = dcs, p.Yt = dyt, p.ldyt = M, p.n_split = ns;
+        const int rc = hv_gemm(&p, nullptr);
+        hipDeviceSynchronize();
+        if (rc != 0) {
+            printf("gemm M=%d N=%d K=%d form=%d policy %d: rc=%d (%s) FAIL\n", M, N, K, form, pol ? 10 : 9, rc, hv_last_error());
+            return 1;
+        }
+        out[pol].resize((size_t)M * (form == 1 ? ns : N));
+        hipMemcpy(out[pol].data(), dy, out[pol].size() * 2, hipMemcpyDeviceToHost);
+        outt[pol].resize((size_t)(N - ns) * M);
+        if (N > ns) hipMemcpy(outt[pol].data(), dyt, outt[pol].size() * 2, hipMemcpyDeviceToHost);
+        hipFree(dy), hipFree(dyt);
+    }
+    hv_set_tuning(HV_TUNE_GEMM_GLDS, 9);
+    double dmax = 0;
+    for (size_t i = 0; i < out[0].size(); ++i) dmax = fmax(dmax, fabs(b2f(out[0][i]) - b2f(out[1][i])));
+    for (size_t i = 0; i < outt[0].size(); ++i) dmax = fmax(dmax, fabs(b2f(outt[0][i]) - b2f(outt[1][i])));
+    // sampled host rows against policy 10
+    double emax = 0, rms = 0;
+    long cnt = 0;
+    for (int r = 0; r < 24; ++r) {
+        const int m = (int)(((long)r * 7919 + 13) % M);
+        for (int n = 0; n < N; ++n) {
+            double acc = 0;
+            for (int k = 0; k < K; ++k) acc += (double)b2f(x[(size_t)m * K + k]) * b2f(w[(size_t)n * K + k]);
+            double ref = form == 0 ? acc + bias[n] + b2f(res[(size_t)m * N + n]) : rstd[m] * (acc - mean[m] * colsum[n]) + bias[n];
+            const float got = n < ns ? b2f(out[1][(size_t)m * (form == 1 ? ns : N) + n]) : b2f(outt[1][(size_t)(n - ns) * M + m]);
+            emax = fmax(emax, fabs(got - ref)), rms += ref * ref, ++cnt;
+        }
+    }
+    rms = sqrt(rms / cnt);
+    const bool ok = dmax <= 0.02 * rms && emax <= 0.02 * rms;
+    printf("gemm M=%d N=%d K=%d form=%d: policy 10 vs 9 max |diff| %.3e, vs host rows max |err| %.3e (rms %.3f) %s\n", M, N, K, form,
+           dmax, emax, rms, ok ? "OK" : "FAIL");
+    fflush(stdout);
+    hipFree(dx), hipFree(dw);
+    return !ok;
+}
+
+int main() {
+    int bad = 0;
+    bad += check_gn(48, 6144, 320, 0, 64, 0.7f, {0, 47});
+    bad += check_gn(4, 384, 1280, 640, 8, -2.0f, {0, 3});
+    bad += check_gn(2, 9, 640, 0, 4, 0.3f, {0, 1});
+    bad += check_gn(3, 96, 2560, 0, 2, 5.0f, {1});
+    bad += check_gemm(18432, 1280, 1280, 0);
+    bad += check_gemm(4608, 1280, 1280, 0);
+    bad += check_gemm(18432, 3840, 1280, 1);
+    printf("hwcheck: %s\n", bad ? "FAIL" : "all OK");
+    return bad;
+}

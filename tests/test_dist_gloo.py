@@ -94,6 +94,49 @@ def test_frame_sharded_temporal_block_matches_unsharded(tmp_path, exchange, monk
     assert not torch.equal(ref, hid)  # the block did something
 
 
+def _group_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from humanvid_amd.runner import FrameShard
+
+    shard = FrameShard(window_groups=2)  # 4 ranks -> 2 window groups of 2 frame-sharding ranks
+    assert (shard.world, shard.rank, shard.window_group) == (2, rank % 2, rank // 2)
+    w, hid = _weights()
+    hid = (hid.float() * (1.0 + 0.5 * shard.window_group)).to(torch.bfloat16)  # each group works on its own window
+    f0, fl = shard.frame_range(F)
+    run = _runner(w, shard)
+    local = hid[:, f0:f0 + fl].reshape(B * fl * N, C).contiguous().clone()
+    run.temporal_attention_block("ab", local, B, fl, N, sharded=True)   # all-to-all inside the sub-group only
+    torch.save(local.view(B, fl, N, C), os.path.join(out_dir, f"r{rank}.pt"))
+    acc = torch.full((3,), float(rank + 1))
+    shard.all_reduce(acc)                                                # the accumulator: over ALL ranks of the job
+    assert torch.equal(acc, torch.full((3,), 10.0)), acc
+    dist.destroy_process_group()
+
+
+def test_window_groups_shard_inside_and_reduce_across(tmp_path):
+    """window-parallel x frame-shard on 4 ranks (last bullet): two groups of two ranks, each
+    group exchanges its own window's q|k|v inside the group, the noise accumulator is reduced over all four"""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    import build_emu
+
+    build_emu.build()
+    mp.spawn(_group_worker, args=(4, port, str(tmp_path)), nprocs=4, join=True)
+    w, hid0 = _weights()
+    run = _runner(w)
+    for grp in range(2):
+        got = torch.cat([torch.load(os.path.join(str(tmp_path), f"r{2 * grp + r}.pt")) for r in range(2)], dim=1)
+        hid = (hid0.float() * (1.0 + 0.5 * grp)).to(torch.bfloat16)
+        ref = hid.reshape(B * F * N, C).contiguous().clone()
+        run.temporal_attention_block("ab", ref, B, F, N, sharded=False)
+        ref = ref.view(B, F, N, C)
+        err = float((got.float() - ref.float()).norm() / ref.float().norm())
+        assert err < 4e-3, (grp, err)
+
+
 class _ToyVae(torch.nn.Module):
     """stand-in for AutoencoderKL.decode: frames are independent batch items (GroupNorm is per sample)"""
 

@@ -48,5 +48,21 @@ def build(force: bool = False, verbose: bool = False) -> str:
     return LIB
 
 
+def build_hwcheck() -> str:
+    """tools/hwcheck.cpp: a C++ consumer of include/humanvid_hip.h with no Python in the process (seconds-long hardware
+    check of hv_groupnorm_affine and the hv_gemm tile policies; run by tests/test_gpu_cabi.py) -> tools/bin/hwcheck"""
+    src = os.path.join(REPO, "tools", "hwcheck.cpp")
+    out = os.path.join(REPO, "tools", "bin", "hwcheck")
+    os.makedirs(os.path.dirname(out), exist_ok=True)
+    if not _newer(out, [src, LIB, os.path.join(REPO, "include", "humanvid_hip.h")]):
+        res = subprocess.run([HIPCC, "-O2", "-Wno-unused-value", "-Wno-unused-result", src, "-I" + os.path.join(REPO, "include"),
+                              "-L" + LIBDIR, "-lhumanvid_hip", "-Wl,-rpath,$ORIGIN/../../humanvid_amd/lib", "-o", out],
+                             capture_output=True, text=True)
+        if res.returncode != 0:
+            raise RuntimeError("hwcheck build failed:\n" + res.stderr[-4000:])
+    return out
+
+
 if __name__ == "__main__":
     print(build(force="--force" in os.sys.argv, verbose=True))
+    print(build_hwcheck())

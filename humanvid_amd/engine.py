@@ -65,7 +65,10 @@ class UNet3DEngine:
         # VALU- and DMA-issue-bound at d = 40, see profiles/README.md); HUMANVID_ATTENTION=2 selects it for same-box A/Bs
         self.attn_kernel = int(os.environ.get("HUMANVID_ATTENTION", "1"))
         # BASELINE.json configs[4]: spatial attention on the fp8 (e4m3) MFMA -- hv_attention_fp8 (transposed-V kernel family)
-        self.attn_fp8 = os.environ.get("HUMANVID_ATTENTION_FP8", "0") == "1"
+        # (denoising UNet only: the ReferenceNet write pass runs once per clip and keeps its banks at bf16 precision)
+        self.attn_fp8 = os.environ.get("HUMANVID_ATTENTION_FP8", "0") == "1" and kind == "denoise"
+        if self.attn_fp8 and self.attn_kernel != 1:
+            raise NotImplementedError("HUMANVID_ATTENTION_FP8=1 needs the transposed-V attention kernel (HUMANVID_ATTENTION=1)")
         self.bank_fp8 = {}
         self.gn_prologue = os.environ.get("HUMANVID_GN_PROLOGUE", "0") == "1"  # round-1 fused GroupNorm-apply GEMM (A/B)
         self._sel_cache: Dict[tuple, torch.Tensor] = {}
@@ -425,7 +428,7 @@ class UNet3DEngine:
                     sel_t = torch.tensor(sel, dtype=torch.int32).to(self.device)
                     self._sel_cache[skey] = sel_t
                 kw = dict(k2=k2, vt2=vt2, ldk2=2 * C if v2 else C, ldvt2=2 * C if v2 else bb * Nb, L2=Nb, bank_sel=sel_t)
-            if self.attn_fp8 and not v2:
+            if self.attn_fp8:
                 Dh = C // self.heads
                 ks1 = ws.get(f"tr_ks_{n}x{N}", (n, self.heads, (N + 63) // 64), F32)
                 va1 = ws.get("tr_va", (self.heads,), F32)

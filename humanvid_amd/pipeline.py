@@ -342,6 +342,13 @@ class Pose2VideoPipeline:
             recorder.destroy()
         return latents
 
+    def interpolate_latents(self, latents: torch.Tensor, interpolation_factor: int, device):
+        """pipeline_pose2vid_long.py:294-337: k-1 blended latents between consecutive denoised frames (linear or slerp, chosen
+        process-wide by src.pipelines.utils.set_tensor_interpolation_method)."""
+        from .latent_interp import interpolate_latents
+
+        return interpolate_latents(latents, interpolation_factor, device)
+
     def _capture(self, fn):
         """Capture `fn`'s launches on a side stream into a HIP graph, launch it once, return the exec."""
         import ctypes
@@ -399,8 +406,6 @@ class Pose2VideoPipeline:
                  callback: Optional[Callable[[int, int, torch.FloatTensor], None]] = None,
                  callback_steps: Optional[int] = 1, context_schedule="uniform", context_frames=24, context_stride=1,
                  context_overlap=4, context_batch_size=1, interpolation_factor=1, **kwargs):
-        if interpolation_factor >= 2:
-            raise NotImplementedError("latent interpolation (interpolation_factor >= 2) is outside the denoising path")
         device = self._require_gpu_and_plain_sampling(eta, num_images_per_prompt)
         do_cfg = guidance_scale > 1.0
         clip_embeds, reader, writer = self._clip_and_reference_pass(ref_image, width, height, do_cfg, device)
@@ -417,6 +422,8 @@ class Pose2VideoPipeline:
                                callback_steps=callback_steps or 1)
         reader.clear()
         writer.clear()
+        if interpolation_factor > 0:  # pipeline_pose2vid_long.py:576-577 (factor 1: unchanged)
+            latents = self.interpolate_latents(latents, interpolation_factor, device)
         images = self.decode_latents(latents)
         if output_type == "tensor":
             images = torch.from_numpy(images)

@@ -865,3 +865,37 @@ def ray_condition(K: Tensor, c2w: Tensor, H: int, W: int) -> Tensor:
     rays_o = c2w[..., :3, 3][:, :, None].expand_as(rays_d)
     rays_dxo = torch.cross(rays_o, rays_d, dim=-1)
     return torch.cat([rays_dxo, rays_d], dim=-1).reshape(B, V, H, W, 6)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Latent interpolation between denoised frames (Pose2VideoPipeline.interpolate_latents,
+# /root/reference/src/pipelines/pipeline_pose2vid_long.py:294-337; blending functions /root/reference/src/pipelines/utils.py:15-30).
+# Pinned by oracle/gen_interp_golden.py (runs the reference's own function bodies) -> tests/golden/latent_interp.npz.
+def interp_linear(v0: Tensor, v1: Tensor, t: float) -> Tensor:
+    return (1.0 - t) * v0 + t * v1  # utils.py:15-16
+
+
+def interp_slerp(v0: Tensor, v1: Tensor, t: float, dot_threshold: float = 0.9995) -> Tensor:
+    """utils.py:19-30: the angle is that of the two WHOLE tensors (one scalar); nearly parallel -> linear blend"""
+    dot = ((v0 / v0.norm()) * (v1 / v1.norm())).sum()
+    if dot.abs() > dot_threshold:
+        return (1.0 - t) * v0 + t * v1
+    omega = dot.acos()
+    return (((1.0 - t) * omega).sin() * v0 + (t * omega).sin() * v1) / omega.sin()
+
+
+def interpolate_latents(latents: Tensor, factor: int, slerp: bool) -> Tensor:
+    """pipeline_pose2vid_long.py:294-337: [B,C,F,h,w] -> [B,C,(F-1)*factor+1,h,w]; between frames i and i+1 the blends at
+    t = 1/factor .. (factor-1)/factor; factor < 2 returns the input."""
+    if factor < 2:
+        return latents
+    blend = interp_slerp if slerp else interp_linear
+    F = latents.shape[2]
+    frames = []
+    for i in range(F - 1):
+        v0, v1 = latents[:, :, i], latents[:, :, i + 1]
+        frames.append(v0)
+        for j in range(1, factor):
+            frames.append(blend(v0, v1, j / factor))
+    frames.append(latents[:, :, F - 1])
+    return torch.stack(frames, dim=2)

@@ -1,0 +1,75 @@
+"""Latent interpolation between denoised frames (Pose2VideoPipeline.interpolate_latents + src.pipelines.utils): the oracle
+restatement and the product's vectorised form against golden vectors produced by the REFERENCE's own function bodies
+(oracle/gen_interp_golden.py -> tests/golden/latent_interp.npz).  Host-side torch code: runs on CPU."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+sys.path.insert(0, os.path.join(REPO, "oracle"))
+import oracle_torch as O  # noqa: E402
+
+from humanvid_amd import latent_interp as LI  # noqa: E402
+
+GOLD = np.load(os.path.join(REPO, "tests", "golden", "latent_interp.npz"))
+CASES = [(n, m, k) for n in ("a", "b", "c") for m in ("linear", "slerp") for k in (1, 2, 3)]
+
+
+@pytest.mark.parametrize("name,method,k", CASES)
+def test_oracle_matches_reference_golden(name, method, k):
+    lat = torch.from_numpy(GOLD["in_" + name])
+    out = O.interpolate_latents(lat, k, method == "slerp")
+    ref = torch.from_numpy(GOLD[f"out_{name}_{method}_{k}"])
+    assert out.shape == ref.shape == (lat.shape[0], lat.shape[1], (lat.shape[2] - 1) * max(k, 1) + 1, *lat.shape[3:])
+    assert float((out - ref).abs().max()) <= 1e-6
+
+
+@pytest.mark.parametrize("name,method,k", CASES)
+def test_product_matches_reference_golden(name, method, k):
+    lat = torch.from_numpy(GOLD["in_" + name])
+    ref = torch.from_numpy(GOLD[f"out_{name}_{method}_{k}"])
+    out = LI.interpolate_latents(lat, k, "cpu", method=method)
+    assert out.shape == ref.shape
+    assert float((out - ref).abs().max()) <= 2e-6, float((out - ref).abs().max())
+    assert torch.equal(out[:, :, ::max(k, 1)], lat)  # the denoised frames themselves pass through untouched
+    LI.set_tensor_interpolation_method(method == "slerp")  # the process-wide selection of src/pipelines/utils.py
+    try:
+        assert torch.equal(LI.interpolate_latents(lat, k, "cpu"), out)
+    finally:
+        LI._METHOD = None
+
+
+def test_blend_functions_and_module_surface():
+    from src.pipelines import utils as U  # the reference's module path
+
+    g = torch.Generator().manual_seed(3)
+    a, b = torch.randn(2, 4, 3, 3, generator=g), torch.randn(2, 4, 3, 3, generator=g)
+    for t in (0.25, 0.5):
+        assert torch.allclose(U.linear(a, b, t), O.interp_linear(a, b, t), atol=1e-7)
+        assert torch.allclose(U.slerp(a, b, t), O.interp_slerp(a, b, t), atol=1e-6)
+        assert torch.allclose(U.slerp(a, 1.0001 * a, t), O.interp_slerp(a, 1.0001 * a, t), atol=1e-6)  # linear branch
+    assert U.get_tensor_interpolation_method() is None
+    U.set_tensor_interpolation_method(True)
+    try:
+        assert U.get_tensor_interpolation_method() is U.slerp
+        U.set_tensor_interpolation_method(False)
+        assert U.get_tensor_interpolation_method() is U.linear
+    finally:
+        LI._METHOD = None
+
+
+def test_unset_method_fails_like_the_reference_and_factor_one_is_identity():
+    lat = torch.from_numpy(GOLD["in_a"])
+    assert LI.interpolate_latents(lat, 1, "cpu") is lat
+    assert LI.interpolate_latents(lat, 0, "cpu") is lat
+    with pytest.raises(TypeError, match="NoneType"):  # the reference: get_tensor_interpolation_method()() with nothing set
+        LI.interpolate_latents(lat, 2, "cpu")
+    from humanvid_amd.pipeline import Pose2VideoPipeline
+
+    pipe = Pose2VideoPipeline(None, None, None, None, None, None, None)
+    out = pipe.interpolate_latents(lat, 1, "cpu")
+    assert out is lat

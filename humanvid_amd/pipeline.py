@@ -130,6 +130,29 @@ class Pose2VideoPipeline:
                 m.to(device=device, dtype=dtype) if dtype is not None else m.to(device=device)
         return self
 
+    def enable_vae_slicing(self):  # pipeline_pose2vid_long.py:83-87: plain delegation to the caller's VAE
+        self.vae.enable_slicing()
+
+    def disable_vae_slicing(self):
+        self.vae.disable_slicing()
+
+    def enable_sequential_cpu_offload(self, gpu_id=0):
+        """pipeline_pose2vid_long.py:89-99 parks the modules in host memory between uses; this path keeps the weights, the
+        reference banks and the step's HIP graph resident in the 288 GB of HBM by design -- refused rather than ignored."""
+        raise NotImplementedError("sequential CPU offload contradicts the resident-weights design of the MI355X path")
+
+    @property
+    def device(self) -> torch.device:
+        for m in (self.denoising_unet, self.reference_unet, self.vae):
+            if m is not None and hasattr(m, "parameters"):
+                for prm in m.parameters():
+                    return prm.device
+        return torch.device("cpu")
+
+    @property
+    def _execution_device(self) -> torch.device:  # pipeline_pose2vid_long.py:101-112 (no accelerate hooks here)
+        return self.device
+
     def enable_frame_sharding(self, group=None, window_groups: Optional[int] = None):
         """Shard every context window along the frame axis over the ranks of `group` (one process per
         GPU, torch.distributed backend "nccl" = RCCL over xGMI).  window_groups = G (default: HUMANVID_WINDOW_GROUPS or 1)

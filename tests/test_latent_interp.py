@@ -73,3 +73,31 @@ def test_unset_method_fails_like_the_reference_and_factor_one_is_identity():
     pipe = Pose2VideoPipeline(None, None, None, None, None, None, None)
     out = pipe.interpolate_latents(lat, 1, "cpu")
     assert out is lat
+
+
+def test_pipeline_housekeeping_surface():
+    """enable/disable_vae_slicing delegate to the caller's VAE, _execution_device is the modules' device, CPU offload is
+    refused (pipeline_pose2vid_long.py:83-112)"""
+    from humanvid_amd.pipeline import Pose2VideoPipeline
+
+    class Vae(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.w = torch.nn.Parameter(torch.zeros(1))
+            self.sliced = None
+
+        def enable_slicing(self):
+            self.sliced = True
+
+        def disable_slicing(self):
+            self.sliced = False
+
+    vae = Vae()
+    pipe = Pose2VideoPipeline(vae, None, None, None, None, None, None)
+    pipe.enable_vae_slicing()
+    assert vae.sliced is True
+    pipe.disable_vae_slicing()
+    assert vae.sliced is False
+    assert pipe._execution_device == pipe.device == torch.device("cpu")
+    with pytest.raises(NotImplementedError):
+        pipe.enable_sequential_cpu_offload()

@@ -598,7 +598,9 @@ __global__ __launch_bounds__(256, 2) void hv_gemm_kernel(HvGemmParams p) {
 //       epilogue run under the other one's MFMAs (measured: in a single resident workgroup the MFMA,
 //       ds_read, LDS-DMA-issue and epilogue times simply add up);
 //   NW = 8: 4 x 2 waves of 64x64 (BN = 128) or 2 x 4 of 128x64 (BN = 256), one workgroup per CU.
-template <int BK, int NS, int BN, int NW, int BM = 256>
+//   PH = 1 (256 x 256 x 64, opt-in tile policies 11 / 12): the k-tile's LDS-DMA instructions as two readiness groups with
+//       counted vmcnt instead of one burst and a drain per k-step (cdna_hip_programming.md T3+T4) -- see the k-loop.
+template <int BK, int NS, int BN, int NW, int BM = 256, int PH = 0>
 __global__ __launch_bounds__(NW * 64, 2) void hv_gemm_glds_kernel(HvGemmParams p, int gm, int form, int walk, int pfd) {
     constexpr int WAVES_N = BN / 64, WAVES_M = NW / WAVES_N;
     constexpr int WTM = BM / WAVES_M, NMF = WTM / 16;
@@ -713,20 +715,21 @@ __global__ __launch_bounds__(NW * 64, 2) void hv_gemm_glds_kernel(HvGemmParams p
         });
     };
     set_tile();
-    auto issue = [&]() __attribute__((always_inline)) {
-        unsigned char* slot = smem + i_slot * SLOT;
-        hv_static_for<XQ>([&](auto Q) __attribute__((always_inline)) {
-            constexpr int q = decltype(Q)::value;
-            unsigned& o = hv_pick4<q>(xo0, xo1, xo2, xo3);
-            hv_glds16(xbase + o, slot + (wave + NW * q) * 1024);
-            o += BK * 2;
-        });
-        hv_static_for<WQ>([&](auto Q) __attribute__((always_inline)) {
-            constexpr int q = decltype(Q)::value;
-            unsigned& o = hv_pick4<q>(wo0, wo1, wo2, wo3);
-            hv_glds16(wbase + o, slot + XT + (wave + NW * q) * 1024);
-            o += BK * 2;
-        });
+    // one DMA instruction of the k-tile being issued (X rows 64 q .. 64 q + 63 / W rows likewise, over the NW waves) ...
+    auto issue_x1 = [&](auto Q) __attribute__((always_inline)) {
+        constexpr int q = decltype(Q)::value;
+        unsigned& o = hv_pick4<q>(xo0, xo1, xo2, xo3);
+        hv_glds16(xbase + o, smem + i_slot * SLOT + (wave + NW * q) * 1024);
+        o += BK * 2;
+    };
+    auto issue_w1 = [&](auto Q) __attribute__((always_inline)) {
+        constexpr int q = decltype(Q)::value;
+        unsigned& o = hv_pick4<q>(wo0, wo1, wo2, wo3);
+        hv_glds16(wbase + o, smem + i_slot * SLOT + XT + (wave + NW * q) * 1024);
+        o += BK * 2;
+    };
+    // ... and the step to the next k-tile once all XQ + WQ of them are out
+    auto issue_advance = [&]() __attribute__((always_inline)) {
         if (++i_slot == NS) i_slot = 0;
         if (++i_k == nk) {
             i_k = 0;
@@ -735,6 +738,19 @@ __global__ __launch_bounds__(NW * 64, 2) void hv_gemm_glds_kernel(HvGemmParams p
         } else if (i_k == k1_steps) {
             set_x(p.X2, p.ldx2);
         }
+    };
+    auto issue = [&]() __attribute__((always_inline)) {
+        if constexpr (PH == 1) {  // readiness-group order: G0 = all of W + the X rows of the first fragment half, G1 = the rest
+            hv_static_for<WQ>([&](auto Q) __attribute__((always_inline)) { issue_w1(Q); });
+            issue_x1(HvInt<0>{});
+            issue_x1(HvInt<2>{});
+            issue_x1(HvInt<1>{});
+            issue_x1(HvInt<3>{});
+        } else {
+            hv_static_for<XQ>([&](auto Q) __attribute__((always_inline)) { issue_x1(Q); });
+            hv_static_for<WQ>([&](auto Q) __attribute__((always_inline)) { issue_w1(Q); });
+        }
+        issue_advance();
     };
 
     // L2 prefetch of the streamed X operand, pfd k-tiles ahead of the LDS-DMA (tuning knob; BK = 64, one k-tile in flight).
@@ -792,7 +808,85 @@ __global__ __launch_bounds__(NW * 64, 2) void hv_gemm_glds_kernel(HvGemmParams p
         if (a < nsteps) issue();
     int c_tile = first, c_k = 0, c_slot = 0;  // consumer state
     int landed = 0;  // k-steps that need no vmcnt wait (see below)
+    static_assert(PH == 0 || (BK == 64 && NS == 2 && BM == 256 && BN == 256 && NW == 8 && HV_GEMM_DEFER),
+                  "the two-group k-loop is written for the 256 x 256 x 64 tile on 8 waves");
     for (int s = 0; s < nsteps; ++s) {
+      if constexpr (PH == 1) {
+        // Two readiness groups per k-tile, counted vmcnt, no drain (cdna_hip_programming.md T3+T4; the one-burst form below
+        // issues its 8 DMA instructions per wave in one go right after the barrier -- gemm_trace: 4000-5000 clocks blocked in
+        // issue on the streamed projections, with the MFMAs waiting behind them -- and drains vmcnt(0) at the end of every
+        // k-step).  A wave multiplies the X rows [128 wm, +128) with the W rows [64 wn, +64).  DMA instruction q of the 8
+        // waves covers rows [64 q, +64) of its operand, so
+        //   G0 = W q=0..3, X q=0, X q=2 : everything the FIRST fragment half (mf 0..3: X rows 128 wm + 0..63) needs,
+        //   G1 = X q=1, X q=3           : the X rows of the second half (mf 4..7).
+        // Each wave issues the k-tile in that order (vmcnt retires in order): G0 of k-tile s+1 during the first half of step
+        // s, G1 of it during the second.  Barrier B0 (step boundary) needs G0(s): the two G1(s) instructions behind it stay
+        // in flight -> vmcnt(2); barrier B1 (mid-step) needs G1(s): the six G0(s+1) instructions behind it stay in flight
+        // -> vmcnt(6).  Slot (s+1) % 2 was last read in step s-1, i.e. before B0(s): free for the whole of step s.
+        // After an epilogue everything has landed (it waits for every load before its first store): both waits of the next
+        // step are skipped, and the stores drain under it (they are older than that step's DMA, so the counted waits of the
+        // step after it retire them first -- a full k-step later).
+        HV_TRACE(1);
+        const bool more = s + 1 < nsteps;
+        const bool skip = landed > 0;
+        if (skip) --landed;
+        else hv_vm_wait<2>();
+        HV_TRACE(2);
+        hv_barrier_raw();
+        HV_TRACE(3);
+        const unsigned char* xs = smem + c_slot * SLOT;
+        const unsigned char* ws = xs + XT;
+        if (++c_slot == NS) c_slot = 0;
+        if (more) {
+            issue_w1(HvInt<0>{});
+            issue_w1(HvInt<1>{});
+            issue_w1(HvInt<2>{});
+        }
+        bf16x8 wf[2][4];
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int f = 0; f < 4; ++f) wf[kk][f] = hv_as_bf16x8(hv_ld16(ws + hv_swz<BK>(64 * wn + 16 * f + r16, kk * 4 + quad)));
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            bf16x8 xf[4];
+#pragma unroll
+            for (int f = 0; f < 4; ++f) xf[f] = hv_as_bf16x8(hv_ld16(xs + hv_swz<BK>(WTM * wm + 16 * f + r16, kk * 4 + quad)));
+            if (kk == 1 && more) {
+                issue_w1(HvInt<3>{});
+                issue_x1(HvInt<0>{});
+                issue_x1(HvInt<2>{});
+            }
+#pragma unroll
+            for (int nf = 0; nf < 4; ++nf)
+#pragma unroll
+                for (int mf = 0; mf < 4; ++mf)
+                    acc[nf][mf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[kk][nf], xf[mf], acc[nf][mf], 0, 0, 0);
+        }
+        HV_TRACE(4);
+        if (!skip) {
+            if (more) hv_vm_wait<6>();
+            else hv_vm_wait<0>();
+        }
+        hv_barrier_raw();
+        if (more) issue_x1(HvInt<1>{});
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            bf16x8 xf[4];
+#pragma unroll
+            for (int f = 0; f < 4; ++f)
+                xf[f] = hv_as_bf16x8(hv_ld16(xs + hv_swz<BK>(WTM * wm + 64 + 16 * f + r16, kk * 4 + quad)));
+            if (kk == 1 && more) {
+                issue_x1(HvInt<3>{});
+                issue_advance();
+            }
+#pragma unroll
+            for (int nf = 0; nf < 4; ++nf)
+#pragma unroll
+                for (int mf = 0; mf < 4; ++mf)
+                    acc[nf][4 + mf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[kk][nf], xf[mf], acc[nf][4 + mf], 0, 0, 0);
+        }
+      } else {
         HV_TRACE(1);
         // this wave's share of k-tile s has landed (up to AHEAD-1 later k-tiles may stay in flight) ...
         // (vmcnt counts stores too, in order: right after an epilogue the youngest outstanding operations are the tile's
@@ -837,6 +931,7 @@ __global__ __launch_bounds__(NW * 64, 2) void hv_gemm_glds_kernel(HvGemmParams p
                 for (int mf = 0; mf < NMF; ++mf)
                     acc[nf][mf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nf], xf[mf], acc[nf][mf], 0, 0, 0);
         }
+      }
         HV_TRACE(5);
         if (++c_k == nk) {
             c_k = 0;
@@ -908,11 +1003,16 @@ static inline int hv_gemm_launch(const HvGemmParams& p, hipStream_t stream) {
         const int t256 = tm * (n256 / 256), rounds256 = (t256 + 255) / 256;
         const bool fills256 = t256 * 10 >= rounds256 * 256 * 9;
         if (ok128 && (g_hv_gemm_glds >= 7) && p.N >= 960 && (n256 - p.N) * 8 <= p.N &&
-            (g_hv_gemm_glds != 8 || p.K >= 640) && (g_hv_gemm_glds != 10 || fills256)) {
+            (g_hv_gemm_glds != 8 || p.K >= 640) && ((g_hv_gemm_glds != 10 && g_hv_gemm_glds != 12) || fills256)) {
             const int tiles = tm * (n256 / 256);
             int grid = ((tiles + 7) / 8) * 8;
             if (grid > 256) grid = 256;
             if (grid > g_hv_gemm_max_grid) grid = g_hv_gemm_max_grid;
+            if (g_hv_gemm_glds >= 11) {  // 11 / 12 = 9 / 10 with the two-readiness-group k-loop (opt-in: not yet measured)
+                hv_note("hv_gemm_glds_kernel<64,2,256,8,256,1> | %s", shape);
+                hv_launch(hv_gemm_glds_kernel<64, 2, 256, 8, 256, 1>, dim3(grid), dim3(512), stream, p, gm, form128, g_hv_gemm_walk, 0);
+                return 0;
+            }
             hv_note("hv_gemm_glds_kernel<64,2,256,8,256> | %s", shape);
             hv_launch(hv_gemm_glds_kernel<64, 2, 256, 8, 256>, dim3(grid), dim3(512), stream, p, gm, form128, g_hv_gemm_walk, g_hv_gemm_pfd);
             return 0;

@@ -2,6 +2,8 @@
 //  1. hv_groupnorm_affine (partial sums + the wave-merge finalize) against a double-precision host reference,
 //  2. hv_gemm under tile policy 10 against policy 9 (same inputs) and against sampled host rows, at the level-2 / level-3
 //     shapes that policy 10 moves from the 256x256x64 to the 128x128x64 kernel.
+// Options: --experimental adds the variants that have not yet run on hardware (tile policies 11 / 12 against 9 / 10, bit for
+// bit); --bench prints ms per launch of the step's GEMM shapes under policies 9 .. 12 (HIP events, no Python start-up).
 // Build: hipcc -O2 -Wno-unused-value tools/hwcheck.cpp -Iinclude -Lhumanvid_amd/lib -lhumanvid_hip -Wl,-rpath,'$ORIGIN/../../humanvid_amd/lib' -o tools/bin/hwcheck
 #include <hip/hip_runtime.h>
 #include <cmath>
@@ -90,7 +92,7 @@ static int check_gn(int n, int pixels, int C1, int C2, int splits, float offset,
     return !(rc == 0 && worst < 2e-4);
 }
 
-static int check_gemm(int M, int N, int K, int form) {  // form 0: bias + residual in place; 1: LayerNorm fold + V^T tail
+static int check_gemm(int M, int N, int K, int form, int pol_a = 9, int pol_b = 10) {  // form 0: bias + residual in place; 1: LayerNorm fold + V^T tail
     std::vector<uint16_t> x((size_t)M * K), w((size_t)N * K), res((size_t)M * N);
     const float ws = 1.0f / sqrtf((float)K);
     for (auto& v : x) v = f2b(rnd() + 0.25f);
@@ -110,7 +112,7 @@ static int check_gemm(int M, int N, int K, int form) {  // form 0: bias + residu
     float *dbias = dev(bias), *dmean = dev(mean), *drstd = dev(rstd), *dcs = dev(colsum);
     std::vector<uint16_t> out[2], outt[2];
     for (int pol = 0; pol < 2; ++pol) {
-        hv_set_tuning(HV_TUNE_GEMM_GLDS, pol ? 10 : 9);
+        hv_set_tuning(HV_TUNE_GEMM_GLDS, pol ? pol_b : pol_a);
         uint16_t* dy = dev(res);  // the residual stream, updated in place (form 0)
         uint16_t* dyt = devz<uint16_t>((size_t)(N - ns + 1) * M);
         hv_gemm_params p;
@@ -122,7 +124,7 @@ static int check_gemm(int M, int N, int K, int form) {  // form 0: bias + residu
         const int rc = hv_gemm(&p, nullptr);
         hipDeviceSynchronize();
         if (rc != 0) {
-            printf("gemm M=%d N=%d K=%d form=%d policy %d: rc=%d (%s) FAIL\n", M, N, K, form, pol ? 10 : 9, rc, hv_last_error());
+            printf("gemm M=%d N=%d K=%d form=%d policy %d: rc=%d (%s) FAIL\n", M, N, K, form, pol ? pol_b : pol_a, rc, hv_last_error());
             return 1;
         }
         out[pol].resize((size_t)M * (form == 1 ? ns : N));
@@ -135,7 +137,7 @@ static int check_gemm(int M, int N, int K, int form) {  // form 0: bias + residu
     double dmax = 0;
     for (size_t i = 0; i < out[0].size(); ++i) dmax = fmax(dmax, fabs(b2f(out[0][i]) - b2f(out[1][i])));
     for (size_t i = 0; i < outt[0].size(); ++i) dmax = fmax(dmax, fabs(b2f(outt[0][i]) - b2f(outt[1][i])));
-    // sampled host rows against policy 10
+    // sampled host rows against the second policy
     double emax = 0, rms = 0;
     long cnt = 0;
     for (int r = 0; r < 24; ++r) {
@@ -150,14 +152,57 @@ static int check_gemm(int M, int N, int K, int form) {  // form 0: bias + residu
     }
     rms = sqrt(rms / cnt);
     const bool ok = dmax <= 0.02 * rms && emax <= 0.02 * rms;
-    printf("gemm M=%d N=%d K=%d form=%d: policy 10 vs 9 max |diff| %.3e, vs host rows max |err| %.3e (rms %.3f) %s\n", M, N, K, form,
-           dmax, emax, rms, ok ? "OK" : "FAIL");
+    printf("gemm M=%d N=%d K=%d form=%d: policy %d vs %d max |diff| %.3e, vs host rows max |err| %.3e (rms %.3f) %s\n", M, N, K, form,
+           pol_b, pol_a, dmax, emax, rms, ok ? "OK" : "FAIL");
     fflush(stdout);
     hipFree(dx), hipFree(dw);
     return !ok;
 }
 
-int main() {
+// --bench: ms per launch of the step's GEMM shapes under the tile policies (operand values do not matter for the timing;
+// LayerNorm-fold forms get zero statistics).  Seconds on the box, no Python start-up: the first measurement of a session.
+static void bench_gemm(int M, int N, int K, int form, const char* what) {  // form 0 residual, 1 LN + V^T tail, 2 LN + GEGLU, 3 LN
+    uint16_t *dx = devz<uint16_t>((size_t)M * K), *dw = devz<uint16_t>((size_t)N * K), *dy = devz<uint16_t>((size_t)M * N);
+    uint16_t* dyt = devz<uint16_t>((size_t)N * M / 3 + 64);
+    float *dbias = devz<float>(N), *dmean = devz<float>(M), *drstd = devz<float>(M), *dcs = devz<float>(N);
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0), hipEventCreate(&e1);
+    printf("%-34s M=%6d N=%5d K=%4d:", what, M, N, K);
+    for (int pol : {9, 10, 11, 12}) {
+        hv_set_tuning(HV_TUNE_GEMM_GLDS, pol);
+        hv_gemm_params p;
+        memset(&p, 0, sizeof p);
+        p.X = dx, p.ldx = K, p.W = dw, p.Y = dy, p.M = M, p.N = N, p.K = K, p.bias = dbias;
+        p.rows_per_image = 1, p.pe_period = 1, p.pe_frames = 1, p.rowvec_period = 1;
+        p.ldy = form == 2 ? N / 2 : (form == 1 ? 2 * N / 3 : N);
+        if (form == 0) p.residual = dy, p.ldr = N;
+        else p.row_mean = dmean, p.row_rstd = drstd, p.colsum = dcs;
+        if (form == 1) p.Yt = dyt, p.ldyt = M, p.n_split = 2 * N / 3;
+        if (form == 2) p.geglu = 1;
+        float ms = -1.f;
+        int rc = 0;
+        for (int rep = 0; rep < 12 && rc == 0; ++rep) {
+            if (rep == 2) hipEventRecord(e0);
+            rc = hv_gemm(&p, nullptr);
+        }
+        hipEventRecord(e1);
+        hipEventSynchronize(e1);
+        hipEventElapsedTime(&ms, e0, e1);
+        if (rc != 0) printf("  p%d rc=%d", pol, rc);
+        else printf("  p%d %.4f ms %6.0f TF/s", pol, ms / 10, 2.0 * M * N * K / (ms / 10) / 1e9);
+    }
+    hv_set_tuning(HV_TUNE_GEMM_GLDS, 9);
+    printf("\n");
+    fflush(stdout);
+    hipFree(dx), hipFree(dw), hipFree(dy), hipFree(dyt);
+}
+
+int main(int argc, char** argv) {
+    bool experimental = false, bench = false;
+    for (int i = 1; i < argc; ++i) {
+        if (!strcmp(argv[i], "--experimental")) experimental = true;  // variants that have not yet run on hardware
+        if (!strcmp(argv[i], "--bench")) bench = true;
+    }
     int bad = 0;
     bad += check_gn(48, 6144, 320, 0, 64, 0.7f, {0, 47});
     bad += check_gn(4, 384, 1280, 640, 8, -2.0f, {0, 3});
@@ -166,6 +211,32 @@ int main() {
     bad += check_gemm(18432, 1280, 1280, 0);
     bad += check_gemm(4608, 1280, 1280, 0);
     bad += check_gemm(18432, 3840, 1280, 1);
+    if (experimental) {  // tile policy 11: the 256x256x64 k-loop with two readiness groups / counted vmcnt (must equal 9 bit for bit)
+        bad += check_gemm(36864, 960, 320, 1, 9, 11);
+        bad += check_gemm(36864, 1280, 320, 0, 9, 11);
+        bad += check_gemm(18432, 3840, 1280, 1, 9, 11);
+        bad += check_gemm(4608, 2560, 64, 0, 9, 11);  // one k-step per tile: an epilogue after every step
+        bad += check_gemm(18432, 3840, 1280, 1, 10, 12);
+    }
+    if (bench) {
+        const int M0 = 48 * 6144, M1 = 48 * 1536, M2 = 48 * 384, M3 = 48 * 96;
+        bench_gemm(M0, 960, 320, 1, "level-0 spatial QKV (LN, V^T)");
+        bench_gemm(M0, 960, 320, 3, "level-0 temporal QKV (LN)");
+        bench_gemm(M0, 2560, 320, 2, "level-0 ff1 (LN, GEGLU)");
+        bench_gemm(M0, 320, 320, 0, "level-0 out-proj (+res)");
+        bench_gemm(M0, 320, 1280, 0, "level-0 ff2 (+res)");
+        bench_gemm(M1, 1920, 640, 1, "level-1 spatial QKV");
+        bench_gemm(M1, 5120, 640, 2, "level-1 ff1");
+        bench_gemm(M1, 640, 640, 0, "level-1 out-proj");
+        bench_gemm(M1, 640, 2560, 0, "level-1 ff2");
+        bench_gemm(M2, 3840, 1280, 1, "level-2 spatial QKV");
+        bench_gemm(M2, 10240, 1280, 2, "level-2 ff1");
+        bench_gemm(M2, 1280, 1280, 0, "level-2 out-proj");
+        bench_gemm(M2, 1280, 5120, 0, "level-2 ff2");
+        bench_gemm(M3, 10240, 1280, 2, "level-3 ff1");
+        bench_gemm(M3, 1280, 1280, 0, "level-3 out-proj");
+        bench_gemm(M3, 1280, 5120, 0, "level-3 ff2");
+    }
     printf("hwcheck: %s\n", bad ? "FAIL" : "all OK");
     return bad;
 }

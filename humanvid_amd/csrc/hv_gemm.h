@@ -740,7 +740,7 @@ __global__ __launch_bounds__(NW * 64, 2) void hv_gemm_glds_kernel(HvGemmParams p
         }
     };
     auto issue = [&]() __attribute__((always_inline)) {
-        if constexpr (PH == 1) {  // readiness-group order: G0 = all of W + the X rows of the first fragment half, G1 = the rest
+        if constexpr (PH >= 1) {  // readiness-group order: G0 = all of W + the X rows of the first fragment half, G1 = the rest
             hv_static_for<WQ>([&](auto Q) __attribute__((always_inline)) { issue_w1(Q); });
             issue_x1(HvInt<0>{});
             issue_x1(HvInt<2>{});
@@ -811,7 +811,7 @@ __global__ __launch_bounds__(NW * 64, 2) void hv_gemm_glds_kernel(HvGemmParams p
     static_assert(PH == 0 || (BK == 64 && NS == 2 && BM == 256 && BN == 256 && NW == 8 && HV_GEMM_DEFER),
                   "the two-group k-loop is written for the 256 x 256 x 64 tile on 8 waves");
     for (int s = 0; s < nsteps; ++s) {
-      if constexpr (PH == 1) {
+      if constexpr (PH >= 1) {
         // Two readiness groups per k-tile, counted vmcnt, no drain (cdna_hip_programming.md T3+T4; the one-burst form below
         // issues its 8 DMA instructions per wave in one go right after the barrier -- gemm_trace: 4000-5000 clocks blocked in
         // issue on the streamed projections, with the MFMAs waiting behind them -- and drains vmcnt(0) at the end of every
@@ -837,7 +837,10 @@ __global__ __launch_bounds__(NW * 64, 2) void hv_gemm_glds_kernel(HvGemmParams p
         const unsigned char* xs = smem + c_slot * SLOT;
         const unsigned char* ws = xs + XT;
         if (++c_slot == NS) c_slot = 0;
-        if (more) {
+        // PH = 2: the same two groups at the eight-phase cadence -- one DMA instruction in front of every 8 MFMAs: W q=0..3
+        // through the first half, X q=0, 2, 1, 3 through the second (G0 is then complete half a step before B0 needs it; at
+        // B1 the four W instructions of k-tile s+1 stay in flight: vmcnt(4)).
+        if (PH == 1 && more) {
             issue_w1(HvInt<0>{});
             issue_w1(HvInt<1>{});
             issue_w1(HvInt<2>{});
@@ -852,39 +855,57 @@ __global__ __launch_bounds__(NW * 64, 2) void hv_gemm_glds_kernel(HvGemmParams p
             bf16x8 xf[4];
 #pragma unroll
             for (int f = 0; f < 4; ++f) xf[f] = hv_as_bf16x8(hv_ld16(xs + hv_swz<BK>(WTM * wm + 16 * f + r16, kk * 4 + quad)));
-            if (kk == 1 && more) {
+            if (PH == 1 && kk == 1 && more) {
                 issue_w1(HvInt<3>{});
                 issue_x1(HvInt<0>{});
                 issue_x1(HvInt<2>{});
             }
 #pragma unroll
-            for (int nf = 0; nf < 4; ++nf)
+            for (int nf = 0; nf < 4; ++nf) {
+                if (PH == 2 && more && (nf & 1) == 0) {
+                    if (kk == 0 && nf == 0) issue_w1(HvInt<0>{});
+                    if (kk == 0 && nf == 2) issue_w1(HvInt<1>{});
+                    if (kk == 1 && nf == 0) issue_w1(HvInt<2>{});
+                    if (kk == 1 && nf == 2) issue_w1(HvInt<3>{});
+                }
 #pragma unroll
                 for (int mf = 0; mf < 4; ++mf)
                     acc[nf][mf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[kk][nf], xf[mf], acc[nf][mf], 0, 0, 0);
+            }
         }
         HV_TRACE(4);
         if (!skip) {
-            if (more) hv_vm_wait<6>();
-            else hv_vm_wait<0>();
+            if (!more) hv_vm_wait<0>();
+            else if (PH == 2) hv_vm_wait<4>();
+            else hv_vm_wait<6>();
         }
         hv_barrier_raw();
-        if (more) issue_x1(HvInt<1>{});
+        if (PH == 1 && more) issue_x1(HvInt<1>{});
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
             bf16x8 xf[4];
 #pragma unroll
             for (int f = 0; f < 4; ++f)
                 xf[f] = hv_as_bf16x8(hv_ld16(xs + hv_swz<BK>(WTM * wm + 64 + 16 * f + r16, kk * 4 + quad)));
-            if (kk == 1 && more) {
+            if (PH == 1 && kk == 1 && more) {
                 issue_x1(HvInt<3>{});
                 issue_advance();
             }
 #pragma unroll
-            for (int nf = 0; nf < 4; ++nf)
+            for (int nf = 0; nf < 4; ++nf) {
+                if (PH == 2 && more && (nf & 1) == 0) {
+                    if (kk == 0 && nf == 0) issue_x1(HvInt<0>{});
+                    if (kk == 0 && nf == 2) issue_x1(HvInt<2>{});
+                    if (kk == 1 && nf == 0) issue_x1(HvInt<1>{});
+                    if (kk == 1 && nf == 2) {
+                        issue_x1(HvInt<3>{});
+                        issue_advance();
+                    }
+                }
 #pragma unroll
                 for (int mf = 0; mf < 4; ++mf)
                     acc[nf][4 + mf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[kk][nf], xf[mf], acc[nf][4 + mf], 0, 0, 0);
+            }
         }
       } else {
         HV_TRACE(1);
@@ -1003,11 +1024,16 @@ static inline int hv_gemm_launch(const HvGemmParams& p, hipStream_t stream) {
         const int t256 = tm * (n256 / 256), rounds256 = (t256 + 255) / 256;
         const bool fills256 = t256 * 10 >= rounds256 * 256 * 9;
         if (ok128 && (g_hv_gemm_glds >= 7) && p.N >= 960 && (n256 - p.N) * 8 <= p.N &&
-            (g_hv_gemm_glds != 8 || p.K >= 640) && ((g_hv_gemm_glds != 10 && g_hv_gemm_glds != 12) || fills256)) {
+            (g_hv_gemm_glds != 8 || p.K >= 640) && ((g_hv_gemm_glds != 10 && g_hv_gemm_glds != 12 && g_hv_gemm_glds != 14) || fills256)) {
             const int tiles = tm * (n256 / 256);
             int grid = ((tiles + 7) / 8) * 8;
             if (grid > 256) grid = 256;
             if (grid > g_hv_gemm_max_grid) grid = g_hv_gemm_max_grid;
+            if (g_hv_gemm_glds >= 13) {  // 13 / 14 = 9 / 10 with the two-group k-loop at the eight-phase issue cadence
+                hv_note("hv_gemm_glds_kernel<64,2,256,8,256,2> | %s", shape);
+                hv_launch(hv_gemm_glds_kernel<64, 2, 256, 8, 256, 2>, dim3(grid), dim3(512), stream, p, gm, form128, g_hv_gemm_walk, 0);
+                return 0;
+            }
             if (g_hv_gemm_glds >= 11) {  // 11 / 12 = 9 / 10 with the two-readiness-group k-loop (opt-in: not yet measured)
                 hv_note("hv_gemm_glds_kernel<64,2,256,8,256,1> | %s", shape);
                 hv_launch(hv_gemm_glds_kernel<64, 2, 256, 8, 256, 1>, dim3(grid), dim3(512), stream, p, gm, form128, g_hv_gemm_walk, 0);

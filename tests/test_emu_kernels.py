@@ -126,8 +126,8 @@ def test_gemm_tile_walks(cx):
 
 
 def test_gemm_two_group_k_loop(cx):
-    """tile policies 11 / 12: the 256x256x64 kernel with its LDS-DMA issued as two readiness groups under counted vmcnt
-    (hv_gemm_glds_kernel<..., PH = 1>).  The emulator checks the indexing of the split issue / split fragment halves and the
+    """tile policies 11 / 12 (13 / 14): the 256x256x64 kernel with its LDS-DMA issued as two readiness groups under counted
+    vmcnt (hv_gemm_glds_kernel<..., PH = 1>; PH = 2: one DMA instruction in front of every 8 MFMAs).  The emulator checks the indexing of the split issue / split fragment halves and the
     tile hand-over (one k-step per tile, several, a second K source); results must equal the one-burst kernel bit for bit
     (same MFMA order per accumulator)."""
     import torch
@@ -141,6 +141,11 @@ def test_gemm_two_group_k_loop(cx):
             kc.case_gemm_forms(cx, M=1300, C=192, N=1024, P=128, form=form, seed=91)         # 3 k-steps per tile
         kc.case_gemm_forms(cx, M=700, C=64, N=1024, P=128, form="res", seed=92)               # one k-step per tile
         kc.case_gemm(cx, M=520, N=1024, K=256, seed=93, two_source=True)                      # second source from k-tile 2 on
+        cx.lib.call("hv_set_tuning", 3, 13)                                                   # eight-phase issue cadence
+        for form in ("ln_yt", "ln_geglu", "res"):
+            kc.case_gemm_forms(cx, M=1300, C=192, N=1024, P=128, form=form, seed=91)
+        kc.case_gemm_forms(cx, M=700, C=64, N=1024, P=128, form="res", seed=92)
+        kc.case_gemm(cx, M=520, N=1024, K=256, seed=93, two_source=True)
         cx.lib.call("hv_set_tuning", 3, 12)                                                   # 11 + the fill test of 10
         kc.case_gemm_forms(cx, M=256 * 58, C=64, N=1024, P=128, form="plain", seed=85)        # 232 of 256 tiles: 256x256 kernel
         kc.case_gemm_forms(cx, M=700, C=64, N=1024, P=128, form="res", seed=92)               # 12 tiles: 128x128x64 kernel
@@ -149,13 +154,13 @@ def test_gemm_two_group_k_loop(cx):
         w = cx.bf(torch.randn(1280, 320, generator=g) * 320**-0.5)
         bias = cx.dev(torch.randn(1280, generator=g) * 0.1)
         outs = []
-        for policy in (9, 11):
+        for policy in (9, 11, 13):
             cx.lib.call("hv_set_tuning", 3, policy)
             y = torch.zeros(1100, 1280, dtype=torch.bfloat16, device=cx.device)
             ops.gemm(cx.lib, cx.stream, x, w, y, bias=bias)
             cx.sync()
             outs.append(y.clone())
-        assert torch.equal(outs[0], outs[1])
+        assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
     finally:
         cx.lib.call("hv_set_tuning", 3, 9)
         cx.lib.call("hv_set_tuning", 2, 512)

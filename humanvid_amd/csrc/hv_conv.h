@@ -20,17 +20,20 @@
 #include "hv_gemm.h"  // hv_swz
 #include "humanvid_hip.h"
 
-template <int TW, int MODE, int NPIX = 128, int WPX = 64>
+template <int TW, int MODE, int NPIX = 128, int WPX = 64, int CK = 32>
 struct HvConvGeom {
     static constexpr int NT = 2 * 64 * (NPIX / WPX);   // threads: one wave per WPX pixels x 64 channels
     static constexpr int TH = NPIX / TW;
     static constexpr int HH = MODE == HV_CONV_S1 ? TH + 2 : (MODE == HV_CONV_S2 ? 2 * TH + 1 : TH / 2 + 2);
     static constexpr int HW = MODE == HV_CONV_S1 ? TW + 2 : (MODE == HV_CONV_S2 ? 2 * TW + 1 : TW / 2 + 2);
     static constexpr int HP = HH * HW;
-    static constexpr int PS = 80;  // bytes per halo pixel in LDS
+    static constexpr int CPP = CK / 8;        // 16-byte pieces per pixel and channel chunk
+    static constexpr int PS = CK * 2 + 16;    // bytes per halo pixel in LDS: data + 16 B pad (80 / 144: an odd number of 16-byte
+                                              // units, so the 16 consecutive pixels of a ds_read_b128 group hit distinct banks)
     static constexpr int HALO_BYTES = ((HP * PS + 15) / 16) * 16;
-    static constexpr int HALO_ITERS = (HP * 4 + NT - 1) / NT;
-    static constexpr int WTILE_BYTES = 128 * 64;
+    static constexpr int HALO_ITERS = (HP * CPP + NT - 1) / NT;
+    static constexpr int WTILE_BYTES = 128 * CK * 2;
+    static constexpr int HBUFS = CK == 64 ? 1 : 2;  // CK = 64: one halo buffer (an extra barrier per chunk) keeps two workgroups per CU
 };
 
 // GLDS = true: the weight tiles stream HBM/L2 -> LDS with global_load_lds into a 3-slot ring (two
@@ -41,15 +44,21 @@ struct HvConvGeom {
 // WPX = 128 (round 2, NPIX = 256 on 4 waves): a wave owns 128 pixels x 64 channels (8 x 4 MFMA fragments, 128 accumulator
 // registers) -- 32 MFMAs per 12 ds_read_b128 and per barrier instead of 16 per 8, the weight tile of a tap serves twice the
 // pixels, the 18 x 18 halo of a 16 x 16 patch carries 27 % border instead of 41 %; 76 KiB of LDS, two workgroups per CU.
-template <int TW, int MODE, bool GLDS, int NPIX, int WPX = 64>
+// CK = 64 (round 2, opt-in: HV_TUNE_CONV_BIG = 3; stride 1, C1 and C2 multiples of 64): the reduction runs over 64-channel
+// chunks -- the weight rows of a tap are whole 128-byte lines (the LDS-DMA path moves 64-byte row segments at half the rate:
+// the finding behind the GEMM's BK = 64), every tap step carries 32 MFMAs per wave behind its barrier instead of 16, and the
+// number of steps, barriers and DMA instructions halves.  74 KiB of LDS (one 26 KiB halo buffer, three 16 KiB weight slots).
+template <int TW, int MODE, bool GLDS, int NPIX, int WPX = 64, int CK = 32>
 __global__ __launch_bounds__(2 * 64 * (NPIX / WPX), (WPX == 128 ? 2 : 1)) void hv_conv3x3_kernel(hv_conv3x3_params p) {
-    using G = HvConvGeom<TW, MODE, NPIX, WPX>;
+    using G = HvConvGeom<TW, MODE, NPIX, WPX, CK>;
+    static_assert(CK == 32 || (CK == 64 && GLDS), "64-channel chunks stream their weights by LDS-DMA");
     constexpr int TH = G::TH;
     constexpr int NT = G::NT, NW = NT / 64, WM = NPIX / WPX, NMF = WPX / 16;
+    constexpr int CPP = G::CPP, CPP_SH = CK == 64 ? 3 : 2;  // shifts / masks: lane and thread indices are non-negative
     constexpr int WSLOTS = GLDS ? 3 : 2;
-    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * G::HALO_BYTES + WSLOTS * G::WTILE_BYTES];
+    __shared__ __attribute__((aligned(16))) unsigned char smem[G::HBUFS * G::HALO_BYTES + WSLOTS * G::WTILE_BYTES];
     unsigned char* halo = smem;
-    unsigned char* wsm = smem + 2 * G::HALO_BYTES;
+    unsigned char* wsm = smem + G::HBUFS * G::HALO_BYTES;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave % WM, wn = wave / WM, r16 = lane & 15, quad = lane >> 4;
@@ -80,23 +89,23 @@ __global__ __launch_bounds__(2 * 64 * (NPIX / WPX), (WPX == 128 ? 2 : 1)) void h
         in_x0 = x0 / 2 - 1;
     }
 
-    const int nchunks = Cin / 32;
+    const int nchunks = Cin / CK;
     const int nsteps = nchunks * 9;
-    const int hc = tid & 3;  // this thread's 16-byte channel slot inside a chunk (constant, 256 % 4 == 0)
+    const int hc = tid & (CPP - 1);  // this thread's 16-byte channel slot inside a chunk (constant: NT % CPP == 0)
 
     u32x4 hreg[G::HALO_ITERS];
-    constexpr int WIT = 512 / NT;  // 16-byte chunks of a weight tile per thread
+    constexpr int WIT = (128 * CPP) / NT;  // 16-byte chunks of a weight tile per thread
     u32x4 wreg[WIT];
 
     auto load_halo = [&](int chunk) {
-        const int ci = chunk * 32 + hc * 8;
+        const int ci = chunk * CK + hc * 8;
         const bool second = ci >= p.C1;
         const bf16_t* base = second ? p.X2 : p.X;
         const int cs = second ? p.C2 : p.C1;
         const int cc = second ? ci - p.C1 : ci;
 #pragma unroll
         for (int j = 0; j < G::HALO_ITERS; ++j) {
-            const int hp = (tid + NT * j) >> 2;
+            const int hp = (tid + NT * j) >> CPP_SH;
             u32x4 v = {0u, 0u, 0u, 0u};
             if (hp < G::HP) {
                 const int iy = in_y0 + hp / G::HW, ix = in_x0 + hp % G::HW;
@@ -108,7 +117,7 @@ __global__ __launch_bounds__(2 * 64 * (NPIX / WPX), (WPX == 128 ? 2 : 1)) void h
     };
 
     auto store_halo = [&](int chunk, int buf) {
-        const int ci = chunk * 32 + hc * 8;
+        const int ci = chunk * CK + hc * 8;
         float sc[8], sh[8];
         const bool pro = p.pro_scale != nullptr;
         if (pro) {
@@ -120,7 +129,7 @@ __global__ __launch_bounds__(2 * 64 * (NPIX / WPX), (WPX == 128 ? 2 : 1)) void h
         }
 #pragma unroll
         for (int j = 0; j < G::HALO_ITERS; ++j) {
-            const int hp = (tid + NT * j) >> 2;
+            const int hp = (tid + NT * j) >> CPP_SH;
             if (hp >= G::HP) continue;
             u32x4 v = hreg[j];
             if (pro || p.pro_act != HV_ACT_NONE) {
@@ -145,10 +154,10 @@ __global__ __launch_bounds__(2 * 64 * (NPIX / WPX), (WPX == 128 ? 2 : 1)) void h
 #pragma unroll
         for (int i = 0; i < WIT; ++i) {
             const int id = tid + NT * i;
-            const int row = id >> 2, c = id & 3;
+            const int row = id >> CPP_SH, c = id & (CPP - 1);
             const int n = n0 + row;
             u32x4 v = {0u, 0u, 0u, 0u};
-            if (n < p.Cout) v = hv_ld16(p.W + ((long)n * 9 + tap) * Cin + chunk * 32 + c * 8);
+            if (n < p.Cout) v = hv_ld16(p.W + ((long)n * 9 + tap) * Cin + chunk * CK + c * 8);
             wreg[i] = v;
         }
     };
@@ -156,7 +165,7 @@ __global__ __launch_bounds__(2 * 64 * (NPIX / WPX), (WPX == 128 ? 2 : 1)) void h
 #pragma unroll
         for (int i = 0; i < WIT; ++i) {
             const int id = tid + NT * i;
-            hv_st16(wsm + buf * G::WTILE_BYTES + hv_swz<32>(id >> 2, id & 3), wreg[i]);
+            hv_st16(wsm + buf * G::WTILE_BYTES + hv_swz<CK>(id >> CPP_SH, id & (CPP - 1)), wreg[i]);
         }
     };
     // LDS-DMA form: 8 wave-instructions of 1 KiB (16 rows x 64 B) per tap tile, 8 / NW per wave; the swizzle of
@@ -164,28 +173,34 @@ __global__ __launch_bounds__(2 * 64 * (NPIX / WPX), (WPX == 128 ? 2 : 1)) void h
     // (weight row, swizzled chunk) is computed once (wofs, 32-bit byte offsets: hv_conv3x3_launch checks the span), the
     // per-step part (tap, channel chunk) is a scalar added to the base; the copies are issued from inline asm
     // (hv_glds16_s) so that hipcc's wait-count tracker does not put a vmcnt(0) in front of every ds_read of the step.
-    constexpr int WQ = 8 / NW;
+    constexpr int RPI = 1024 / (CK * 2);            // weight rows per 1 KiB wave-instruction: 16 (CK = 32) / 8 (CK = 64)
+    constexpr int WQ = (G::WTILE_BYTES / 1024) / NW;  // DMA instructions per wave and tap tile
+    static_assert(WQ >= 1 && WQ <= 4, "one to four LDS-DMA instructions per wave and tap");
 #ifndef HV_EMU
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
 #else
     const int wave_u = wave;
 #endif
-    unsigned wofs0 = 0, wofs1 = 0;
+    unsigned wofs0 = 0, wofs1 = 0, wofs2 = 0, wofs3 = 0;
     {
-        const int sub = lane >> 2, pc = lane & 3;
-        const int row0 = 16 * wave_u + sub;
-        wofs0 = ((unsigned)min(n0 + row0, p.Cout - 1) * 9u * (unsigned)Cin + (unsigned)((pc ^ ((row0 >> 2) & 3)) * 8)) * 2u;
-        if (WQ > 1) {
-            const int row1 = 16 * (wave_u + NW) + sub;
-            wofs1 = ((unsigned)min(n0 + row1, p.Cout - 1) * 9u * (unsigned)Cin + (unsigned)((pc ^ ((row1 >> 2) & 3)) * 8)) * 2u;
-        }
+        const int sub = lane >> CPP_SH, pc = lane & (CPP - 1);
+        constexpr int RPB_SH = CK == 64 ? 1 : 2;  // log2(rows per 256-byte bank row): the swizzle of hv_swz<CK> on the source side
+        hv_static_for<WQ>([&](auto Q) __attribute__((always_inline)) {
+            constexpr int q = decltype(Q)::value;
+            const int row = RPI * (wave_u + NW * q) + sub;
+            hv_pick4<q>(wofs0, wofs1, wofs2, wofs3) =
+                ((unsigned)min(n0 + row, p.Cout - 1) * 9u * (unsigned)Cin + (unsigned)((pc ^ ((row >> RPB_SH) & (CPP - 1))) * 8)) * 2u;
+        });
     }
     int iw_chunk = 0, iw_tap = 0, iw_slot = 0;  // issue state: advanced one step per call
     auto issue_w = [&]() __attribute__((always_inline)) {
         unsigned char* slot = wsm + iw_slot * G::WTILE_BYTES;
-        const unsigned step = (unsigned)(iw_tap * Cin + iw_chunk * 32) * 2u;  // wave-uniform part of the offset
-        hv_glds16_s(p.W, wofs0 + step, slot + wave_u * 1024);  // base = the kernel argument: always an SGPR pair
-        if (WQ > 1) hv_glds16_s(p.W, wofs1 + step, slot + (wave_u + NW) * 1024);
+        const unsigned step = (unsigned)(iw_tap * Cin + iw_chunk * CK) * 2u;  // wave-uniform part of the offset
+        hv_static_for<WQ>([&](auto Q) __attribute__((always_inline)) {
+            constexpr int q = decltype(Q)::value;
+            // base = the kernel argument: always an SGPR pair
+            hv_glds16_s(p.W, hv_pick4<q>(wofs0, wofs1, wofs2, wofs3) + step, slot + (wave_u + NW * q) * 1024);
+        });
         if (++iw_slot == 3) iw_slot = 0;
         if (++iw_tap == 9) {
             iw_tap = 0;
@@ -226,15 +241,19 @@ __global__ __launch_bounds__(2 * 64 * (NPIX / WPX), (WPX == 128 ? 2 : 1)) void h
     // which drained the LDS-DMA weight ring in every step.  Unrolled, the only compiler waits left are the true ones at
     // tap 0, and the tap offsets / ring slots (9 % 3 == 0) are immediates.)
     for (int chunk = 0; chunk < nchunks; ++chunk) {
-        const int hbuf = chunk & 1;
+        const int hbuf = G::HBUFS == 2 ? (chunk & 1) : 0;
         hv_static_for<9>([&](auto T) __attribute__((always_inline)) {
             constexpr int tap = decltype(T)::value;
             const int s = chunk * 9 + tap;
             const int wbuf = GLDS ? tap % 3 : (s & 1);
-            if (tap == 0) store_halo(chunk, hbuf);
+            if (tap == 0) {
+                // one halo buffer: every wave must be done with the previous chunk's tap-8 reads before it is overwritten
+                if (G::HBUFS == 1 && chunk > 0) hv_barrier_raw();
+                store_halo(chunk, hbuf);
+            }
             if (GLDS) {
                 if (s + 1 < nsteps)
-                    hv_vm_wait<8 / NW>();  // tap tile s landed, tile s+1 may stay in flight
+                    hv_vm_wait<WQ>();  // tap tile s landed, tile s+1 may stay in flight
                 else
                     hv_vm_wait<0>();
                 hv_barrier_raw();
@@ -251,29 +270,33 @@ __global__ __launch_bounds__(2 * 64 * (NPIX / WPX), (WPX == 128 ? 2 : 1)) void h
             constexpr int dy = tap / 3, dx = tap - dy * 3;
             const unsigned char* hb = halo + hbuf * G::HALO_BYTES + quad * 16;
             const unsigned char* wb = wsm + wbuf * G::WTILE_BYTES;
-            bf16x8 wf[4];
 #pragma unroll
-            for (int f = 0; f < 4; ++f) wf[f] = hv_as_bf16x8(hv_ld16(wb + hv_swz<32>(64 * wn + 16 * f + r16, quad)));
-            // pixel fragments in groups of four (16 registers of operands at a time)
+            for (int kk = 0; kk < CK / 32; ++kk) {  // 32-channel MFMA slices of the chunk
+                bf16x8 wf[4];
 #pragma unroll
-            for (int g = 0; g < NMF; g += 4) {
-                bf16x8 xf[4];
+                for (int f = 0; f < 4; ++f)
+                    wf[f] = hv_as_bf16x8(hv_ld16(wb + hv_swz<CK>(64 * wn + 16 * f + r16, kk * 4 + quad)));
+                // pixel fragments in groups of four (16 registers of operands at a time)
 #pragma unroll
-                for (int f = 0; f < 4; ++f) {
-                    int lp;
-                    if (MODE == HV_CONV_S1)
-                        lp = lpb[g + f] + dy * G::HW + dx;
-                    else if (MODE == HV_CONV_S2)
-                        lp = lpb[g + f] + dy * G::HW + dx;
-                    else
-                        lp = ((py[g + f] + dy + 1) >> 1) * G::HW + ((px[g + f] + dx + 1) >> 1);
-                    xf[f] = hv_as_bf16x8(hv_ld16(hb + lp * G::PS));
+                for (int g = 0; g < NMF; g += 4) {
+                    bf16x8 xf[4];
+#pragma unroll
+                    for (int f = 0; f < 4; ++f) {
+                        int lp;
+                        if (MODE == HV_CONV_S1)
+                            lp = lpb[g + f] + dy * G::HW + dx;
+                        else if (MODE == HV_CONV_S2)
+                            lp = lpb[g + f] + dy * G::HW + dx;
+                        else
+                            lp = ((py[g + f] + dy + 1) >> 1) * G::HW + ((px[g + f] + dx + 1) >> 1);
+                        xf[f] = hv_as_bf16x8(hv_ld16(hb + lp * G::PS + kk * 64));
+                    }
+#pragma unroll
+                    for (int nf = 0; nf < 4; ++nf)
+#pragma unroll
+                        for (int mf = 0; mf < 4; ++mf)
+                            acc[nf][g + mf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nf], xf[mf], acc[nf][g + mf], 0, 0, 0);
                 }
-#pragma unroll
-                for (int nf = 0; nf < 4; ++nf)
-#pragma unroll
-                    for (int mf = 0; mf < 4; ++mf)
-                        acc[nf][g + mf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nf], xf[mf], acc[nf][g + mf], 0, 0, 0);
             }
         });
     }
@@ -329,19 +352,19 @@ static int g_hv_conv_glds = 1;  // tuning knob (hv_set_tuning): LDS-DMA weight t
 
 static int g_hv_conv_big = 1;  // tuning knob: 256-pixel tiles (8 waves) on images that fill them
 
-template <int TW, int MODE, int NPIX, int WPX = 64>
+template <int TW, int MODE, int NPIX, int WPX = 64, int CK = 32>
 static inline void hv_conv3x3_launch_t(const hv_conv3x3_params& p, hipStream_t stream) {
     constexpr int TH = NPIX / TW;
     constexpr int NT = 2 * 64 * (NPIX / WPX);
     const int tiles = p.n_images * ((p.Ho + TH - 1) / TH) * ((p.Wo + TW - 1) / TW) * ((p.Cout + 127) / 128);
     const int grid = ((tiles + 7) / 8) * 8;
-    hv_note("hv_conv3x3_kernel<%d,%d,%d,%d%s> | n=%d Hs=%d Ws=%d Ho=%d Wo=%d Cin=%d Cout=%d gn=%d res=%d", TW, MODE,
-            g_hv_conv_glds, NPIX, WPX == 128 ? ",128" : "", p.n_images, p.Hs, p.Ws, p.Ho, p.Wo, p.C1 + p.C2, p.Cout, p.pro_scale != nullptr,
-            p.residual != nullptr);
-    if (g_hv_conv_glds || WPX == 128)
-        hv_launch(hv_conv3x3_kernel<TW, MODE, true, NPIX, WPX>, dim3(grid), dim3(NT), stream, p);
-    else
-        hv_launch(hv_conv3x3_kernel<TW, MODE, false, NPIX, WPX>, dim3(grid), dim3(NT), stream, p);
+    hv_note("hv_conv3x3_kernel<%d,%d,%d,%d%s%s> | n=%d Hs=%d Ws=%d Ho=%d Wo=%d Cin=%d Cout=%d gn=%d res=%d", TW, MODE,
+            g_hv_conv_glds, NPIX, WPX == 128 ? ",128" : "", CK == 64 ? ",ck64" : "", p.n_images, p.Hs, p.Ws, p.Ho, p.Wo, p.C1 + p.C2,
+            p.Cout, p.pro_scale != nullptr, p.residual != nullptr);
+    if (g_hv_conv_glds || WPX == 128 || CK == 64)
+        hv_launch(hv_conv3x3_kernel<TW, MODE, true, NPIX, WPX, CK>, dim3(grid), dim3(NT), stream, p);
+    else if constexpr (CK == 32)
+        hv_launch(hv_conv3x3_kernel<TW, MODE, false, NPIX, WPX, CK>, dim3(grid), dim3(NT), stream, p);
 }
 
 static inline int hv_conv3x3_launch(const hv_conv3x3_params& p, hipStream_t stream) {
@@ -360,9 +383,13 @@ static inline int hv_conv3x3_launch(const hv_conv3x3_params& p, hipStream_t stre
     const bool big = g_hv_conv_big && !narrow && p.Ho >= 16 && p.mode == HV_CONV_UP2;
     // 256-pixel tiles on 4 waves of 128 pixels (tuning value 2): stride-1 convolutions whose images fill 16 x 16 patches
     const bool wide = g_hv_conv_big == 2 && !narrow && p.Ho >= 16 && p.Wo >= 16 && p.mode == HV_CONV_S1;
+    // 64-channel chunks (tuning value 3; opt-in until measured): stride 1, both sources in whole 64-channel chunks
+    const bool ck64 = g_hv_conv_big == 3 && p.mode == HV_CONV_S1 && p.C1 % 64 == 0 && p.C2 % 64 == 0;
     switch (p.mode) {
         case HV_CONV_S1:
-            if (wide) hv_conv3x3_launch_t<16, HV_CONV_S1, 256, 128>(p, stream);
+            if (ck64 && narrow) hv_conv3x3_launch_t<8, HV_CONV_S1, 128, 64, 64>(p, stream);
+            else if (ck64) hv_conv3x3_launch_t<16, HV_CONV_S1, 128, 64, 64>(p, stream);
+            else if (wide) hv_conv3x3_launch_t<16, HV_CONV_S1, 256, 128>(p, stream);
             else if (big) hv_conv3x3_launch_t<16, HV_CONV_S1, 256>(p, stream);
             else if (narrow) hv_conv3x3_launch_t<8, HV_CONV_S1, 128>(p, stream);
             else hv_conv3x3_launch_t<16, HV_CONV_S1, 128>(p, stream);

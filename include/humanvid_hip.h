@@ -190,7 +190,7 @@ int hv_attention_fp8(const hv_attention_params* p, const float* kscale, const fl
 #define HV_TUNE_CONV_GLDS 4     /* 1: conv weight tiles by LDS-DMA (default), 0: register-staged */
 #define HV_TUNE_GEMM_RASTER 6   /* m-blocks per tile-raster group of the LDS-DMA GEMM (0 = auto, 1 = row-major) */
 #define HV_TUNE_TEMPORAL_MFMA 7 /* temporal attention: 1 = MFMA kernel, one wave per (batch, pixel, head) (default), 0 = VALU kernel */
-#define HV_TUNE_CONV_BIG 5      /* 1: 256-pixel conv tiles where the image fills them (default), 0: 128 */
+#define HV_TUNE_CONV_BIG 5      /* 1: 256-pixel conv tiles where the image fills them (default), 0: 128; 2: 256-pixel tiles on 4 waves of 128 pixels for stride-1 convolutions (measured slower); 3: 64-channel reduction chunks for stride-1 convolutions (whole 128-byte weight lines by LDS-DMA, 32 MFMAs per tap step; written at the end of round 2, emulator-checked, not yet measured) */
 #define HV_TUNE_GEMM_WALK 8     /* LDS-DMA GEMM tile walk: 1 = every workgroup takes a contiguous run of tiles, 0 = strided over the XCD's range (default) */
 #define HV_TUNE_GEMM_PREFETCH 9 /* LDS-DMA GEMM: L2 prefetch of the X operand this many k-tiles ahead (0 = off) */
 int hv_set_tuning(int key, int value);

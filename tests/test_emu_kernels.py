@@ -221,6 +221,24 @@ def test_conv_wide_wave_tiles(cx):
         cx.lib.call("hv_set_tuning", 5, 1)
 
 
+def test_conv_64_channel_chunks(cx):
+    """stride-1 convs with 64-channel reduction chunks (tuning value 3: whole 128-byte weight lines by LDS-DMA, one halo
+    buffer, 32 MFMAs per tap step): 16x8 and 8x16 patches, ragged images and output channels, two sources in whole chunks,
+    GroupNorm + SiLU prologue on and off, several chunks (the single halo buffer is rewritten per chunk); sources that are
+    not multiples of 64 channels keep the 32-channel kernel"""
+    cx.lib.call("hv_set_tuning", 5, 3)
+    try:
+        kc.case_conv(cx, n=2, H=12, W=20, C1=64, Cout=40, mode=A.CONV_S1, seed=61)
+        kc.case_conv(cx, n=1, H=9, W=17, C1=64, C2=64, Cout=132, mode=A.CONV_S1, seed=62)                       # two sources, 2 chunks
+        kc.case_conv(cx, n=1, H=10, W=18, C1=192, Cout=24, mode=A.CONV_S1, pro=False, temb=False, residual=False, seed=63)  # 3 chunks
+        kc.case_conv(cx, n=2, H=12, W=8, C1=128, Cout=36, mode=A.CONV_S1, seed=64)                               # narrow: 8 x 16 patch
+        kc.case_conv(cx, n=1, H=5, W=7, C1=64, C2=128, Cout=8, mode=A.CONV_S1, seed=65)
+        kc.case_conv(cx, n=1, H=12, W=20, C1=64, C2=32, Cout=40, mode=A.CONV_S1, seed=66)                        # C2 = 32: 32-channel kernel
+        kc.case_conv(cx, n=1, H=8, W=10, C1=64, Cout=40, mode=A.CONV_UP2, seed=67)                               # other modes unchanged
+    finally:
+        cx.lib.call("hv_set_tuning", 5, 1)
+
+
 def test_conv_register_staged_variant(cx):
     cx.lib.call("hv_set_tuning", 4, 0)
     try:

@@ -2,8 +2,8 @@
 //  1. hv_groupnorm_affine (partial sums + the wave-merge finalize) against a double-precision host reference,
 //  2. hv_gemm under tile policy 10 against policy 9 (same inputs) and against sampled host rows, at the level-2 / level-3
 //     shapes that policy 10 moves from the 256x256x64 to the 128x128x64 kernel.
-// Options: --experimental adds the variants that have not yet run on hardware (tile policies 11 / 12 against 9 / 10, bit for
-// bit); --bench prints ms per launch of the step's GEMM shapes under policies 9, 10, 11, 13 (HIP events, no Python start-up).
+// Options: --experimental adds the variants that have not yet run on hardware (tile policies 11 / 12 / 13 against 9 / 10, bit
+// for bit; the 64-channel-chunk convolution against the default one); --bench prints ms per launch of the step's GEMM shapes under policies 9, 10, 11, 13 (HIP events, no Python start-up).
 // Build: hipcc -O2 -Wno-unused-value tools/hwcheck.cpp -Iinclude -Lhumanvid_amd/lib -lhumanvid_hip -Wl,-rpath,'$ORIGIN/../../humanvid_amd/lib' -o tools/bin/hwcheck
 #include <hip/hip_runtime.h>
 #include <cmath>
@@ -197,6 +197,66 @@ static void bench_gemm(int M, int N, int K, int form, const char* what) {  // fo
     hipFree(dx), hipFree(dw), hipFree(dy), hipFree(dyt);
 }
 
+// 3x3 convolution (stride 1, GroupNorm + SiLU prologue, bias, residual) under two values of HV_TUNE_CONV_BIG: outputs compared
+// (different summation order: not bit-identical) and both timed.
+static int conv_ab(int n, int H, int W, int Cin, int Cout, int tune_a, int tune_b, bool time_only) {
+    std::vector<uint16_t> x((size_t)n * H * W * Cin), w((size_t)Cout * 9 * Cin), res((size_t)n * H * W * Cout);
+    const float ws = 1.0f / sqrtf(9.0f * Cin);
+    for (auto& v : x) v = f2b(rnd());
+    for (auto& v : w) v = f2b(rnd() * ws * 1.7f);
+    for (auto& v : res) v = f2b(rnd());
+    std::vector<float> sc((size_t)n * Cin), sh((size_t)n * Cin), bias(Cout);
+    for (auto& v : sc) v = 1.f + 0.3f * rnd();
+    for (auto& v : sh) v = 0.2f * rnd();
+    for (auto& v : bias) v = 0.1f * rnd();
+    uint16_t *dx = dev(x), *dw = dev(w), *dres = dev(res);
+    float *dsc = dev(sc), *dsh = dev(sh), *db = dev(bias);
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0), hipEventCreate(&e1);
+    std::vector<uint16_t> out[2];
+    float ms[2] = {0, 0};
+    int bad = 0;
+    for (int v = 0; v < 2; ++v) {
+        hv_set_tuning(HV_TUNE_CONV_BIG, v ? tune_b : tune_a);
+        uint16_t* dy = devz<uint16_t>(res.size());
+        hv_conv3x3_params p;
+        memset(&p, 0, sizeof p);
+        p.X = dx, p.C1 = Cin, p.W = dw, p.Y = dy, p.n_images = n, p.Hs = H, p.Ws = W, p.Ho = H, p.Wo = W, p.Cout = Cout;
+        p.mode = HV_CONV_S1, p.pro_scale = dsc, p.pro_shift = dsh, p.pro_act = HV_ACT_SILU, p.bias = db;
+        p.images_per_rowvec = 1, p.rowvec_ld = Cout, p.residual = dres, p.residual_images = n;
+        int rc = 0;
+        for (int rep = 0; rep < 7 && rc == 0; ++rep) {
+            if (rep == 2) hipEventRecord(e0);
+            rc = hv_conv3x3(&p, nullptr);
+        }
+        hipEventRecord(e1);
+        hipEventSynchronize(e1);
+        hipEventElapsedTime(&ms[v], e0, e1);
+        ms[v] /= 5;
+        if (rc != 0) {
+            printf("conv tune %d: rc=%d (%s) FAIL\n", v ? tune_b : tune_a, rc, hv_last_error());
+            bad = 1;
+        }
+        out[v].resize(res.size());
+        hipMemcpy(out[v].data(), dy, res.size() * 2, hipMemcpyDeviceToHost);
+        hipFree(dy);
+    }
+    hv_set_tuning(HV_TUNE_CONV_BIG, 1);
+    double d2 = 0, r2 = 0;
+    for (size_t i = 0; i < out[0].size(); ++i) {
+        const double a = b2f(out[0][i]), b = b2f(out[1][i]);
+        d2 += (a - b) * (a - b), r2 += a * a;
+    }
+    const double rel = sqrt(d2 / (r2 + 1e-30));
+    const bool ok = !bad && rel < 3e-3 && r2 > 0;
+    const double tf = 2.0 * 9 * Cin * Cout * (double)n * H * W / 1e9;
+    printf("conv n=%d %dx%d Cin=%d Cout=%d: tune %d %.4f ms %5.0f TF/s | tune %d %.4f ms %5.0f TF/s | rel rms diff %.2e %s\n", n, H, W, Cin,
+           Cout, tune_a, ms[0], tf / ms[0], tune_b, ms[1], tf / ms[1], rel, (ok || time_only) ? "OK" : "FAIL");
+    fflush(stdout);
+    hipFree(dx), hipFree(dw), hipFree(dres);
+    return (ok || time_only) ? 0 : 1;
+}
+
 int main(int argc, char** argv) {
     bool experimental = false, bench = false;
     for (int i = 1; i < argc; ++i) {
@@ -221,7 +281,17 @@ int main(int argc, char** argv) {
         bad += check_gemm(18432, 3840, 1280, 1, 9, 13);
         bad += check_gemm(4608, 2560, 64, 0, 9, 13);
     }
+    if (experimental) {  // 64-channel reduction chunks (HV_TUNE_CONV_BIG = 3) against the default convolution kernel
+        bad += conv_ab(4, 96, 64, 320, 320, 1, 3, false);
+        bad += conv_ab(3, 21, 13, 128, 200, 1, 3, false);  // ragged patches and output channels
+        bad += conv_ab(6, 12, 8, 1280, 1280, 1, 3, false);  // narrow images: 8 x 16 patches
+    }
     if (bench) {
+        conv_ab(48, 96, 64, 320, 320, 1, 3, true);
+        conv_ab(48, 48, 32, 640, 640, 1, 3, true);
+        conv_ab(48, 24, 16, 1280, 1280, 1, 3, true);
+        conv_ab(48, 12, 8, 1280, 1280, 1, 3, true);
+        conv_ab(48, 96, 64, 640, 320, 1, 3, true);
         const int M0 = 48 * 6144, M1 = 48 * 1536, M2 = 48 * 384, M3 = 48 * 96;
         bench_gemm(M0, 960, 320, 1, "level-0 spatial QKV (LN, V^T)");
         bench_gemm(M0, 960, 320, 3, "level-0 temporal QKV (LN)");

@@ -808,15 +808,16 @@ __global__ __launch_bounds__(NW * 64, 2) void hv_gemm_glds_kernel(HvGemmParams p
         if (a < nsteps) issue();
     int c_tile = first, c_k = 0, c_slot = 0;  // consumer state
     int landed = 0;  // k-steps that need no vmcnt wait (see below)
-    static_assert(PH == 0 || (BK == 64 && NS == 2 && BM == 256 && BN == 256 && NW == 8 && HV_GEMM_DEFER),
-                  "the two-group k-loop is written for the 256 x 256 x 64 tile on 8 waves");
+    static_assert(PH == 0 || (BK == 64 && NS == 2 && HV_GEMM_DEFER && XQ == 4 && WQ == 4 && WAVES_M == 2 && NMF % 2 == 0),
+                  "the two-group k-loop is written for the 256 x 256 x 64 tile on 8 waves and the 128 x 128 x 64 tile on 4");
+    constexpr int HMF = NMF / 2;  // fragment rows per half: X DMA instruction q covers rows [BM / 4 * q, +BM / 4) = half q % 2 of wm = q / 2
     for (int s = 0; s < nsteps; ++s) {
       if constexpr (PH >= 1) {
         // Two readiness groups per k-tile, counted vmcnt, no drain (cdna_hip_programming.md T3+T4; the one-burst form below
         // issues its 8 DMA instructions per wave in one go right after the barrier -- gemm_trace: 4000-5000 clocks blocked in
         // issue on the streamed projections, with the MFMAs waiting behind them -- and drains vmcnt(0) at the end of every
-        // k-step).  A wave multiplies the X rows [128 wm, +128) with the W rows [64 wn, +64).  DMA instruction q of the 8
-        // waves covers rows [64 q, +64) of its operand, so
+        // k-step).  A wave multiplies the X rows [WTM wm, +WTM) with the W rows [64 wn, +64) (256-tile: WTM = 128).  DMA
+        // instruction q of the NW waves covers rows [BM / 4 q, +BM / 4) of its operand, so
         //   G0 = W q=0..3, X q=0, X q=2 : everything the FIRST fragment half (mf 0..3: X rows 128 wm + 0..63) needs,
         //   G1 = X q=1, X q=3           : the X rows of the second half (mf 4..7).
         // Each wave issues the k-tile in that order (vmcnt retires in order): G0 of k-tile s+1 during the first half of step
@@ -852,9 +853,9 @@ __global__ __launch_bounds__(NW * 64, 2) void hv_gemm_glds_kernel(HvGemmParams p
             for (int f = 0; f < 4; ++f) wf[kk][f] = hv_as_bf16x8(hv_ld16(ws + hv_swz<BK>(64 * wn + 16 * f + r16, kk * 4 + quad)));
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
-            bf16x8 xf[4];
+            bf16x8 xf[HMF];
 #pragma unroll
-            for (int f = 0; f < 4; ++f) xf[f] = hv_as_bf16x8(hv_ld16(xs + hv_swz<BK>(WTM * wm + 16 * f + r16, kk * 4 + quad)));
+            for (int f = 0; f < HMF; ++f) xf[f] = hv_as_bf16x8(hv_ld16(xs + hv_swz<BK>(WTM * wm + 16 * f + r16, kk * 4 + quad)));
             if (PH == 1 && kk == 1 && more) {
                 issue_w1(HvInt<3>{});
                 issue_x1(HvInt<0>{});
@@ -869,7 +870,7 @@ __global__ __launch_bounds__(NW * 64, 2) void hv_gemm_glds_kernel(HvGemmParams p
                     if (kk == 1 && nf == 2) issue_w1(HvInt<3>{});
                 }
 #pragma unroll
-                for (int mf = 0; mf < 4; ++mf)
+                for (int mf = 0; mf < HMF; ++mf)
                     acc[nf][mf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[kk][nf], xf[mf], acc[nf][mf], 0, 0, 0);
             }
         }
@@ -883,10 +884,10 @@ __global__ __launch_bounds__(NW * 64, 2) void hv_gemm_glds_kernel(HvGemmParams p
         if (PH == 1 && more) issue_x1(HvInt<1>{});
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
-            bf16x8 xf[4];
+            bf16x8 xf[HMF];
 #pragma unroll
-            for (int f = 0; f < 4; ++f)
-                xf[f] = hv_as_bf16x8(hv_ld16(xs + hv_swz<BK>(WTM * wm + 64 + 16 * f + r16, kk * 4 + quad)));
+            for (int f = 0; f < HMF; ++f)
+                xf[f] = hv_as_bf16x8(hv_ld16(xs + hv_swz<BK>(WTM * wm + 16 * HMF + 16 * f + r16, kk * 4 + quad)));
             if (PH == 1 && kk == 1 && more) {
                 issue_x1(HvInt<3>{});
                 issue_advance();
@@ -903,8 +904,8 @@ __global__ __launch_bounds__(NW * 64, 2) void hv_gemm_glds_kernel(HvGemmParams p
                     }
                 }
 #pragma unroll
-                for (int mf = 0; mf < 4; ++mf)
-                    acc[nf][4 + mf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[kk][nf], xf[mf], acc[nf][4 + mf], 0, 0, 0);
+                for (int mf = 0; mf < HMF; ++mf)
+                    acc[nf][HMF + mf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[kk][nf], xf[mf], acc[nf][HMF + mf], 0, 0, 0);
             }
         }
       } else {
@@ -1024,12 +1025,12 @@ static inline int hv_gemm_launch(const HvGemmParams& p, hipStream_t stream) {
         const int t256 = tm * (n256 / 256), rounds256 = (t256 + 255) / 256;
         const bool fills256 = t256 * 10 >= rounds256 * 256 * 9;
         if (ok128 && (g_hv_gemm_glds >= 7) && p.N >= 960 && (n256 - p.N) * 8 <= p.N &&
-            (g_hv_gemm_glds != 8 || p.K >= 640) && ((g_hv_gemm_glds != 10 && g_hv_gemm_glds != 12 && g_hv_gemm_glds != 14) || fills256)) {
+            (g_hv_gemm_glds != 8 || p.K >= 640) && ((g_hv_gemm_glds != 10 && g_hv_gemm_glds != 12 && g_hv_gemm_glds < 14) || fills256)) {
             const int tiles = tm * (n256 / 256);
             int grid = ((tiles + 7) / 8) * 8;
             if (grid > 256) grid = 256;
             if (grid > g_hv_gemm_max_grid) grid = g_hv_gemm_max_grid;
-            if (g_hv_gemm_glds >= 13) {  // 13 / 14 = 9 / 10 with the two-group k-loop at the eight-phase issue cadence
+            if (g_hv_gemm_glds == 13 || g_hv_gemm_glds == 14 || g_hv_gemm_glds == 16) {  // 13 / 14 = 9 / 10 at the eight-phase issue cadence
                 hv_note("hv_gemm_glds_kernel<64,2,256,8,256,2> | %s", shape);
                 hv_launch(hv_gemm_glds_kernel<64, 2, 256, 8, 256, 2>, dim3(grid), dim3(512), stream, p, gm, form128, g_hv_gemm_walk, 0);
                 return 0;
@@ -1060,6 +1061,16 @@ static inline int hv_gemm_launch(const HvGemmParams& p, hipStream_t stream) {
             int grid6 = ((tiles6 + 7) / 8) * 8;
             if (grid6 > 512) grid6 = 512;
             if (grid6 > g_hv_gemm_max_grid) grid6 = g_hv_gemm_max_grid;
+            if (g_hv_gemm_glds >= 15) {  // 15 / 16 = 12 / 14 with the two-group k-loop in the 128 x 128 x 64 kernel as well
+                if (g_hv_gemm_glds == 16) {
+                    hv_note("hv_gemm_glds_kernel<64,2,128,4,128,2> | %s", shape);
+                    hv_launch(hv_gemm_glds_kernel<64, 2, 128, 4, 128, 2>, dim3(grid6), dim3(256), stream, p, gm, form64, g_hv_gemm_walk, 0);
+                } else {
+                    hv_note("hv_gemm_glds_kernel<64,2,128,4,128,1> | %s", shape);
+                    hv_launch(hv_gemm_glds_kernel<64, 2, 128, 4, 128, 1>, dim3(grid6), dim3(256), stream, p, gm, form64, g_hv_gemm_walk, 0);
+                }
+                return 0;
+            }
             hv_note("hv_gemm_glds_kernel<64,2,128,4,128> | %s", shape);
             hv_launch(hv_gemm_glds_kernel<64, 2, 128, 4, 128>, dim3(grid6), dim3(256), stream, p, gm, form64, g_hv_gemm_walk, g_hv_gemm_pfd);
             return 0;

@@ -149,6 +149,12 @@ def test_gemm_two_group_k_loop(cx):
         cx.lib.call("hv_set_tuning", 3, 12)                                                   # 11 + the fill test of 10
         kc.case_gemm_forms(cx, M=256 * 58, C=64, N=1024, P=128, form="plain", seed=85)        # 232 of 256 tiles: 256x256 kernel
         kc.case_gemm_forms(cx, M=700, C=64, N=1024, P=128, form="res", seed=92)               # 12 tiles: 128x128x64 kernel
+        for policy in (15, 16):  # the same k-loop in the 128x128x64 kernel (N < 960, or 256-tiles that would not fill the CUs)
+            cx.lib.call("hv_set_tuning", 3, policy)
+            for form in ("ln", "ln_yt", "ln_geglu", "res", "plain"):
+                kc.case_gemm_forms(cx, M=900, C=192, N=320, P=128, form=form, seed=95)
+            kc.case_gemm_forms(cx, M=520, C=64, N=192, P=64, form="ln", seed=96)        # one k-step per tile, 64-row table period
+            kc.case_gemm(cx, M=520, N=320, K=256, seed=97, two_source=True)
         g = torch.Generator().manual_seed(94)
         x = cx.bf(torch.randn(1100, 320, generator=g))
         w = cx.bf(torch.randn(1280, 320, generator=g) * 320**-0.5)
@@ -158,6 +164,15 @@ def test_gemm_two_group_k_loop(cx):
             cx.lib.call("hv_set_tuning", 3, policy)
             y = torch.zeros(1100, 1280, dtype=torch.bfloat16, device=cx.device)
             ops.gemm(cx.lib, cx.stream, x, w, y, bias=bias)
+            cx.sync()
+            outs.append(y.clone())
+        assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+        w2 = cx.bf(torch.randn(320, 320, generator=g) * 320**-0.5)
+        outs = []
+        for policy in (9, 15, 16):  # N = 320: the 128x128x64 kernel
+            cx.lib.call("hv_set_tuning", 3, policy)
+            y = torch.zeros(1100, 320, dtype=torch.bfloat16, device=cx.device)
+            ops.gemm(cx.lib, cx.stream, x, w2, y, bias=bias[:320].contiguous())
             cx.sync()
             outs.append(y.clone())
         assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])

@@ -3,7 +3,7 @@
 //  2. hv_gemm under tile policy 10 against policy 9 (same inputs) and against sampled host rows, at the level-2 / level-3
 //     shapes that policy 10 moves from the 256x256x64 to the 128x128x64 kernel.
 // Options: --experimental adds the variants that have not yet run on hardware (tile policies 11 / 12 / 13 against 9 / 10, bit
-// for bit; the 64-channel-chunk convolution against the default one); --bench prints ms per launch of the step's GEMM shapes under policies 9, 10, 11, 13 (HIP events, no Python start-up).
+// for bit; the 64-channel-chunk convolution against the default one); --bench prints ms per launch of the step's GEMM shapes under policies 9, 10, 11, 13, 15, 16 (HIP events, no Python start-up).
 // Build: hipcc -O2 -Wno-unused-value tools/hwcheck.cpp -Iinclude -Lhumanvid_amd/lib -lhumanvid_hip -Wl,-rpath,'$ORIGIN/../../humanvid_amd/lib' -o tools/bin/hwcheck
 #include <hip/hip_runtime.h>
 #include <cmath>
@@ -168,7 +168,7 @@ static void bench_gemm(int M, int N, int K, int form, const char* what) {  // fo
     hipEvent_t e0, e1;
     hipEventCreate(&e0), hipEventCreate(&e1);
     printf("%-34s M=%6d N=%5d K=%4d:", what, M, N, K);
-    for (int pol : {9, 10, 11, 13}) {
+    for (int pol : {9, 10, 11, 13, 15, 16}) {
         hv_set_tuning(HV_TUNE_GEMM_GLDS, pol);
         hv_gemm_params p;
         memset(&p, 0, sizeof p);
@@ -280,6 +280,10 @@ int main(int argc, char** argv) {
         bad += check_gemm(36864, 960, 320, 1, 9, 13);  // 13: the same loop at the eight-phase issue cadence
         bad += check_gemm(18432, 3840, 1280, 1, 9, 13);
         bad += check_gemm(4608, 2560, 64, 0, 9, 13);
+        bad += check_gemm(36864, 320, 320, 0, 9, 15);   // 15 / 16: the two-group loop in the 128 x 128 x 64 kernel
+        bad += check_gemm(36864, 320, 1280, 0, 9, 16);
+        bad += check_gemm(18432, 640, 64, 0, 9, 15);    // one k-step per tile
+        bad += check_gemm(18432, 1280, 1280, 0, 10, 16);
     }
     if (experimental) {  // 64-channel reduction chunks (HV_TUNE_CONV_BIG = 3) against the default convolution kernel
         bad += conv_ab(4, 96, 64, 320, 320, 1, 3, false);

@@ -62,6 +62,9 @@
 #ifndef HV_ATTN_THR
 #define HV_ATTN_THR 8.0f
 #endif
+#ifndef HV_ATTN_LOCALMAX
+#define HV_ATTN_LOCALMAX 1  // round 3: lane-local v_max3 maxima on the common path (0 = the round-2 reduction, for A/Bs)
+#endif
 
 // Head-dim remainder of the QK^T reduction (d = 40: 8 channels, d = 80: 16).  Round 1 fed it through a 16-deep
 // mfma_f32_16x16x16_bf16 appended to the chain of 32-deep MFMAs on the same accumulator.  That mix is unsafe on gfx950
@@ -248,9 +251,12 @@ __global__ __launch_bounds__(256, (HvAttnOcc<D, QT>::value)) void hv_attention_k
 
     f32x4 oacc[QT][DT];
     float mrun[QT], lrun[QT];
+    f32x4 cneg[QT];  // HV_ATTN_DEFER: the query's reference maximum, negated, as the QK^T accumulator's initial value (changes
+                     // only in the rescale branch: kept as a register quad instead of being rebuilt in every tile)
 #pragma unroll
     for (int qt = 0; qt < QT; ++qt) {
         mrun[qt] = HV_ATTN_DEFER ? 0.f : -INFINITY;
+        cneg[qt] = f32x4{0.f, 0.f, 0.f, 0.f};
         lrun[qt] = 0.f;
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) oacc[qt][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -280,10 +286,7 @@ __global__ __launch_bounds__(256, (HvAttnOcc<D, QT>::value)) void hv_attention_k
 #pragma unroll
         for (int kvf = 0; kvf < 4; ++kvf) {
 #pragma unroll
-            for (int qt = 0; qt < QT; ++qt) {
-                const float ci = HV_ATTN_DEFER ? -mrun[qt] : 0.f;  // lane = one query: its reference maximum, negated
-                sacc[kvf][qt] = f32x4{ci, ci, ci, ci};
-            }
+            for (int qt = 0; qt < QT; ++qt) sacc[kvf][qt] = cneg[qt];  // lane = one query: -(its reference maximum), or 0
 #pragma unroll
             for (int s = 0; s < NFULL; ++s) {
                 const bf16x8 kf = hv_as_bf16x8(hv_ld16(kb + (16 * kvf) * G::KRS + s * 64 + quad * 16));
@@ -325,6 +328,20 @@ __global__ __launch_bounds__(256, (HvAttnOcc<D, QT>::value)) void hv_attention_k
         bf16x8 pf[QT][2];
 #pragma unroll
         for (int qt = 0; qt < QT; ++qt) {
+#if HV_ATTN_DEFER && HV_ATTN_LOCALMAX
+            // lane-local maximum of the lane's 16 scores: eight v_max3_f32 (hipcc's fmaxf canonicalises every operand
+            // first -- a v_max x, x in front of each real maximum: 28 instructions for these 16 values).  The cross-quad
+            // reduction to the query's tile maximum (two ds_bpermute round trips) moves into the rare branch: "some query
+            // of this wave exceeds the threshold" is the same predicate over lane-local maxima as over reduced ones.
+            float mx = hv_max3(sacc[0][qt][0], sacc[0][qt][1], sacc[0][qt][2]);
+            mx = hv_max3(mx, sacc[0][qt][3], sacc[1][qt][0]);
+            mx = hv_max3(mx, sacc[1][qt][1], sacc[1][qt][2]);
+            mx = hv_max3(mx, sacc[1][qt][3], sacc[2][qt][0]);
+            mx = hv_max3(mx, sacc[2][qt][1], sacc[2][qt][2]);
+            mx = hv_max3(mx, sacc[2][qt][3], sacc[3][qt][0]);
+            mx = hv_max3(mx, sacc[3][qt][1], sacc[3][qt][2]);
+            mx = hv_max3(mx, sacc[3][qt][3], sacc[3][qt][3]);
+#else
             float mx = fmaxf(fmaxf(sacc[0][qt][0], sacc[0][qt][1]), fmaxf(sacc[0][qt][2], sacc[0][qt][3]));
 #pragma unroll
             for (int kvf = 1; kvf < 4; ++kvf)
@@ -332,6 +349,7 @@ __global__ __launch_bounds__(256, (HvAttnOcc<D, QT>::value)) void hv_attention_k
                            sacc[kvf][qt][3]);
             mx = fmaxf(mx, __shfl_xor(mx, 16));
             mx = fmaxf(mx, __shfl_xor(mx, 32));
+#endif
 #if HV_ATTN_DEFER
             static_assert(!G::TAIL, "HV_ATTN_DEFER needs HV_ATTN_PAD32 (pre-scaled queries have no 16-deep tail fragment)");
             float pv[4][4];
@@ -346,6 +364,10 @@ __global__ __launch_bounds__(256, (HvAttnOcc<D, QT>::value)) void hv_attention_k
                     for (int r = 0; r < 4; ++r) pv[kvf][r] = __builtin_amdgcn_exp2f(sacc[kvf][qt][r]);
                 const bool first = ti == 0;  // the first tile fixes the reference maximum (it starts at 0, not at a score)
                 if (first || __any(mx > HV_ATTN_THR)) {
+#if HV_ATTN_LOCALMAX
+                    mx = fmaxf(mx, __shfl_xor(mx, 16));
+                    mx = fmaxf(mx, __shfl_xor(mx, 32));
+#endif
                     const float inc = first ? mx : fmaxf(mx, 0.f);
 #pragma unroll
                     for (int kvf = 0; kvf < 4; ++kvf)
@@ -358,6 +380,7 @@ __global__ __launch_bounds__(256, (HvAttnOcc<D, QT>::value)) void hv_attention_k
                         for (int dt = 0; dt < DT; ++dt) oacc[qt][dt] *= alpha;
                     }
                     mrun[qt] += inc;
+                    cneg[qt] -= f32x4{inc, inc, inc, inc};
                 }
                 if (!G::ONES) {
 #pragma unroll

@@ -58,6 +58,18 @@ HV_DEV uint32_t hv_pack2(float lo, float hi) {
 #endif
 }
 
+// max(a, b, c) as ONE v_max3_f32: fmaxf() makes hipcc quiet every operand first (v_max_f32 x, x) because the kernels run in
+// IEEE mode; the operands here are MFMA results / finite scores, never signalling NaNs
+HV_DEV float hv_max3(float a, float b, float c) {
+#ifndef HV_EMU
+    float r;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+#else
+    return fmaxf(fmaxf(a, b), c);
+#endif
+}
+
 HV_DEV float hv_silu(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504089f * x)); }
 
 HV_DEV float hv_gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }

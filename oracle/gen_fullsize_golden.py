@@ -3,6 +3,7 @@
 
     python oracle/gen_fullsize_golden.py config3          # 24f x 768x512  (BASELINE.json configs[2])
     python oracle/gen_fullsize_golden.py config2          # 16f x 512x512  (configs[1])
+    HV_TIMED_REPEATS=0 python oracle/gen_fullsize_golden.py config5   # one 24f x 1024x576 window of configs[4], golden only
 
 Runs in the build container (needs /root/reference).  It imports the reference's UNet3DConditionModel,
 ReferenceAttentionControl, PoseGuider and CameraPoseEncoder *verbatim* (on top of oracle/refshim),
@@ -130,6 +131,8 @@ def main():
     cam.load_state_dict(O.make_camera_encoder_weights(), strict=True)
     pose_img = torch.rand(1, 3, F, h * 8, w * 8, generator=torch.Generator().manual_seed(1))
     plucker = torch.randn(1, 6, F, h * 8, w * 8, generator=torch.Generator().manual_seed(3))
+    if timed_repeats <= 0:  # golden only (HV_TIMED_REPEATS=0)
+        return 0
     times = []
     for _ in range(timed_repeats):
         t0 = time.time()

@@ -1,4 +1,4 @@
-"""Seeded inputs of the full-size parity cases (BASELINE.json configs #2 and #3)  --  test infrastructure.
+"""Seeded inputs of the full-size parity cases (BASELINE.json configs #2, #3 and a window of #5)  --  test infrastructure.
 
 Shared by oracle/gen_fullsize_golden.py (build container: runs the REFERENCE's own UNet3DConditionModel on these
 inputs and commits the result under tests/golden/) and tests/test_gpu_fullsize_parity.py (GPU box: runs the native
@@ -13,6 +13,8 @@ CASES = {
     # name: frames, latent h, latent w   (config #3: 24f x 768x512; config #2: 16f x 512x512)
     "config3": dict(F=24, h=96, w=64),
     "config2": dict(F=16, h=64, w=64),
+    # one 24-frame context window of config #5 (48f x 1024x576: latent 128x72, three such windows per step)
+    "config5": dict(F=24, h=128, w=72),
 }
 
 

@@ -8,6 +8,8 @@
 #include <cstdio>
 #include <vector>
 thread_local HvCmdList* g_hv_recording = nullptr;
+thread_local HvProfile* g_hv_prof = nullptr;
+thread_local char g_hv_note[192];
 
 int main() {
     const int n_img = 48, heads = 8, D = 40, N = 6144, C = 320;

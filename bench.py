@@ -112,6 +112,9 @@ def profile_step(run_step):
     finally:
         buf = ctypes.create_string_buffer(1 << 20)
         need = L.cdll.hv_profile_end(buf, len(buf))
+        if need > len(buf):  # the text is kept until a buffer of the returned size collects it
+            buf = ctypes.create_string_buffer(need)
+            need = L.cdll.hv_profile_end(buf, len(buf))
     if need < 0:
         raise RuntimeError("hv_profile_end failed")
     kernels = {}

@@ -5,6 +5,7 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <cstring>
 #include <string>
 
 #include "hv_common.h"
@@ -218,40 +219,55 @@ int hv_profile_begin(void) {
     g_hv_prof = new HvProfile();
     return HV_OK;
 }
+// The reduced text of a profile whose first hv_profile_end() call came with too small a buffer: launches stop being
+// recorded at that call (g_hv_prof is cleared), the text stays here until a call with enough room (or out == NULL with
+// capacity < 0 to drop it) collects it -- the "call again with a larger buffer" contract of the header.
+static thread_local std::string* g_hv_prof_text = nullptr;
 int hv_profile_end(char* out, int capacity) {
     // -> lines "launches\ttotal_ms\tkey\n", one per distinct key, in first-seen order; returns the byte count needed
-    if (!g_hv_prof) return hv_fail(HV_EINVAL, "hv_profile_end: no open profile");
-    HvProfile* pr = g_hv_prof;
-    g_hv_prof = nullptr;
-    std::vector<std::string> keys;
-    std::vector<double> ms;
-    std::vector<int> cnt;
-    for (auto& en : pr->entries) {
-        float t = 0.f;
-        (void)hipEventSynchronize(en.e1);
-        (void)hipEventElapsedTime(&t, en.e0, en.e1);
-        (void)hipEventDestroy(en.e0);
-        (void)hipEventDestroy(en.e1);
-        size_t i = 0;
-        for (; i < keys.size(); ++i)
-            if (keys[i] == en.key) break;
-        if (i == keys.size()) {
-            keys.push_back(en.key);
-            ms.push_back(0.0);
-            cnt.push_back(0);
+    if (!g_hv_prof && !g_hv_prof_text) return hv_fail(HV_EINVAL, "hv_profile_end: no open profile");
+    if (g_hv_prof) {
+        HvProfile* pr = g_hv_prof;
+        g_hv_prof = nullptr;
+        std::vector<std::string> keys;
+        std::vector<double> ms;
+        std::vector<int> cnt;
+        for (auto& en : pr->entries) {
+            float t = 0.f;
+            (void)hipEventSynchronize(en.e1);
+            (void)hipEventElapsedTime(&t, en.e0, en.e1);
+            (void)hipEventDestroy(en.e0);
+            (void)hipEventDestroy(en.e1);
+            size_t i = 0;
+            for (; i < keys.size(); ++i)
+                if (keys[i] == en.key) break;
+            if (i == keys.size()) {
+                keys.push_back(en.key);
+                ms.push_back(0.0);
+                cnt.push_back(0);
+            }
+            ms[i] += t;
+            cnt[i] += 1;
         }
-        ms[i] += t;
-        cnt[i] += 1;
+        delete pr;
+        delete g_hv_prof_text;
+        g_hv_prof_text = new std::string();
+        char line[320];
+        for (size_t i = 0; i < keys.size(); ++i) {
+            snprintf(line, sizeof(line), "%d\t%.6f\t%s\n", cnt[i], ms[i], keys[i].c_str());
+            *g_hv_prof_text += line;
+        }
     }
-    delete pr;
-    std::string txt;
-    char line[320];
-    for (size_t i = 0; i < keys.size(); ++i) {
-        snprintf(line, sizeof(line), "%d\t%.6f\t%s\n", cnt[i], ms[i], keys[i].c_str());
-        txt += line;
+    const int need = (int)g_hv_prof_text->size() + 1;
+    if (out && capacity >= need) {
+        memcpy(out, g_hv_prof_text->c_str(), (size_t)need);
+    } else if (!(out == nullptr && capacity < 0)) {
+        if (out && capacity > 0) out[0] = 0;
+        return need;  // too small (or a size query): the text is kept for the next call
     }
-    if (out && capacity > 0) snprintf(out, (size_t)capacity, "%s", txt.c_str());
-    return (int)txt.size() + 1;
+    delete g_hv_prof_text;
+    g_hv_prof_text = nullptr;
+    return need;
 }
 int hv_graph_begin(void* stream) {
     hipError_t e = hipStreamBeginCapture((hipStream_t)stream, hipStreamCaptureModeRelaxed);

@@ -12,16 +12,21 @@
 //    scores of ONE query (column lane&15) for 4 keys per fragment, so the softmax row reduction is
 //    16 in-register values + two cross-quad shuffles, and the running max / rescale factor of a query
 //    live in the same lane as its O^T accumulator column (no broadcast needed).
-//  * the head dim is not a multiple of 32 for d = 40 / 80: the remainder of the QK^T reduction uses
-//    the 16-deep mfma_f32_16x16x16_bf16 so d = 40 costs 48 (not 64) and d = 80 costs exactly 80.
+//  * the head dim is not a multiple of 32 for d = 40 / 80: the remainder of the QK^T reduction is a zero-padded
+//    32-deep step (d = 40 costs 64, d = 80 costs 96): every MFMA of an accumulation chain has the same shape -- a
+//    16-deep MFMA chained to 32-deep ones reads a partially written accumulator on gfx950 with hipcc / ROCm 7.2
+//    (profiles/r02_mfma_chain_hazard.md).
 //  * key rows are staged into LDS in a permuted order (bits 2 and 3-4 rotated) so that the
 //    probabilities of two adjacent score fragments concatenate, in-register, into the B operand of
 //    O^T += V^T.P^T with natural key order -- no cross-lane traffic between the two matmuls.
 //  * V arrives already transposed ([channel][token], written by the QKV GEMM epilogue), so both
 //    K and V^T fragments are single LDS vector reads; LDS rows are padded to an odd number of
 //    16-byte slots (conflict-free ds_read_b128).
-//  * the O^T rescale is skipped for tiles in which no query of the wave raised its running maximum
-//    (wave-uniform test); the ragged-tail masking is a separate template instance.
+//  * deferred-rescale softmax in the exp2 domain: the queries are pre-multiplied by scale * log2(e), the query's
+//    reference maximum enters the QK^T MFMA as the accumulator's initial value (C = -m: the MFMA delivers s - m), and
+//    the reference is only raised -- O^T and the denominator row scaled once -- in tiles where some probability of the
+//    wave exceeds 2^THR (wave-uniform branch; forced in tests/kernel_cases.py); the ragged-tail masking is a separate
+//    template instance.
 //  * K/V tiles (64 keys) are double-buffered through registers, one barrier per tile; online
 //    softmax in the exp2 domain; fp32 accumulation; register budget sized for >= 2 workgroups per CU.
 #pragma once
@@ -38,53 +43,20 @@
 #endif
 #ifndef HV_ATTN_ONES
 // Denominator through the MFMA: d = 40 pads V^T to 48 rows; the first spare row is a row of ones, so the P.V MFMA that is
-// issued anyway also accumulates sum(P) and the 16 VALU adds per query fragment and tile disappear (level 0: 6.21 -> 5.89 ms
-// same-box).  Round 1 found this variant "wrong on hardware" and parked it; that was the mixed-shape MFMA chain of the
-// QK^T remainder (see HV_ATTN_PAD32 below; with fewer VALU instructions between the dependent pair it tripped more
-// often).  With same-shape chains it passes every hardware case, bench shapes included.
+// issued anyway also accumulates sum(P) and the 16 VALU adds per query fragment and tile disappear.
 #define HV_ATTN_ONES 1
 #endif
-#ifndef HV_ATTN_LAZY
-#define HV_ATTN_LAZY 1
-#endif
-#ifndef HV_ATTN_DEFER
-// Softmax with fewer VALU instructions per score (round 2).  At d = 40 the softmax is the longest phase of a tile: per
-// score one max, one fused multiply-subtract, one v_exp_f32 (half rate) and half a packed convert -- ~750 VALU cycles per
-// 64-key tile against 448 MFMA cycles.  Here (a) the queries are pre-multiplied by scale * log2(e) once at load, (b) the
-// running reference maximum enters the QK^T MFMA as the accumulator's initial value (C = -m), so the MFMA delivers
-// s - m directly, and (c) the reference maximum is only raised when a query's tile maximum exceeds it by more than
-// HV_ATTN_THR (in log2 units; the probabilities are then bounded by 2^THR instead of 1, harmless in bf16 x fp32) -- the
-// common tile needs max + exp2 + convert per score and no multiply-subtract.  The rescale branch (wave-uniform) subtracts
-// the increase from the scores BEFORE they are exponentiated and scales O (and the denominator row) by 2^-increase, i.e.
-// everything still at the old reference is scaled exactly once.  0 = the round-1 softmax, for A/Bs.
-#define HV_ATTN_DEFER 1
-#endif
 #ifndef HV_ATTN_THR
-#define HV_ATTN_THR 8.0f
+#define HV_ATTN_THR 8.0f  // log2 units: probabilities stay below 2^THR before the reference maximum is raised
 #endif
-#ifndef HV_ATTN_LOCALMAX
-#define HV_ATTN_LOCALMAX 1  // round 3: lane-local v_max3 maxima on the common path (0 = the round-2 reduction, for A/Bs)
-#endif
-
-// Head-dim remainder of the QK^T reduction (d = 40: 8 channels, d = 80: 16).  Round 1 fed it through a 16-deep
-// mfma_f32_16x16x16_bf16 appended to the chain of 32-deep MFMAs on the same accumulator.  That mix is unsafe on gfx950
-// with hipcc (ROCm 7.2): a v_mfma_f32_16x16x16_bf16 that takes the result of a v_mfma_f32_16x16x32_bf16 as SrcC (or the
-// reverse) is issued back to back, without the wait states / independent instructions the different pass counts need,
-// and reads a partially written accumulator -- wrong rows that change run to run, depending on what else shares the
-// SIMD (root-caused on the temporal kernel: tools/diag_fence.py, profiles/r02_mfma_chain_hazard.md).  This kernel never
-// showed it (its two query fragments interleave independent MFMAs between the dependent pair), but nothing guaranteed
-// that.  HV_ATTN_PAD32 = 1 (default) keeps every MFMA of a chain the same shape: the remainder becomes a zero-padded
-// 32-deep step (K rows in LDS are zero beyond D, the query fragment is masked).  0 = the round-1 form, for A/Bs only.
-#ifndef HV_ATTN_PAD32
-#define HV_ATTN_PAD32 1
-#endif
+#define HV_ATTN_PTHR 256.0f  // = 2^HV_ATTN_THR, the same threshold on the probabilities
+static_assert(HV_ATTN_THR == 8.0f, "HV_ATTN_PTHR must be 2^HV_ATTN_THR");
 
 template <int D, int QT>
 struct HvAttnGeom {
-    static constexpr int NFULL = HV_ATTN_PAD32 ? (D + 31) / 32 : D / 32;   // 32-deep QK^T steps
-    static constexpr bool TAIL = !HV_ATTN_PAD32 && (D % 32) != 0;          // + one 16-deep step (round-1 form)
+    static constexpr int NFULL = (D + 31) / 32;       // 32-deep QK^T steps (the last one zero-padded)
     static constexpr int DT = (D + 15) / 16;          // 16-row fragments of V^T / O^T
-    static constexpr int DK = 32 * NFULL + (TAIL ? 16 : 0);
+    static constexpr int DK = 32 * NFULL;
     static constexpr int DV = 16 * DT;
     static constexpr bool ONES = HV_ATTN_ONES && DV > D;              // spare V^T row available for the denominator
     static constexpr int KRS = DK * 2 + 16;           // K row stride in LDS (bytes), odd multiple of 16
@@ -93,8 +65,15 @@ struct HvAttnGeom {
     static constexpr int VBYTES = DV * VRS;
     static constexpr int KCH = 64 * (D / 8);          // 16-byte chunks of a K tile
     static constexpr int VCH = D * 8;                 // 16-byte chunks of a V^T tile
-    static constexpr int KIT = (KCH + 255) / 256;
-    static constexpr int VIT = (VCH + 255) / 256;
+    // a tile = KCH (= VCH) chunks over 256 threads: FIT whole 16-byte chunks per thread, and the REM remaining chunks cut
+    // into 256 equal pieces of PB bytes (d = 40: 64 chunks -> 4 bytes per thread, d = 80: 128 -> 8, d = 160: none) -- every
+    // thread issues the same loads / LDS stores (round 2 gave the remainder to wave 0 as whole chunks: a second, mostly
+    // idle 16-byte register set and address pair per operand in every thread, and exec-masked branches in every tile)
+    static constexpr int FIT = KCH / 256;
+    static constexpr int REM = KCH % 256;
+    static constexpr int PB = REM * 16 / 256;         // bytes of the remainder piece per thread (0, 4 or 8)
+    static constexpr int PPC = PB ? 16 / PB : 1;      // pieces per chunk
+    static_assert(KCH == VCH && (REM == 0 || REM == 64 || REM == 128), "tile split");
     static constexpr int BQ = 4 * 16 * QT;            // queries per workgroup
 };
 
@@ -150,7 +129,6 @@ __global__ __launch_bounds__(256, (HvAttnOcc<D, QT>::value)) void hv_attention_k
 
     // ---- query fragments (B operand of S^T = K.Q^T), resident for the whole kernel
     bf16x8 qf[QT][NFULL > 0 ? NFULL : 1];
-    bf16x4 qtail[QT];
     const int q_wave = qb * G::BQ + wave * 16 * QT;
 #pragma unroll
     for (int qt = 0; qt < QT; ++qt) {
@@ -160,7 +138,7 @@ __global__ __launch_bounds__(256, (HvAttnOcc<D, QT>::value)) void hv_attention_k
         for (int s = 0; s < NFULL; ++s) {
             u32x4 v = {0u, 0u, 0u, 0u};
             if (q < p.Lq && 32 * s + 8 * quad + 8 <= D) v = hv_ld16(qrow + 32 * s + 8 * quad);
-            if (HV_ATTN_DEFER) {  // scores come out of the MFMA in the exp2 domain
+            {  // scores come out of the MFMA in the exp2 domain
                 float f[8];
                 hv_unpack8(v, f);
 #pragma unroll
@@ -169,36 +147,21 @@ __global__ __launch_bounds__(256, (HvAttnOcc<D, QT>::value)) void hv_attention_k
             }
             qf[qt][s] = hv_as_bf16x8(v);
         }
-        if (G::TAIL) {
-            const int d = 32 * NFULL + 4 * quad;
-            u32x2 v = {0u, 0u};
-            if (q < p.Lq && d + 4 <= D) v = hv_ld8(qrow + d);
-            union {
-                u32x2 u;
-                bf16x4 s;
-            } c;
-            c.u = v;
-            qtail[qt] = c.s;
-        }
     }
 
-    u32x4 kreg[G::KIT], vreg[G::VIT];
+    u32x4 kreg[G::FIT > 0 ? G::FIT : 1], vreg[G::FIT > 0 ? G::FIT : 1];
+    u32x2 kpc = {0u, 0u}, vpc = {0u, 0u};  // remainder pieces (PB bytes each)
     // Per-lane parts of the K / V^T tile addresses, computed once (32-bit byte offsets from the wave-uniform tensor base:
-    // hv_attention_launch checks the spans); per tile only a scalar offset changes.  (Round 1 rebuilt every 64-bit address
-    // from scratch in every tile: ~60 of the ~290 instructions of a tile.)
-    unsigned koff[G::KIT], voff[G::VIT], koff2[G::KIT], voff2[G::VIT];
+    // hv_attention_launch checks the spans); per tile only a scalar offset changes.  The offsets for the bank tensors
+    // (other row strides) are derived from (row, byte-in-row) when a bank tile is loaded: one v_mad per load.
+    constexpr int CPRK = D / 8;  // 16-byte chunks per K row
+    int krow[G::FIT + 1], kcol[G::FIT + 1], vrow[G::FIT + 1], vcol[G::FIT + 1];  // [FIT] = the remainder piece
 #pragma unroll
-    for (int i = 0; i < G::KIT; ++i) {
-        const int id = tid + 256 * i;
-        const int r = id / (D / 8), c = id % (D / 8);
-        koff[i] = ((unsigned)r * (unsigned)p.ldk + (unsigned)c * 8u) * 2u;
-        koff2[i] = ((unsigned)r * (unsigned)p.ldk2 + (unsigned)c * 8u) * 2u;
-    }
-#pragma unroll
-    for (int i = 0; i < G::VIT; ++i) {
-        const int id = tid + 256 * i;
-        voff[i] = ((unsigned)(id >> 3) * (unsigned)p.ldvt + (unsigned)(id & 7) * 8u) * 2u;
-        voff2[i] = ((unsigned)(id >> 3) * (unsigned)p.ldvt2 + (unsigned)(id & 7) * 8u) * 2u;
+    for (int i = 0; i <= G::FIT; ++i) {
+        const int id = i < G::FIT ? tid + 256 * i : 256 * G::FIT + tid / G::PPC;
+        const int sub = i < G::FIT ? 0 : (tid % G::PPC) * G::PB;
+        krow[i] = id / CPRK, kcol[i] = (id % CPRK) * 16 + sub;
+        vrow[i] = id >> 3, vcol[i] = (id & 7) * 16 + sub;
     }
     auto load_tile = [&](int ti) {
         const bool bank = ti >= T1;
@@ -208,60 +171,61 @@ __global__ __launch_bounds__(256, (HvAttnOcc<D, QT>::value)) void hv_attention_k
         const char* Kp = reinterpret_cast<const char*>(bank ? p.K2 : p.K);
         const char* Vp = reinterpret_cast<const char*>(bank ? p.Vt2 : p.Vt);
         // wave-uniform parts
-        const unsigned kb = ((rowbase + (unsigned)kv0) * (unsigned)(bank ? p.ldk2 : p.ldk) + (unsigned)(head * D)) * 2u;
-        const unsigned vb = ((unsigned)(head * D) * (unsigned)(bank ? p.ldvt2 : p.ldvt) + rowbase + (unsigned)kv0) * 2u;
+        const unsigned ldk2 = (unsigned)(bank ? p.ldk2 : p.ldk) * 2u, ldv2 = (unsigned)(bank ? p.ldvt2 : p.ldvt) * 2u;  // bytes
+        const unsigned kb = (rowbase + (unsigned)kv0) * ldk2 + (unsigned)(head * D) * 2u;
+        const unsigned vb = (unsigned)(head * D) * ldv2 + (rowbase + (unsigned)kv0) * 2u;
 #pragma unroll
-        for (int i = 0; i < G::KIT; ++i) {
-            const int id = tid + 256 * i;
-            u32x4 v = {0u, 0u, 0u, 0u};
-            if (id < G::KCH) {
-                const int r = id / (D / 8);
-                if (!MASK || kv0 + r < L) v = hv_ld16(Kp + (kb + (bank ? koff2[i] : koff[i])));
-            }
-            kreg[i] = v;
+        for (int i = 0; i < G::FIT; ++i) {
+            u32x4 kv = {0u, 0u, 0u, 0u}, vv = {0u, 0u, 0u, 0u};
+            if (!MASK || kv0 + krow[i] < L) kv = hv_ld16(Kp + (kb + hv_umul24(krow[i], ldk2) + (unsigned)kcol[i]));
+            if (!MASK || kv0 + (vcol[i] >> 1) < L) vv = hv_ld16(Vp + (vb + hv_umul24(vrow[i], ldv2) + (unsigned)vcol[i]));
+            kreg[i] = kv, vreg[i] = vv;
         }
-#pragma unroll
-        for (int i = 0; i < G::VIT; ++i) {
-            const int id = tid + 256 * i;
-            u32x4 v = {0u, 0u, 0u, 0u};
-            if (id < G::VCH) {
-                const int c = id & 7;
-                if (!MASK || kv0 + c * 8 < L) v = hv_ld16(Vp + (vb + (bank ? voff2[i] : voff[i])));
+        if (G::PB) {
+            const char* ka = Kp + (kb + hv_umul24(krow[G::FIT], ldk2) + (unsigned)kcol[G::FIT]);
+            const char* va = Vp + (vb + hv_umul24(vrow[G::FIT], ldv2) + (unsigned)vcol[G::FIT]);
+            kpc = vpc = u32x2{0u, 0u};
+            if (!MASK || kv0 + krow[G::FIT] < L) {
+                if (G::PB == 8) kpc = hv_ld8(ka);
+                else kpc[0] = *reinterpret_cast<const unsigned*>(ka);
             }
-            vreg[i] = v;
+            if (!MASK || kv0 + (vcol[G::FIT] >> 1) < L) {  // (pieces never straddle the 8-key granule of the MASK contract)
+                if (G::PB == 8) vpc = hv_ld8(va);
+                else vpc[0] = *reinterpret_cast<const unsigned*>(va);
+            }
         }
     };
+    // key kv = 32a + 8b + 4c' + e  ->  LDS row 32a + 16c' + 4b + e
+    auto key_row = [](int r) { return (r & ~0x1c) | ((r & 4) << 2) | ((r & 0x18) >> 1); };
     auto store_tile = [&](int buf) {
 #pragma unroll
-        for (int i = 0; i < G::KIT; ++i) {
-            const int id = tid + 256 * i;
-            if (id < G::KCH) {
-                const int r = id / (D / 8), c = id % (D / 8);
-                // key kv = 32a + 8b + 4c' + e  ->  LDS row 32a + 16c' + 4b + e
-                const int lr = (r & ~0x1c) | ((r & 4) << 2) | ((r & 0x18) >> 1);
-                hv_st16(Ks + buf * G::KBYTES + lr * G::KRS + c * 16, kreg[i]);
-            }
+        for (int i = 0; i < G::FIT; ++i) {
+            hv_st16(Ks + buf * G::KBYTES + key_row(krow[i]) * G::KRS + kcol[i], kreg[i]);
+            hv_st16(Vs + buf * G::VBYTES + vrow[i] * G::VRS + vcol[i], vreg[i]);
         }
-#pragma unroll
-        for (int i = 0; i < G::VIT; ++i) {
-            const int id = tid + 256 * i;
-            if (id < G::VCH) hv_st16(Vs + buf * G::VBYTES + (id >> 3) * G::VRS + (id & 7) * 16, vreg[i]);
+        if (G::PB) {
+            unsigned char* kd = Ks + buf * G::KBYTES + key_row(krow[G::FIT]) * G::KRS + kcol[G::FIT];
+            unsigned char* vd = Vs + buf * G::VBYTES + vrow[G::FIT] * G::VRS + vcol[G::FIT];
+            if (G::PB == 8) {
+                hv_st8(kd, kpc);
+                hv_st8(vd, vpc);
+            } else {
+                *reinterpret_cast<unsigned*>(kd) = kpc[0];
+                *reinterpret_cast<unsigned*>(vd) = vpc[0];
+            }
         }
     };
 
     f32x4 oacc[QT][DT];
-    float mrun[QT], lrun[QT];
-    f32x4 cneg[QT];  // HV_ATTN_DEFER: the query's reference maximum, negated, as the QK^T accumulator's initial value (changes
-                     // only in the rescale branch: kept as a register quad instead of being rebuilt in every tile)
+    float lrun[QT];
+    float mneg[QT];  // the query's reference maximum, negated: the QK^T accumulator's initial value; starts at 0
 #pragma unroll
     for (int qt = 0; qt < QT; ++qt) {
-        mrun[qt] = HV_ATTN_DEFER ? 0.f : -INFINITY;
-        cneg[qt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        mneg[qt] = 0.f;
         lrun[qt] = 0.f;
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) oacc[qt][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
-    const float c2 = p.scale * 1.44269504089f;
 
 #ifdef HV_GEMM_TRACE
     int hv_ti = 0;
@@ -282,31 +246,22 @@ __global__ __launch_bounds__(256, (HvAttnOcc<D, QT>::value)) void hv_attention_k
 
         // ---- S^T fragments: sacc[kvf][qt], lane = (query r16, quad), reg r <-> key
         //      kv = 32*(kvf>>1) + 8*quad + 4*(kvf&1) + r
-        f32x4 sacc[4][QT];
+        f32x4 sacc[QT][4];
 #pragma unroll
         for (int kvf = 0; kvf < 4; ++kvf) {
 #pragma unroll
-            for (int qt = 0; qt < QT; ++qt) sacc[kvf][qt] = cneg[qt];  // lane = one query: -(its reference maximum), or 0
+            for (int qt = 0; qt < QT; ++qt) sacc[qt][kvf] = f32x4{mneg[qt], mneg[qt], mneg[qt], mneg[qt]};  // lane = one query
 #pragma unroll
             for (int s = 0; s < NFULL; ++s) {
                 const bf16x8 kf = hv_as_bf16x8(hv_ld16(kb + (16 * kvf) * G::KRS + s * 64 + quad * 16));
 #pragma unroll
                 for (int qt = 0; qt < QT; ++qt)
-                    sacc[kvf][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[qt][s], sacc[kvf][qt], 0, 0, 0);
-            }
-            if (G::TAIL) {
-                union {
-                    u32x2 u;
-                    bf16x4 s;
-                } kt;
-                kt.u = hv_ld8(kb + (16 * kvf) * G::KRS + NFULL * 64 + quad * 8);
-#pragma unroll
-                for (int qt = 0; qt < QT; ++qt)
-                    sacc[kvf][qt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(kt.s, qtail[qt], sacc[kvf][qt], 0, 0, 0);
+                    sacc[qt][kvf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[qt][s], sacc[qt][kvf], 0, 0, 0);
             }
         }
         // ---- mask the ragged tail of this source (MASK instances only)
-        if (MASK) {
+        auto mask_tail = [&](f32x4 (&sc)[4]) __attribute__((always_inline)) {
+            if (!MASK) return;
             const bool bank = ti >= T1;
             const int kv0 = (bank ? ti - T1 : ti) * 64;
             const int L = bank ? p.L2 : p.L1;
@@ -314,103 +269,83 @@ __global__ __launch_bounds__(256, (HvAttnOcc<D, QT>::value)) void hv_attention_k
 #pragma unroll
                 for (int kvf = 0; kvf < 4; ++kvf)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int kv = kv0 + 32 * (kvf >> 1) + 8 * quad + 4 * (kvf & 1) + r;
-                        if (kv >= L) {
-#pragma unroll
-                            for (int qt = 0; qt < QT; ++qt) sacc[kvf][qt][r] = -INFINITY;
-                        }
-                    }
+                    for (int r = 0; r < 4; ++r)
+                        if (kv0 + 32 * (kvf >> 1) + 8 * quad + 4 * (kvf & 1) + r >= L) sc[kvf][r] = -INFINITY;
             }
-        }
+        };
         HV_TRACE(5);
         // ---- online softmax (exp2 domain) and P^T fragments
         bf16x8 pf[QT][2];
 #pragma unroll
         for (int qt = 0; qt < QT; ++qt) {
-#if HV_ATTN_DEFER && HV_ATTN_LOCALMAX
-            // lane-local maximum of the lane's 16 scores: eight v_max3_f32 (hipcc's fmaxf canonicalises every operand
-            // first -- a v_max x, x in front of each real maximum: 28 instructions for these 16 values).  The cross-quad
-            // reduction to the query's tile maximum (two ds_bpermute round trips) moves into the rare branch: "some query
-            // of this wave exceeds the threshold" is the same predicate over lane-local maxima as over reduced ones.
-            float mx = hv_max3(sacc[0][qt][0], sacc[0][qt][1], sacc[0][qt][2]);
-            mx = hv_max3(mx, sacc[0][qt][3], sacc[1][qt][0]);
-            mx = hv_max3(mx, sacc[1][qt][1], sacc[1][qt][2]);
-            mx = hv_max3(mx, sacc[1][qt][3], sacc[2][qt][0]);
-            mx = hv_max3(mx, sacc[2][qt][1], sacc[2][qt][2]);
-            mx = hv_max3(mx, sacc[2][qt][3], sacc[3][qt][0]);
-            mx = hv_max3(mx, sacc[3][qt][1], sacc[3][qt][2]);
-            mx = hv_max3(mx, sacc[3][qt][3], sacc[3][qt][3]);
-#else
-            float mx = fmaxf(fmaxf(sacc[0][qt][0], sacc[0][qt][1]), fmaxf(sacc[0][qt][2], sacc[0][qt][3]));
+            // Exponentials against the current reference maximum first (the QK^T MFMA delivered s - m).  The tile only needs
+            // the rescale branch when some probability exceeds 2^THR -- exp2 is monotonic, so the test runs on the
+            // probabilities: their lane-local maximum is eight v_max3_f32 (exp2 results are canonical; fmaxf on the raw
+            // MFMA outputs costs a canonicalising v_max x, x per operand in IEEE mode: 28 instructions for 16 values, and
+            // an inline-asm v_max3 on MFMA outputs is not covered by hipcc's MFMA -> VALU hazard padding), and "some
+            // query of this wave exceeds the threshold" is the same predicate over lane-local maxima as over the
+            // cross-quad reduced ones -- the two ds_bpermute round trips of the reduction move into the rare branch.
+            mask_tail(sacc[qt]);
+            float pv[4][4];  // takes the place of the scores (they are recomputed in the rare branch: registers)
 #pragma unroll
-            for (int kvf = 1; kvf < 4; ++kvf)
-                mx = fmaxf(fmaxf(fmaxf(mx, sacc[kvf][qt][0]), fmaxf(sacc[kvf][qt][1], sacc[kvf][qt][2])),
-                           sacc[kvf][qt][3]);
-            mx = fmaxf(mx, __shfl_xor(mx, 16));
-            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            for (int kvf = 0; kvf < 4; ++kvf)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) pv[kvf][r] = __builtin_amdgcn_exp2f(sacc[qt][kvf][r]);
+            float pm = fmaxf(fmaxf(pv[0][0], pv[0][1]), pv[0][2]);
+            pm = fmaxf(fmaxf(pm, pv[0][3]), pv[1][0]);
+            pm = fmaxf(fmaxf(pm, pv[1][1]), pv[1][2]);
+            pm = fmaxf(fmaxf(pm, pv[1][3]), pv[2][0]);
+            pm = fmaxf(fmaxf(pm, pv[2][1]), pv[2][2]);
+            pm = fmaxf(fmaxf(pm, pv[2][3]), pv[3][0]);
+            pm = fmaxf(fmaxf(pm, pv[3][1]), pv[3][2]);
+            pm = fmaxf(pm, pv[3][3]);
+            const bool first = ti == 0;  // the first tile fixes the reference maximum (it starts at 0, not at a score)
+            if (first || __any(pm > HV_ATTN_PTHR)) {
+                // rare: raise the reference maximum by the query's tile maximum (reduced over the four quads), redo the
+                // exponentials against it and scale everything that is still at the old reference exactly once.  The
+                // scores are recomputed from the K tile in LDS (keeping them live beside the probabilities on the common
+                // path costs 16 registers per query fragment -- spills at four waves per SIMD).
+#ifndef HV_EMU
+                asm volatile("" ::: "memory");  // keeps the LDS reads (and with them the MFMAs) below from being hoisted out of the branch
 #endif
-#if HV_ATTN_DEFER
-            static_assert(!G::TAIL, "HV_ATTN_DEFER needs HV_ATTN_PAD32 (pre-scaled queries have no 16-deep tail fragment)");
-            float pv[4][4];
-            {
-                // exponentials first, against the current reference: they do not depend on this tile's maximum unless the
-                // (rare) rescale branch fires, so the max reduction and its two cross-lane steps run beside them
-                // instead of in front of them
+                f32x4 s2[4];
+#pragma unroll
+                for (int kvf = 0; kvf < 4; ++kvf) {
+                    s2[kvf] = f32x4{mneg[qt], mneg[qt], mneg[qt], mneg[qt]};
+#pragma unroll
+                    for (int s = 0; s < NFULL; ++s) {
+                        const bf16x8 kf = hv_as_bf16x8(hv_ld16(kb + (16 * kvf) * G::KRS + s * 64 + quad * 16));
+                        s2[kvf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[qt][s], s2[kvf], 0, 0, 0);
+                    }
+                }
+                mask_tail(s2);
+                float mx = fmaxf(fmaxf(s2[0][0], s2[0][1]), fmaxf(s2[0][2], s2[0][3]));
+#pragma unroll
+                for (int kvf = 1; kvf < 4; ++kvf)
+                    mx = fmaxf(fmaxf(fmaxf(mx, s2[kvf][0]), fmaxf(s2[kvf][1], s2[kvf][2])), s2[kvf][3]);
+                mx = fmaxf(mx, __shfl_xor(mx, 16));
+                mx = fmaxf(mx, __shfl_xor(mx, 32));
+                const float inc = first ? mx : fmaxf(mx, 0.f);
+#pragma unroll
+                for (int kvf = 0; kvf < 4; ++kvf)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) pv[kvf][r] = __builtin_amdgcn_exp2f(s2[kvf][r] - inc);
+                if (!first) {
+                    const float alpha = __builtin_amdgcn_exp2f(-inc);
+                    if (!G::ONES) lrun[qt] *= alpha;
+#pragma unroll
+                    for (int dt = 0; dt < DT; ++dt) oacc[qt][dt] *= alpha;
+                }
+                mneg[qt] -= inc;
+            }
+            if (!G::ONES) {
                 float psum = 0.f;
 #pragma unroll
                 for (int kvf = 0; kvf < 4; ++kvf)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) pv[kvf][r] = __builtin_amdgcn_exp2f(sacc[kvf][qt][r]);
-                const bool first = ti == 0;  // the first tile fixes the reference maximum (it starts at 0, not at a score)
-                if (first || __any(mx > HV_ATTN_THR)) {
-#if HV_ATTN_LOCALMAX
-                    mx = fmaxf(mx, __shfl_xor(mx, 16));
-                    mx = fmaxf(mx, __shfl_xor(mx, 32));
-#endif
-                    const float inc = first ? mx : fmaxf(mx, 0.f);
-#pragma unroll
-                    for (int kvf = 0; kvf < 4; ++kvf)
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) pv[kvf][r] = __builtin_amdgcn_exp2f(sacc[kvf][qt][r] - inc);
-                    if (!first) {
-                        const float alpha = __builtin_amdgcn_exp2f(-inc);
-                        if (!G::ONES) lrun[qt] *= alpha;
-#pragma unroll
-                        for (int dt = 0; dt < DT; ++dt) oacc[qt][dt] *= alpha;
-                    }
-                    mrun[qt] += inc;
-                    cneg[qt] -= f32x4{inc, inc, inc, inc};
-                }
-                if (!G::ONES) {
-#pragma unroll
-                    for (int kvf = 0; kvf < 4; ++kvf)
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) psum += pv[kvf][r];
-                    lrun[qt] += psum;
-                }
+                    for (int r = 0; r < 4; ++r) psum += pv[kvf][r];
+                lrun[qt] += psum;
             }
-#else
-            const float mold = mrun[qt];
-            const float mnew = fmaxf(mold, mx * c2);
-            mrun[qt] = mnew;
-            float pv[4][4];
-            float psum = 0.f;
-#pragma unroll
-            for (int kvf = 0; kvf < 4; ++kvf)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    pv[kvf][r] = __builtin_amdgcn_exp2f(sacc[kvf][qt][r] * c2 - mnew);
-                    if (!G::ONES) psum += pv[kvf][r];
-                }
-            if (!HV_ATTN_LAZY || __any(mnew > mold)) {  // some query of this wave raised its maximum: rescale the accumulators
-                const float alpha = __builtin_amdgcn_exp2f(mold - mnew);
-                if (!G::ONES) lrun[qt] *= alpha;
-#pragma unroll
-                for (int dt = 0; dt < DT; ++dt) oacc[qt][dt] *= alpha;
-            }
-            if (!G::ONES) lrun[qt] += psum;
-#endif
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
                 u32x4 w = {hv_pack2(pv[2 * ks][0], pv[2 * ks][1]), hv_pack2(pv[2 * ks][2], pv[2 * ks][3]),
@@ -482,6 +417,11 @@ static inline int hv_attention_launch(const hv_attention_params& p, hipStream_t 
     if (p.L1 <= 0 || p.L1 % 8 != 0 || p.L2 % 8 != 0 || p.Lq <= 0) return -1;
     if (p.ldq % 8 || p.ldk % 8 || p.ldvt % 8 || p.ldo % 4) return -1;
     if (p.L2 > 0 && p.bank_sel != nullptr && (!p.K2 || !p.Vt2 || p.ldk2 % 8 || p.ldvt2 % 8)) return -1;
+    {  // row strides in bytes are 24-bit multiplier operands inside the kernel (hv_umul24)
+        const long lim24 = 1L << 24;
+        if (p.ldk * 2 >= lim24 || p.ldvt * 2 >= lim24) return -1;
+        if (p.L2 > 0 && p.bank_sel != nullptr && (p.ldk2 * 2 >= lim24 || p.ldvt2 * 2 >= lim24)) return -1;
+    }
     {  // 32-bit byte offsets inside the kernel
         const long lim = 1L << 32, C = (long)p.heads * p.D;
         if ((long)p.n_images * p.L1 * p.ldk * 2 >= lim || (C * p.ldvt + (long)p.n_images * p.L1) * 2 >= lim) return -1;

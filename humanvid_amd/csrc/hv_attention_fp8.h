@@ -417,6 +417,14 @@ __global__ __launch_bounds__(256, (D == 40 ? 4 : (D == 80 ? 2 : 1))) void hv_att
     }
 }
 
+// zeroes the per-head V amax ahead of the atomicMax pass.  A kernel (not hipMemsetAsync) so that it goes through hv_launch:
+// the command-list recorder of the multi-GPU step only sees hv_launch, and a memset it does not replay left the running
+// maximum of every earlier layer and step in the shared buffer.
+__global__ void hv_attention_fp8_zero_kernel(float* v, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) v[i] = 0.f;
+}
+
 template <int D>
 static inline void hv_attention_fp8_quantize_launch_t(const bf16_t* K, long ldk, const bf16_t* Vt, long ldvt, int n, int heads, int L,
                                                       float* kscale, float* vamax, const float* vfloor, unsigned char* K8,
@@ -439,7 +447,10 @@ static inline int hv_attention_fp8_quantize_launch(const bf16_t* K, long ldk, co
                                                    long ldk8, unsigned char* Vt8, long ldvt8, int phase, hipStream_t stream) {
     if (L <= 0 || L % 8 != 0 || ldk % 8 || ldvt % 8 || n <= 0 || heads <= 0 || phase < 1 || phase > 3) return -1;
     if ((phase & 2) && (!K8 || !Vt8 || ldk8 % 8 || ldvt8 % 8)) return -1;
-    if (phase & 1) (void)hipMemsetAsync(vamax, 0, sizeof(float) * (size_t)heads, stream);
+    if (phase & 1) {
+        hv_note("hv_attention_fp8_zero_kernel | heads=%d", heads);
+        hv_launch(hv_attention_fp8_zero_kernel, dim3((heads + 63) / 64), dim3(64), stream, vamax, heads);
+    }
     switch (D) {
         case 40: hv_attention_fp8_quantize_launch_t<40>(K, ldk, Vt, ldvt, n, heads, L, kscale, vamax, vfloor, K8, ldk8, Vt8, ldvt8, phase, stream); break;
         case 80: hv_attention_fp8_quantize_launch_t<80>(K, ldk, Vt, ldvt, n, heads, L, kscale, vamax, vfloor, K8, ldk8, Vt8, ldvt8, phase, stream); break;

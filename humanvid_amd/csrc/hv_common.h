@@ -58,15 +58,12 @@ HV_DEV uint32_t hv_pack2(float lo, float hi) {
 #endif
 }
 
-// max(a, b, c) as ONE v_max3_f32: fmaxf() makes hipcc quiet every operand first (v_max_f32 x, x) because the kernels run in
-// IEEE mode; the operands here are MFMA results / finite scores, never signalling NaNs
-HV_DEV float hv_max3(float a, float b, float c) {
+// a * b for a, b < 2^24 (row index x row stride in bytes): full-rate v_mul_u32_u24 instead of the quarter-rate v_mul_lo_u32
+HV_DEV unsigned hv_umul24(unsigned a, unsigned b) {
 #ifndef HV_EMU
-    float r;
-    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
-    return r;
+    return __umul24(a, b);
 #else
-    return fmaxf(fmaxf(a, b), c);
+    return a * b;
 #endif
 }
 

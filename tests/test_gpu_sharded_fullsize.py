@@ -1,0 +1,123 @@
+"""The frame-sharded engine at the per-rank shapes of BASELINE.json configs[3] (24f x 768x512 over 8 MI355X), on ONE GPU.
+
+R ranks (8 x 3 frames = config #4's exact per-rank geometry: 6 images per rank, row-permuted QKV GEMM at M = 36 864, the
+exchanged temporal kernel at P = 768; and 2 x 12 frames) share the box's single MI355X through host-staged gloo collectives
+-- RCCL refuses two ranks per device, so only the transport differs from `bench.py --gpus R`.  Every rank builds the SD-1.5
+width UNet, runs ONE read-mode CFG forward of its own frames with the temporal-attention all-to-all exchange, and the parent
+assembles the ranks' outputs, tap slices and per-image rms and compares them with the REFERENCE's own fp32 output
+(tests/golden/unet3d_config3.npz, made by oracle/gen_fullsize_golden.py from /root/reference/src/models/unet_3d.py:397-577)
+at the same stated tolerances as the unsharded test: output / taps NRMSE <= 2e-2, per-image rms within 2 % on all 48 images.
+"""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+sys.path.insert(0, os.path.join(REPO, "oracle"))
+sys.path.insert(0, os.path.dirname(__file__))
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+CASE = "config3"
+TOL_OUT, TOL_TAP, TOL_RMS = 2e-2, 2e-2, 2e-2
+
+
+def _worker(rank, world, port, out_dir, exchange):
+    import torch.distributed as dist
+
+    import fullsize_case as FC
+    import oracle_torch as O  # test infrastructure: weight generator only
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HUMANVID_TEMPORAL_EXCHANGE=exchange)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.set_num_threads(max(1, (os.cpu_count() or 8) // world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    from humanvid_amd.engine import UNet3DEngine
+    from humanvid_amd.runner import FrameShard
+    from humanvid_amd.unet3d import UNet3DConditionModel
+
+    cfg = dict(O.SD15_UNET3D_CFG)
+    sd = O.make_unet3d_weights(cfg, seed=FC.WEIGHT_SEED)
+    net = UNet3DConditionModel(**dict(cfg, use_inflated_groupnorm=True, unet_use_cross_frame_attention=False,
+                                      unet_use_temporal_attention=False, motion_module_type="Vanilla"))
+    net.load_state_dict(sd, strict=True)
+    chan = {p: sd[p + ".norm.weight"].numel() for p in O.transformer_locations(cfg)}
+    del sd
+    net = net.to("cuda")
+    shard = FrameShard()
+    assert shard.staged and shard.world == world
+    net._engine = eng = UNet3DEngine(net, shard=shard)
+    sample, ehs, pose, banks = FC.make_inputs(CASE, list(chan), lambda p: chan[p])
+    F = FC.CASES[CASE]["F"]
+    f0, fl = shard.frame_range(F)
+    eng.set_reference_banks({k: v.cuda() for k, v in banks.items()}, do_cfg=True)
+    eng._banks_from_modules = lambda: None
+    mine = [(k, bi, fi) for k, (bi, fi) in enumerate(FC.tap_images(F)) if f0 <= fi < f0 + fl]
+    slices, rms = {}, {}
+
+    def tap(name, x):  # x [(b fl), h, w, c]: local frames
+        ys, xs = FC.tap_grid(x.shape[1], x.shape[2])
+        slices[name] = {k: x[bi * fl + fi - f0][ys][:, xs].float().cpu() for k, bi, fi in mine}
+        rms[name] = FC.rms_nhwc(x).cpu()
+
+    eng.tap = tap
+    out = net(sample[:, :, f0:f0 + fl].contiguous().cuda(), FC.TIMESTEP, ehs.cuda(),
+              pose_cond_fea=pose[:, :, f0:f0 + fl].contiguous().cuda(), return_dict=False)[0]
+    torch.cuda.synchronize()
+    torch.save(dict(out=out.float().cpu(), slices=slices, rms=rms, f0=f0, fl=fl), os.path.join(out_dir, f"rank{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [8, 2])
+def test_sharded_forward_at_config4_rank_shapes_matches_the_reference(tmp_path, world):
+    import fullsize_case as FC
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_worker, args=(world, port, str(tmp_path), "alltoall"), nprocs=world, join=True)
+    z = np.load(os.path.join(GOLD, f"unet3d_{CASE}.npz"))
+    F = int(z["F"])
+    parts = [torch.load(os.path.join(str(tmp_path), f"rank{r}.pt")) for r in range(world)]
+    out = torch.cat([p["out"] for p in parts], dim=2)  # [2, 4, F, h, w]: ranks hold consecutive frame ranges
+    ref = torch.from_numpy(z["out"].astype(np.float32))
+    assert out.shape == ref.shape and torch.isfinite(out).all()
+    e_out = float((out - ref).norm() / ref.norm())
+    d = (out - ref).pow(2).sum(dim=(1, 3, 4)).sqrt() / ref.pow(2).sum(dim=(1, 3, 4)).sqrt()
+    print(f"[{CASE} / {world} ranks] output nrmse {e_out:.4e}  worst image {float(d.max()):.4e}")
+    names = [k[4:] for k in z.files if k.startswith("tap:")]
+    assert len(names) == 35 and all(set(names) == set(p["rms"]) for p in parts)
+    worst_tap, worst_rms = ("", 0.0), ("", 0.0)
+    for name in names:
+        want = torch.from_numpy(z["tap:" + name].astype(np.float32))  # [2 tap images, ny, nx, c]
+        got = [None, None]
+        for p in parts:
+            for k, v in p["slices"][name].items():
+                got[k] = v
+        assert all(g is not None for g in got)
+        e = float((torch.stack(got) - want).norm() / want.norm())
+        # per-image rms in the reference's (b f) order: rank r holds frames [f0, f0 + fl) of both CFG halves
+        rr = torch.from_numpy(z["rms:" + name])
+        mine = torch.empty_like(rr)
+        for p in parts:
+            fl, f0 = p["fl"], p["f0"]
+            for b in range(2):
+                mine[b * F + f0:b * F + f0 + fl] = p["rms"][name][b * fl:(b + 1) * fl]
+        er = float(((mine - rr).abs() / rr).max())
+        if e > worst_tap[1]:
+            worst_tap = (name, e)
+        if er > worst_rms[1]:
+            worst_rms = (name, er)
+    print(f"[{CASE} / {world} ranks] worst tap {worst_tap}  worst per-image rms deviation {worst_rms}")
+    assert worst_tap[1] < TOL_TAP, worst_tap
+    assert worst_rms[1] < TOL_RMS, worst_rms
+    assert e_out < TOL_OUT and float(d.max()) < 1.5 * TOL_OUT, (e_out, float(d.max()))

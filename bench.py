@@ -270,14 +270,6 @@ def main():
         from humanvid_amd import lib as hvlib
 
         hvlib.load().call("hv_set_tuning", 5, int(os.environ["HUMANVID_CONV_BIG"]))
-    if os.environ.get("HUMANVID_GEMM_PF"):
-        from humanvid_amd import lib as hvlib
-
-        hvlib.load().call("hv_set_tuning", 9, int(os.environ["HUMANVID_GEMM_PF"]))
-    if os.environ.get("HUMANVID_GEMM_WALK"):
-        from humanvid_amd import lib as hvlib
-
-        hvlib.load().call("hv_set_tuning", 8, int(os.environ["HUMANVID_GEMM_WALK"]))
     cfgsel = CONFIGS[args.config]
     F, H, W = args.frames or cfgsel["F"], args.height or cfgsel["H"], args.width or cfgsel["W"]
     h, w = H // 8, W // 8

@@ -381,15 +381,16 @@ static inline int hv_conv3x3_launch(const hv_conv3x3_params& p, hipStream_t stre
     // (measured on MI355X: the 8-wave tile wins for the upsample-folded conv, 0.90 -> 1.03 PF/s, and
     //  loses for stride 1, where the per-step barrier over 8 waves costs more than the traffic saved)
     const bool big = g_hv_conv_big && !narrow && p.Ho >= 16 && p.mode == HV_CONV_UP2;
-    // 256-pixel tiles on 4 waves of 128 pixels (tuning value 2): stride-1 convolutions whose images fill 16 x 16 patches
-    const bool wide = g_hv_conv_big == 2 && !narrow && p.Ho >= 16 && p.Wo >= 16 && p.mode == HV_CONV_S1;
-    // 64-channel chunks (tuning value 3; opt-in until measured): stride 1, both sources in whole 64-channel chunks
-    const bool ck64 = g_hv_conv_big == 3 && p.mode == HV_CONV_S1 && p.C1 % 64 == 0 && p.C2 % 64 == 0;
+    // 64-channel reduction chunks (whole 128-byte weight lines by LDS-DMA, 32 MFMAs per tap step): stride 1, both sources in
+    // whole 64-channel chunks.  Hardware A/B (profiles/r03_hwcheck.txt, 48 images): 24x16 1280 -> 1280 0.746 -> 0.719 ms,
+    // 12x8 0.258 -> 0.221 ms, but 96x64 320 -> 320 0.863 -> 0.928 and 48x32 640 -> 640 0.742 -> 0.770: the default takes
+    // them for images of at most 384 output pixels (tuning value 3 forces them everywhere, 0 / 2 never).
+    const bool ck64 = p.mode == HV_CONV_S1 && p.C1 % 64 == 0 && p.C2 % 64 == 0 &&
+                      (g_hv_conv_big == 3 || (g_hv_conv_big == 1 && p.Ho * p.Wo <= 384));
     switch (p.mode) {
         case HV_CONV_S1:
             if (ck64 && narrow) hv_conv3x3_launch_t<8, HV_CONV_S1, 128, 64, 64>(p, stream);
             else if (ck64) hv_conv3x3_launch_t<16, HV_CONV_S1, 128, 64, 64>(p, stream);
-            else if (wide) hv_conv3x3_launch_t<16, HV_CONV_S1, 256, 128>(p, stream);
             else if (big) hv_conv3x3_launch_t<16, HV_CONV_S1, 256>(p, stream);
             else if (narrow) hv_conv3x3_launch_t<8, HV_CONV_S1, 128>(p, stream);
             else hv_conv3x3_launch_t<16, HV_CONV_S1, 128>(p, stream);

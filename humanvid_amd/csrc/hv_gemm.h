@@ -589,29 +589,32 @@ __global__ __launch_bounds__(256, 2) void hv_gemm_kernel(HvGemmParams p) {
     }
 }
 
-// ---- LDS-DMA variant (no operand prologue): 256 x BN x BK tiles on an NS-slot LDS ring filled with
-// global_load_lds (no VGPR staging, no ds_write: the register-staged kernel above is bound by the LDS
-// write path), NS-1 k-tiles in flight across the barrier with counted vmcnt waits, one raw s_barrier per
-// k-step, persistent tile walk as above.  NW waves per workgroup:
-//   NW = 4, BN = 128 (default): 2 x 2 waves of 128x64 (32 MFMA per 12 ds_read_b128), 72 KiB ring, TWO
-//       workgroups per CU -> every SIMD hosts one wave of each, so one workgroup's loads / barrier /
-//       epilogue run under the other one's MFMAs (measured: in a single resident workgroup the MFMA,
-//       ds_read, LDS-DMA-issue and epilogue times simply add up);
-//   NW = 8: 4 x 2 waves of 64x64 (BN = 128) or 2 x 4 of 128x64 (BN = 256), one workgroup per CU.
-//   PH = 1 (256 x 256 x 64, opt-in tile policies 11 / 12): the k-tile's LDS-DMA instructions as two readiness groups with
-//       counted vmcnt instead of one burst and a drain per k-step (cdna_hip_programming.md T3+T4) -- see the k-loop.
-template <int BK, int NS, int BN, int NW, int BM = 256, int PH = 0>
-__global__ __launch_bounds__(NW * 64, 2) void hv_gemm_glds_kernel(HvGemmParams p, int gm, int form, int walk, int pfd) {
+// ---- LDS-DMA kernel (no operand prologue): BM x BN x 64 tiles on a 2-slot LDS ring filled with global_load_lds (no VGPR
+// staging, no ds_write: the register-staged kernel above is bound by the LDS write path), persistent tile walk as above,
+// one raw s_barrier per half k-step, counted vmcnt waits -- never vmcnt(0) inside the loop.  Two instantiations:
+//   256 x 256 x 64, 8 waves (2 x 4 of 128 x 64), 128 KiB ring, one workgroup per CU: a third fewer operand bytes per FLOP
+//       through the per-CU L2 -> LDS fill path, which is what bounds this kernel (profiles/r02_gemm_trace.txt);
+//   128 x 128 x 64, 4 waves (2 x 2 of 64 x 64), 64 KiB ring, two workgroups per CU: finer quantisation over the 256 CUs
+//       for narrow / short problems, one workgroup's epilogue under the other's k-loop.
+// The k-tile's LDS-DMA instructions go out as two readiness groups (cdna_hip_programming.md T3+T4) -- see the k-loop.
+//   PH = 1: each group as a burst at the head of its half step (measured best for the 256 x 256 tile, round 3),
+//   PH = 2: one DMA instruction in front of every 8 MFMAs (measured best for the 128 x 128 tile).
+// Both are bit-identical to the round-2 one-burst loop (same MFMA order per accumulator; hardware-checked in
+// profiles/r03_hwcheck.txt), which is deleted together with the BK = 32 / 3-slot / contiguous-walk / L2-prefetch variants
+// that never won a same-box A/B.
+template <int BN, int NW, int BM, int PH>
+__global__ __launch_bounds__(NW * 64, 2) void hv_gemm_glds_kernel(HvGemmParams p, int gm, int form) {
+    constexpr int BK = 64, NS = 2;
     constexpr int WAVES_N = BN / 64, WAVES_M = NW / WAVES_N;
     constexpr int WTM = BM / WAVES_M, NMF = WTM / 16;
     constexpr int XT = BM * BK * 2, WT = BN * BK * 2, SLOT = XT + WT;
     constexpr int RPI = 1024 / (BK * 2);        // tile rows covered by one 1 KiB wave-instruction
     constexpr int CPR = BK / 8, RPB = 16 / CPR;  // 16-byte chunks per row, rows per 256-byte bank row
     constexpr int XQ = BM / RPI / NW, WQ = BN / RPI / NW;  // DMA instructions per wave and k-tile
-    constexpr int LPW = XQ + WQ;
-    constexpr int AHEAD = NS - 1;               // k-tiles in flight
-    constexpr int NPF = BM / 64;  // L2-prefetch wave-instructions per k-tile: one 128-byte line per X row (BK = 64 only)
-    __shared__ __attribute__((aligned(16))) unsigned char smem[NS * SLOT + NW * 256];  // ring + a throw-away line per wave
+    static_assert(PH == 1 || PH == 2, "issue cadence");
+    static_assert(XQ == 4 && WQ == 4 && WAVES_M == 2 && NMF % 2 == 0 && HV_GEMM_DEFER,
+                  "the two-group k-loop is written for the 256 x 256 x 64 tile on 8 waves and the 128 x 128 x 64 tile on 4");
+    __shared__ __attribute__((aligned(16))) unsigned char smem[NS * SLOT];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -625,11 +628,11 @@ __global__ __launch_bounds__(NW * 64, 2) void hv_gemm_glds_kernel(HvGemmParams p
 
     const int tiles_n = (p.N + BN - 1) / BN, tiles_m = (p.M + BM - 1) / BM;
     const int total = tiles_n * tiles_m;
-    // Tile raster.  The ~64 workgroups of an XCD walk consecutive tile indices at the same time and share its 4 MiB
-    // L2.  Row-major tile order makes them 64 n-tiles of ONE m-block when N is wide: every m-block then re-streams
-    // the whole weight matrix through the L2-miss path (measured with FETCH_SIZE: 27x the algorithmic read bytes at
-    // N = 10240).  Walking gm m-blocks per n-step instead makes the concurrent set gm x (64/gm) tiles: each X
-    // k-slice is shared by 64/gm workgroups and each W k-slice by gm.
+    // Tile raster.  The workgroups of an XCD walk consecutive tile indices at the same time and share its 4 MiB L2.
+    // Row-major tile order makes them n-tiles of ONE m-block when N is wide: every m-block then re-streams the whole
+    // weight matrix through the L2-miss path (measured with FETCH_SIZE: 27x the algorithmic read bytes at N = 10240).
+    // Walking gm m-blocks per n-step instead makes the concurrent set gm x (64/gm) tiles: each X k-slice is shared by
+    // 64/gm workgroups and each W k-slice by gm.
     auto tile_origin = [&](int ti, int& m0, int& n0) __attribute__((always_inline)) {
         if (gm <= 1) {
             m0 = (ti / tiles_n) * BM;
@@ -642,33 +645,22 @@ __global__ __launch_bounds__(NW * 64, 2) void hv_gemm_glds_kernel(HvGemmParams p
         m0 = (g * gm + r % rows) * BM;
         n0 = (r / rows) * BN;
     };
+    // workgroup w of an XCD takes tiles w, w + G, w + 2G ... of the XCD's contiguous range
     const int wg_per_xcd = gridDim.x / 8;
     const int xcd = blockIdx.x % 8, wg = blockIdx.x / 8;
     const int per_xcd = (total + 7) / 8;
     const int t_begin = xcd * per_xcd;
     const int t_end = min(total, t_begin + per_xcd);
-    // Tile walk.  walk = 0 (round 1): workgroup w of an XCD takes tiles w, w + G, w + 2G ... of the XCD's range, so the G
-    // concurrent workgroups hold G consecutive tiles -- the n-tiles of one m-block run side by side and share its X panel in
-    // L2, but every one of them meets that panel for the first time: each k-step's LDS-DMA is an HBM miss (gemm_trace: ~5000
-    // clocks of blocked DMA issue per k-step on the streamed level-0 projections, whose LDS ring can only keep one k-tile in
-    // flight).  walk = 1: every workgroup takes a CONTIGUOUS run of tiles, i.e. it sweeps the n-tiles of an m-block itself,
-    // one after the other: the first sweep streams the X panel from HBM, the others find it in L2 / MALL; the workgroups of
-    // an XCD sweep n in step, so the W tile of a step is shared by all of them.
-    const int chunk = (t_end - t_begin + wg_per_xcd - 1) / wg_per_xcd;
-    const int first = walk ? t_begin + wg * chunk : t_begin + wg;
-    const int tstep = walk ? 1 : wg_per_xcd;
+    const int first = t_begin + wg;
+    const int tstep = wg_per_xcd;
     if (first >= t_end) return;
-    const int my_tiles = walk ? min(chunk, t_end - first) : (t_end - first + wg_per_xcd - 1) / wg_per_xcd;
+    const int my_tiles = (t_end - first + wg_per_xcd - 1) / wg_per_xcd;
     const int nk = p.K / BK;
     const int nsteps = my_tiles * nk;
 
-    // LDS-DMA issue state, advanced one k-tile per call.  Round 1 recomputed every source address in every k-step
-    // (row clamp, 64-bit row * stride product, the two-source test on reloaded kernel arguments): ~150 scalar and
-    // vector instructions and four dependent s_load round trips around six DMA instructions -- most of the "830-1100
-    // cycles of LDS-DMA issue" in the gemm_trace timeline.  Now the per-lane source address of each of the wave's DMA
-    // instructions is computed once per tile (xa / wa) and advanced by BK elements per k-step; the k-loop needs no
-    // kernel argument besides them.  The row -> bank-row swizzle only depends on (row / RPB) % CPR: a lane's chunk
-    // column is the same for every wave-instruction when these start at multiples of 16 rows (BK = 32).
+    // LDS-DMA issue state, advanced one k-tile per call.  The per-lane source address of each of the wave's DMA
+    // instructions is computed once per tile and advanced by BK elements per k-step; the k-loop needs no kernel
+    // argument besides them.  The row -> bank-row swizzle only depends on (row / RPB) % CPR.
     auto chunk_ofs_s = [&](int j, int sub) __attribute__((always_inline)) {
         const int row = (RPI % 16 == 0) ? sub : RPI * j + sub;
         return (((lane & (CPR - 1))) ^ ((row / RPB) % CPR)) * 8;
@@ -678,12 +670,11 @@ __global__ __launch_bounds__(NW * 64, 2) void hv_gemm_glds_kernel(HvGemmParams p
     int i_m0, i_n0;
     // 32-bit byte offsets from a wave-uniform base (hv_gemm_launch checks that the operands span < 4 GiB): half the
     // registers of full pointers, and the DMA instruction takes the base from an SGPR pair
-    static_assert(XQ <= 4 && WQ <= 4, "at most four DMA instructions per operand, wave and k-tile");
-    unsigned xo0 = 0, xo1 = 0, xo2 = 0, xo3 = 0, wo0 = 0, wo1 = 0, wo2 = 0, wo3 = 0;  // named scalars: see the note on set_x
+    unsigned xo0 = 0, xo1 = 0, xo2 = 0, xo3 = 0, wo0 = 0, wo1 = 0, wo2 = 0, wo3 = 0;  // named scalars: see the note below
     const char* xbase = reinterpret_cast<const char*>(p.X);
     const char* const wbase = reinterpret_cast<const char*>(p.W);
-    // (named scalars picked by a compile-time index: as arrays -- "#pragma unroll" or compile-time loops alike -- hipcc
-    //  kept the offsets of the NS = 2 instantiations in a stack slot: a scratch reload behind vmcnt(0) in every k-step)
+    // (named scalars picked by a compile-time index: as arrays hipcc kept the offsets in a stack slot: a scratch reload
+    //  behind vmcnt(0) in every k-step)
     // (tile changes are rare: keep their lane constants OUT of the k-loop's register budget -- an opaque copy per call stops
     //  hipcc from hoisting "RPI * j + sub" for every j into loop-carried registers, which spilled in the 256 x 256 kernel)
     auto fresh = [&](int v) __attribute__((always_inline)) {
@@ -698,7 +689,7 @@ __global__ __launch_bounds__(NW * 64, 2) void hv_gemm_glds_kernel(HvGemmParams p
         hv_static_for<XQ>([&](auto Q) __attribute__((always_inline)) {
             constexpr int q = decltype(Q)::value;
             const int j = wave + NW * q;
-            const int m = min(((HV_GEMM_DBG & 16) ? 0 : i_m0) + RPI * j + sub, p.M - 1);
+            const int m = min(i_m0 + RPI * j + sub, p.M - 1);
             hv_pick4<q>(xo0, xo1, xo2, xo3) = ((unsigned)m * (unsigned)ld + (unsigned)chunk_ofs_s(j, sub)) * 2u;  // < 4 GiB: exact in 32 bits
         });
     };
@@ -715,7 +706,7 @@ __global__ __launch_bounds__(NW * 64, 2) void hv_gemm_glds_kernel(HvGemmParams p
         });
     };
     set_tile();
-    // one DMA instruction of the k-tile being issued (X rows 64 q .. 64 q + 63 / W rows likewise, over the NW waves) ...
+    // one DMA instruction of the k-tile being issued (X rows BM/4 q .. +BM/4 / W rows likewise, over the NW waves) ...
     auto issue_x1 = [&](auto Q) __attribute__((always_inline)) {
         constexpr int q = decltype(Q)::value;
         unsigned& o = hv_pick4<q>(xo0, xo1, xo2, xo3);
@@ -739,57 +730,6 @@ __global__ __launch_bounds__(NW * 64, 2) void hv_gemm_glds_kernel(HvGemmParams p
             set_x(p.X2, p.ldx2);
         }
     };
-    auto issue = [&]() __attribute__((always_inline)) {
-        if constexpr (PH >= 1) {  // readiness-group order: G0 = all of W + the X rows of the first fragment half, G1 = the rest
-            hv_static_for<WQ>([&](auto Q) __attribute__((always_inline)) { issue_w1(Q); });
-            issue_x1(HvInt<0>{});
-            issue_x1(HvInt<2>{});
-            issue_x1(HvInt<1>{});
-            issue_x1(HvInt<3>{});
-        } else {
-            hv_static_for<XQ>([&](auto Q) __attribute__((always_inline)) { issue_x1(Q); });
-            hv_static_for<WQ>([&](auto Q) __attribute__((always_inline)) { issue_w1(Q); });
-        }
-        issue_advance();
-    };
-
-    // L2 prefetch of the streamed X operand, pfd k-tiles ahead of the LDS-DMA (tuning knob; BK = 64, one k-tile in flight).
-    // gemm_trace: on the level-0 projections the DMA of a k-tile is blocked ~4000-5000 clocks in issue -- its X rows are
-    // first touches that come from HBM / MALL at ~15 B/clk per CU, while lines already in L2 fill at ~56 B/clk.  Waves
-    // 0..NPF-1 therefore request one dword of every X row's 128-byte k-slice of the k-tile pfd steps further on (by LDS-DMA
-    // into a throw-away line: no VGPR destination).  The request is issued AFTER the step's own DMA; vmcnt retires in order,
-    // so the wait for that DMA at the next step leaves exactly this one request in flight and needs the previous step's
-    // request done -- a full k-step old by then.
-    const bool pf_on = pfd > 0 && BK == 64 && AHEAD == 1 && p.X2 == nullptr;
-    int f_tile = first, f_k = 0, f_step = 0, f_m0 = 0;
-    {
-        int dummy_n0;
-        tile_origin(f_tile, f_m0, dummy_n0);
-    }
-    auto pf_advance = [&]() __attribute__((always_inline)) {
-        ++f_step;
-        if (++f_k == nk) {
-            f_k = 0;
-            f_tile += tstep;
-            int dummy_n0;
-            tile_origin(f_tile, f_m0, dummy_n0);
-        }
-    };
-    auto pf_issue = [&]() __attribute__((always_inline)) {
-        if (f_step < nsteps && wave < NPF) {
-#ifndef HV_EMU
-            int l;  // lane id recomputed here: a loop-carried copy was the register that spilled in the 256 x 256 kernel
-            asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
-#else
-            const int l = lane;
-#endif
-            const int m = min(f_m0 + 64 * wave + l, p.M - 1);
-            hv_l2_prefetch_dword(p.X, ((unsigned)m * (unsigned)p.ldx + (unsigned)(f_k * BK)) * 2u, smem + NS * SLOT + wave * 256);
-        }
-        pf_advance();
-    };
-    if (pf_on)
-        for (int a = 0; a < AHEAD + pfd; ++a) pf_advance();  // the prefetch iterator runs pfd k-tiles ahead of the DMA iterator
 
     f32x4 acc[4][NMF];  // [nf][mf]
     auto clear_acc = [&]() __attribute__((always_inline)) {
@@ -803,27 +743,27 @@ __global__ __launch_bounds__(NW * 64, 2) void hv_gemm_glds_kernel(HvGemmParams p
 #ifdef HV_GEMM_TRACE
     int hv_ti = 0;
 #endif
-#pragma unroll
-    for (int a = 0; a < AHEAD; ++a)
-        if (a < nsteps) issue();
+    {  // prologue: k-tile 0 in readiness-group order (G0 = all of W + the X rows of the first fragment half, G1 = the rest)
+        hv_static_for<WQ>([&](auto Q) __attribute__((always_inline)) { issue_w1(Q); });
+        issue_x1(HvInt<0>{});
+        issue_x1(HvInt<2>{});
+        issue_x1(HvInt<1>{});
+        issue_x1(HvInt<3>{});
+        issue_advance();
+    }
     int c_tile = first, c_k = 0, c_slot = 0;  // consumer state
     int landed = 0;  // k-steps that need no vmcnt wait (see below)
-    static_assert(PH == 0 || (BK == 64 && NS == 2 && HV_GEMM_DEFER && XQ == 4 && WQ == 4 && WAVES_M == 2 && NMF % 2 == 0),
-                  "the two-group k-loop is written for the 256 x 256 x 64 tile on 8 waves and the 128 x 128 x 64 tile on 4");
     constexpr int HMF = NMF / 2;  // fragment rows per half: X DMA instruction q covers rows [BM / 4 * q, +BM / 4) = half q % 2 of wm = q / 2
     for (int s = 0; s < nsteps; ++s) {
-      if constexpr (PH >= 1) {
-        // Two readiness groups per k-tile, counted vmcnt, no drain (cdna_hip_programming.md T3+T4; the one-burst form below
-        // issues its 8 DMA instructions per wave in one go right after the barrier -- gemm_trace: 4000-5000 clocks blocked in
-        // issue on the streamed projections, with the MFMAs waiting behind them -- and drains vmcnt(0) at the end of every
-        // k-step).  A wave multiplies the X rows [WTM wm, +WTM) with the W rows [64 wn, +64) (256-tile: WTM = 128).  DMA
-        // instruction q of the NW waves covers rows [BM / 4 q, +BM / 4) of its operand, so
-        //   G0 = W q=0..3, X q=0, X q=2 : everything the FIRST fragment half (mf 0..3: X rows 128 wm + 0..63) needs,
-        //   G1 = X q=1, X q=3           : the X rows of the second half (mf 4..7).
+        // Two readiness groups per k-tile, counted vmcnt, no drain.  A wave multiplies the X rows [WTM wm, +WTM) with the
+        // W rows [64 wn, +64).  DMA instruction q of the NW waves covers rows [BM / 4 q, +BM / 4) of its operand, so
+        //   G0 = W q=0..3, X q=0, X q=2 : everything the FIRST fragment half (X rows WTM wm + 0 .. WTM/2 - 1) needs,
+        //   G1 = X q=1, X q=3           : the X rows of the second half.
         // Each wave issues the k-tile in that order (vmcnt retires in order): G0 of k-tile s+1 during the first half of step
         // s, G1 of it during the second.  Barrier B0 (step boundary) needs G0(s): the two G1(s) instructions behind it stay
         // in flight -> vmcnt(2); barrier B1 (mid-step) needs G1(s): the six G0(s+1) instructions behind it stay in flight
-        // -> vmcnt(6).  Slot (s+1) % 2 was last read in step s-1, i.e. before B0(s): free for the whole of step s.
+        // -> vmcnt(6) (PH = 2: only the four W instructions are out by then -> vmcnt(4)).  Slot (s+1) % 2 was last read in
+        // step s-1, i.e. before B0(s): free for the whole of step s.
         // After an epilogue everything has landed (it waits for every load before its first store): both waits of the next
         // step are skipped, and the stores drain under it (they are older than that step's DMA, so the counted waits of the
         // step after it retire them first -- a full k-step later).
@@ -838,9 +778,6 @@ __global__ __launch_bounds__(NW * 64, 2) void hv_gemm_glds_kernel(HvGemmParams p
         const unsigned char* xs = smem + c_slot * SLOT;
         const unsigned char* ws = xs + XT;
         if (++c_slot == NS) c_slot = 0;
-        // PH = 2: the same two groups at the eight-phase cadence -- one DMA instruction in front of every 8 MFMAs: W q=0..3
-        // through the first half, X q=0, 2, 1, 3 through the second (G0 is then complete half a step before B0 needs it; at
-        // B1 the four W instructions of k-tile s+1 stay in flight: vmcnt(4)).
         if (PH == 1 && more) {
             issue_w1(HvInt<0>{});
             issue_w1(HvInt<1>{});
@@ -908,52 +845,6 @@ __global__ __launch_bounds__(NW * 64, 2) void hv_gemm_glds_kernel(HvGemmParams p
                     acc[nf][HMF + mf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[kk][nf], xf[mf], acc[nf][HMF + mf], 0, 0, 0);
             }
         }
-      } else {
-        HV_TRACE(1);
-        // this wave's share of k-tile s has landed (up to AHEAD-1 later k-tiles may stay in flight) ...
-        // (vmcnt counts stores too, in order: right after an epilogue the youngest outstanding operations are the tile's
-        //  stores, and a counted wait would drain them.  The fast epilogue waits for every load and DMA before its first
-        //  store -- k-tiles s .. s+AHEAD-1 have landed -- so the next AHEAD k-steps need no wait at all and the stores
-        //  drain under them.)
-        const int later = nsteps - 1 - s;
-        if (HV_GEMM_DEFER && landed > 0)
-            --landed;
-        else if (pf_on && wave < NPF && AHEAD == 1)
-            hv_vm_wait<1>();  // this wave's prefetch request of the previous step may stay in flight
-        else if (later >= AHEAD - 1)
-            hv_vm_wait<(AHEAD - 1) * LPW>();
-        else if (AHEAD > 2 && later == 1)
-            hv_vm_wait<LPW>();
-        else
-            hv_vm_wait<0>();
-        // ... and so has everybody else's; all waves are also done reading k-tile s-1
-        HV_TRACE(2);
-        hv_barrier_raw();
-        HV_TRACE(3);
-        if (!(HV_GEMM_DBG & 8) && s + AHEAD < nsteps) issue();  // reuses the slot of k-tile s-1
-        if (pf_on) pf_issue();
-        HV_TRACE(4);
-        const unsigned char* xs = smem + c_slot * SLOT;
-        const unsigned char* ws = xs + XT;
-        if (++c_slot == NS) c_slot = 0;
-#pragma unroll
-        for (int kk = 0; kk < BK / 32; ++kk) {
-            bf16x8 wf[4], xf[NMF];
-#pragma unroll
-            for (int f = 0; f < 4; ++f)
-                wf[f] = (HV_GEMM_DBG & 4) ? hv_as_bf16x8(u32x4{(unsigned)s, (unsigned)lane, (unsigned)f, 1u})
-                                          : hv_as_bf16x8(hv_ld16(ws + hv_swz<BK>(64 * wn + 16 * f + r16, kk * 4 + quad)));
-#pragma unroll
-            for (int f = 0; f < NMF; ++f)
-                xf[f] = (HV_GEMM_DBG & 4) ? hv_as_bf16x8(u32x4{(unsigned)s, (unsigned)lane, (unsigned)f, 2u})
-                                          : hv_as_bf16x8(hv_ld16(xs + hv_swz<BK>(WTM * wm + 16 * f + r16, kk * 4 + quad)));
-#pragma unroll
-            for (int nf = 0; nf < 4; ++nf)
-#pragma unroll
-                for (int mf = 0; mf < NMF; ++mf)
-                    acc[nf][mf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nf], xf[mf], acc[nf][mf], 0, 0, 0);
-        }
-      }
         HV_TRACE(5);
         if (++c_k == nk) {
             c_k = 0;
@@ -962,7 +853,7 @@ __global__ __launch_bounds__(NW * 64, 2) void hv_gemm_glds_kernel(HvGemmParams p
                 int m0, n0;
                 tile_origin(c_tile, m0, n0);
                 hv_gemm_epilogue_form<NMF>(form, p, acc, m0 + WTM * wm, n0 + 64 * wn, r16, quad HV_TRACE_ARG);
-                landed = AHEAD;
+                landed = 1;
             }
             c_tile += tstep;
             clear_acc();
@@ -972,18 +863,13 @@ __global__ __launch_bounds__(NW * 64, 2) void hv_gemm_glds_kernel(HvGemmParams p
 }
 
 static int g_hv_gemm_max_grid = 512;  // tuning knob (hv_set_tuning): persistent workgroups
-static int g_hv_gemm_walk = 0;          // tuning knob: 1 = contiguous tile run per workgroup (see the kernel; measured no gain: the X panel of a 256-row block does not survive in the 4 MiB L2 next to 32 workgroups' tiles), 0 = strided (default)
-static int g_hv_gemm_pfd = 0;           // tuning knob: L2-prefetch distance in k-tiles (0 = off)
-static int g_hv_gemm_raster = 0;        // tuning knob: m-blocks per raster group (0 = auto: 8 when N spans more than 8 tiles)
-// tuning knob (hv_set_tuning key 3) -- tile policy of the LDS-DMA kernel:
-//   9 (default, round 2): BK = 64 everywhere (whole 128-byte lines per operand row: the kernel is bound by the CU's
-//     L2 -> LDS fill path, which moves 64-byte row segments at half the rate) -- 256x256x64 (one 8-wave workgroup per CU)
-//     when N >= 960, 128x128x64 (two 4-wave workgroups per CU) otherwise.  Same-box sweep after the round-2 epilogue
-//     (gpurun_out/gm_*.txt -> profiles/r02_gemm_tile_modes.txt): level-0 QKV 0.435 -> 0.373 ms, level-2 ff1 0.558 -> 0.480,
-//     level-0 out-projection 0.216 -> 0.193 against policy 2
-//   2: round-1 policy (256x128x32 two workgroups per CU; 128x128x64 when K >= 2N)
-//   1 / 3 / 4 / 6 / 7 / 8: force one instantiation (A/Bs); 0 = register-staged kernel
-static int g_hv_gemm_glds = 9;  // 10 = 9 + the fill test below: per-shape gains measured, the step not yet
+// tuning knob (hv_set_tuning key 3) -- kernel selection:
+//   1 (default): 256 x 256 x 64 (one 8-wave workgroup per CU) when N >= 960 and its tiles fill the last round over the 256
+//      CUs to >= 90 %, otherwise 128 x 128 x 64 (two 4-wave workgroups per CU); round-3 same-box step A/B
+//      (profiles/r03_step_ab.txt): 130.0 ms (round-2 default) -> 128.0 ms
+//   2: 256 x 256 x 64 wherever its tile shape is legal (A/Bs), 3: 128 x 128 x 64 everywhere (A/Bs)
+//   0: the register-staged kernel for everything (A/Bs; also what problems outside the fast epilogue forms run on)
+static int g_hv_gemm_glds = 1;
 
 static inline int hv_gemm_launch(const HvGemmParams& p, hipStream_t stream) {
     if (p.M <= 0 || p.N <= 0 || p.K <= 0) return -1;
@@ -1008,91 +894,29 @@ static inline int hv_gemm_launch(const HvGemmParams& p, hipStream_t stream) {
     const int form128 = hv_gemm_fast_form(p, 128), form64 = hv_gemm_fast_form(p, 64);
     if (g_hv_gemm_glds && !prologue && p.M >= 256 && span_ok && form64 != HV_FORM_NONE) {
         const int tm = (p.M + 255) / 256;
-        // 256x256 tiles (one 128 KiB workgroup per CU, a third fewer bytes per FLOP through the
-        // per-CU load path) when N fills them about as well as 256x128 tiles would
         const int n128 = ((p.N + 127) / 128) * 128, n256 = ((p.N + 255) / 256) * 256;
-        // (the grouped raster is a property of the strided walk; a contiguous run sweeps n inside one m-block)
-        const int gm = g_hv_gemm_walk ? 1 : (g_hv_gemm_raster > 0 ? g_hv_gemm_raster : (n128 / 128 > 8 ? 8 : 1));
-        // 256x256x64 tiles, 2-slot 128 KiB ring, 8 waves (2 x 4 of 128x64), one workgroup per CU: whole 128-byte lines per
-        // row (twice the LDS-DMA fill rate of 64-byte segments) and 2/3 of the operand bytes per FLOP of the 256x128 tile.
-        // The kernel is bound by the CU's L2 -> LDS fill path (~27-60 B/clk measured: round-2 attention trace, round-1
-        // fillbw probe), so for wide N this is the shape that gets closest to the MFMA bound.
+        const int gm = n128 / 128 > 8 ? 8 : 1;  // grouped raster for wide outputs (see the kernel)
         const bool ok128 = form128 != HV_FORM_NONE;  // a per-row table may fit 64-row but not 128-row wave sub-tiles
-        // Policy 10 (opt-in until the step is re-measured with it): ... and when the 256x256 tiles fill the 256 CUs' last round to >= 90 % (one workgroup per CU:
-        // 360 tiles are two rounds at 70 %); otherwise the 128x128x64 kernel, whose 512 slots quantise four times finer --
-        // measured on the level-2 projections (M = 18432): N = 1280 0.096 -> 0.083 ms, K = 5120 0.280 -> 0.245 ms, N = 3840
-        // 0.212 -> 0.202 ms (profiles/r02_gemm_tile_modes.txt).
+        // 256 x 256 tiles when N fills them about as well as 128-column tiles would, and when they fill the 256 CUs' last
+        // round to >= 90 % (one workgroup per CU: 360 tiles are two rounds at 70 %); otherwise the 128 x 128 x 64 kernel,
+        // whose 512 slots quantise four times finer
         const int t256 = tm * (n256 / 256), rounds256 = (t256 + 255) / 256;
         const bool fills256 = t256 * 10 >= rounds256 * 256 * 9;
-        if (ok128 && (g_hv_gemm_glds >= 7) && p.N >= 960 && (n256 - p.N) * 8 <= p.N &&
-            (g_hv_gemm_glds != 8 || p.K >= 640) && ((g_hv_gemm_glds != 10 && g_hv_gemm_glds != 12 && g_hv_gemm_glds < 14) || fills256)) {
-            const int tiles = tm * (n256 / 256);
-            int grid = ((tiles + 7) / 8) * 8;
+        const bool shape256 = ok128 && p.N >= 960 && (n256 - p.N) * 8 <= p.N;
+        if (g_hv_gemm_glds != 3 && shape256 && (fills256 || g_hv_gemm_glds == 2)) {
+            int grid = ((t256 + 7) / 8) * 8;
             if (grid > 256) grid = 256;
             if (grid > g_hv_gemm_max_grid) grid = g_hv_gemm_max_grid;
-            if (g_hv_gemm_glds == 13 || g_hv_gemm_glds == 14 || g_hv_gemm_glds == 16) {  // 13 / 14 = 9 / 10 at the eight-phase issue cadence
-                hv_note("hv_gemm_glds_kernel<64,2,256,8,256,2> | %s", shape);
-                hv_launch(hv_gemm_glds_kernel<64, 2, 256, 8, 256, 2>, dim3(grid), dim3(512), stream, p, gm, form128, g_hv_gemm_walk, 0);
-                return 0;
-            }
-            if (g_hv_gemm_glds >= 11) {  // 11 / 12 = 9 / 10 with the two-readiness-group k-loop (opt-in: not yet measured)
-                hv_note("hv_gemm_glds_kernel<64,2,256,8,256,1> | %s", shape);
-                hv_launch(hv_gemm_glds_kernel<64, 2, 256, 8, 256, 1>, dim3(grid), dim3(512), stream, p, gm, form128, g_hv_gemm_walk, 0);
-                return 0;
-            }
-            hv_note("hv_gemm_glds_kernel<64,2,256,8,256> | %s", shape);
-            hv_launch(hv_gemm_glds_kernel<64, 2, 256, 8, 256>, dim3(grid), dim3(512), stream, p, gm, form128, g_hv_gemm_walk, g_hv_gemm_pfd);
+            hv_note("hv_gemm_glds_kernel<256,8,256,1> | %s", shape);
+            hv_launch(hv_gemm_glds_kernel<256, 8, 256, 1>, dim3(grid), dim3(512), stream, p, gm, form128);
             return 0;
         }
-        if (ok128 && g_hv_gemm_glds == 3 && p.N >= 512 && (n256 - n128) * 12 <= p.N) {
-            const int tiles = tm * (n256 / 256);
-            int grid = ((tiles + 7) / 8) * 8;
-            if (grid > 256) grid = 256;
-            if (grid > g_hv_gemm_max_grid) grid = g_hv_gemm_max_grid;
-            hv_note("hv_gemm_glds_kernel<32,4,256,8> | %s", shape);
-            hv_launch(hv_gemm_glds_kernel<32, 4, 256, 8>, dim3(grid), dim3(512), stream, p, gm, form128, g_hv_gemm_walk, g_hv_gemm_pfd);
-            return 0;
-        }
-        // 128x128x64 tiles (whole 128-byte lines per row: 1.8x the LDS-DMA rate of 64-byte row segments), 2-slot 64 KiB
-        // ring, two workgroups per CU: measured 7-13 % faster than 256x128x32 when K >= 2 N (the FF output projections),
-        // slower for wide outputs (half the operand reuse per tile)
-        if (!ok128 || g_hv_gemm_glds == 6 || g_hv_gemm_glds >= 9 || ((g_hv_gemm_glds == 2 || g_hv_gemm_glds >= 7) && p.K >= 2 * p.N)) {
-            const int tiles6 = ((p.M + 127) / 128) * (n128 / 128);
-            int grid6 = ((tiles6 + 7) / 8) * 8;
-            if (grid6 > 512) grid6 = 512;
-            if (grid6 > g_hv_gemm_max_grid) grid6 = g_hv_gemm_max_grid;
-            if (g_hv_gemm_glds >= 15) {  // 15 / 16 = 12 / 14 with the two-group k-loop in the 128 x 128 x 64 kernel as well
-                if (g_hv_gemm_glds == 16) {
-                    hv_note("hv_gemm_glds_kernel<64,2,128,4,128,2> | %s", shape);
-                    hv_launch(hv_gemm_glds_kernel<64, 2, 128, 4, 128, 2>, dim3(grid6), dim3(256), stream, p, gm, form64, g_hv_gemm_walk, 0);
-                } else {
-                    hv_note("hv_gemm_glds_kernel<64,2,128,4,128,1> | %s", shape);
-                    hv_launch(hv_gemm_glds_kernel<64, 2, 128, 4, 128, 1>, dim3(grid6), dim3(256), stream, p, gm, form64, g_hv_gemm_walk, 0);
-                }
-                return 0;
-            }
-            hv_note("hv_gemm_glds_kernel<64,2,128,4,128> | %s", shape);
-            hv_launch(hv_gemm_glds_kernel<64, 2, 128, 4, 128>, dim3(grid6), dim3(256), stream, p, gm, form64, g_hv_gemm_walk, g_hv_gemm_pfd);
-            return 0;
-        }
-        const int tiles = tm * (n128 / 128);
-        int grid = ((tiles + 7) / 8) * 8;
-        if (g_hv_gemm_glds == 1) {  // BK = 64, 144 KiB ring: one workgroup per CU
-            if (grid > 256) grid = 256;
-            if (grid > g_hv_gemm_max_grid) grid = g_hv_gemm_max_grid;
-            hv_note("hv_gemm_glds_kernel<64,3,128,8> | %s", shape);
-            hv_launch(hv_gemm_glds_kernel<64, 3, 128, 8>, dim3(grid), dim3(512), stream, p, gm, form64, g_hv_gemm_walk, g_hv_gemm_pfd);
-        } else {  // BK = 32, 72 KiB ring: two workgroups per CU whose epilogues interleave
-            if (grid > 512) grid = 512;
-            if (grid > g_hv_gemm_max_grid) grid = g_hv_gemm_max_grid;
-            if (g_hv_gemm_glds == 4) {
-                hv_note("hv_gemm_glds_kernel<32,3,128,8> | %s", shape);
-                hv_launch(hv_gemm_glds_kernel<32, 3, 128, 8>, dim3(grid), dim3(512), stream, p, gm, form64, g_hv_gemm_walk, g_hv_gemm_pfd);
-            } else {
-                hv_note("hv_gemm_glds_kernel<32,3,128,4> | %s", shape);
-                hv_launch(hv_gemm_glds_kernel<32, 3, 128, 4>, dim3(grid), dim3(256), stream, p, gm, form128, g_hv_gemm_walk, g_hv_gemm_pfd);
-            }
-        }
+        const int tiles6 = ((p.M + 127) / 128) * (n128 / 128);
+        int grid6 = ((tiles6 + 7) / 8) * 8;
+        if (grid6 > 512) grid6 = 512;
+        if (grid6 > g_hv_gemm_max_grid) grid6 = g_hv_gemm_max_grid;
+        hv_note("hv_gemm_glds_kernel<128,4,128,2> | %s", shape);
+        hv_launch(hv_gemm_glds_kernel<128, 4, 128, 2>, dim3(grid6), dim3(256), stream, p, gm, form64);
         return 0;
     }
     const int tiles = ((p.N + 127) / 128) * ((p.M + 127) / 128);

@@ -5,6 +5,3 @@
 int hvk_gemm(const hv_gemm_params& p, hipStream_t s) { return hv_gemm_launch(p, s); }
 void hvk_gemm_tune(int max_grid) { g_hv_gemm_max_grid = max_grid; }
 void hvk_gemm_use_glds(int on) { g_hv_gemm_glds = on; }
-void hvk_gemm_raster(int gm) { g_hv_gemm_raster = gm; }
-void hvk_gemm_walk(int v) { g_hv_gemm_walk = v; }
-void hvk_gemm_prefetch(int v) { g_hv_gemm_pfd = v; }

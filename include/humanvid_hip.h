@@ -186,13 +186,10 @@ int hv_attention_fp8(const hv_attention_params* p, const float* kscale, const fl
 #define HV_TUNE_ATTN_QT_D40 0  /* query fragments per wave for head dim 40: 2 or 4 (default 2) */
 #define HV_TUNE_ATTN_QT_D160 1 /* for head dim 160: 1 or 2 (default 2) */
 #define HV_TUNE_GEMM_MAX_GRID 2 /* persistent GEMM workgroups (multiple of 8, default 512) */
-#define HV_TUNE_GEMM_GLDS 3     /* LDS-DMA GEMM tile policy: 9 = default (round 2): BK = 64 everywhere -- 256x256x64 for N >= 960, 128x128x64 otherwise; 10 = as 9, but 256x256x64 only when its tiles fill the last round over the 256 CUs to >= 90 % (level-2 / level-3 projections go to 128x128x64: per-shape 5-14 % faster, step not yet re-measured); 11 / 12 = 9 / 10 with the 256x256x64 k-loop issuing its LDS-DMA as two readiness groups under counted vmcnt (no drain per k-step; written at the end of round 2, emulator-checked, not yet measured); 13 / 14 = the same at the eight-phase cadence (one LDS-DMA instruction in front of every 8 MFMAs); 15 / 16 = 12 / 14 with that k-loop in the 128x128x64 kernel as well; 7 / 8 = as 2 plus 256x256x64 tiles (8 waves, one workgroup per CU) for N >= 960 (8: only when K >= 640); 2 = the round-1 policy: 4-wave 256x128x32, two workgroups/CU, or 128x128x64 when K >= 2N; 6 = 128x128x64 always, 4 = 8-wave 256x128x32, 1 = 8-wave BK=64, 3 = 256x256 tiles, 0 = register-staged */
+#define HV_TUNE_GEMM_GLDS 3     /* GEMM kernel selection: 1 = default -- LDS-DMA kernel, 256x256x64 tiles (one 8-wave workgroup per CU) when N >= 960 and the tiles fill the last round over the 256 CUs to >= 90 %, 128x128x64 (two 4-wave workgroups per CU) otherwise; 2 = 256x256x64 wherever the shape allows, 3 = 128x128x64 everywhere, 0 = register-staged kernel (A/Bs; results are bit-identical across 1 / 2 / 3) */
 #define HV_TUNE_CONV_GLDS 4     /* 1: conv weight tiles by LDS-DMA (default), 0: register-staged */
-#define HV_TUNE_GEMM_RASTER 6   /* m-blocks per tile-raster group of the LDS-DMA GEMM (0 = auto, 1 = row-major) */
 #define HV_TUNE_TEMPORAL_MFMA 7 /* temporal attention: 1 = MFMA kernel, one wave per (batch, pixel, head) (default), 0 = VALU kernel */
-#define HV_TUNE_CONV_BIG 5      /* 1: 256-pixel conv tiles where the image fills them (default), 0: 128; 2: 256-pixel tiles on 4 waves of 128 pixels for stride-1 convolutions (measured slower); 3: 64-channel reduction chunks for stride-1 convolutions (whole 128-byte weight lines by LDS-DMA, 32 MFMAs per tap step; written at the end of round 2, emulator-checked, not yet measured) */
-#define HV_TUNE_GEMM_WALK 8     /* LDS-DMA GEMM tile walk: 1 = every workgroup takes a contiguous run of tiles, 0 = strided over the XCD's range (default) */
-#define HV_TUNE_GEMM_PREFETCH 9 /* LDS-DMA GEMM: L2 prefetch of the X operand this many k-tiles ahead (0 = off) */
+#define HV_TUNE_CONV_BIG 5      /* 1 (default): 256-pixel tiles for the upsample-folded convolution, 64-channel reduction chunks for stride-1 convolutions on images of <= 384 pixels; 0 / 2: neither / only the 256-pixel tiles (A/Bs); 3: 64-channel chunks for every stride-1 convolution whose sources allow them (A/B) */
 int hv_set_tuning(int key, int value);
 
 /* ---- temporal self-attention over the frame axis ------------------------------------------

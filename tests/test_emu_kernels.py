@@ -53,7 +53,7 @@ def test_gemm_lds_dma_kernel_variants(cx):
     kc.case_gemm(cx, M=260, N=64, K=64, seed=24, residual=False, out_f32=True)
     kc.case_gemm_lnfold(cx, B=2, Fr=3, P=50, C=128, N=192, seed=25)
     kc.case_gemm_geglu(cx, M=257, C=64, seed=26)
-    for variant in (0, 1, 2, 4, 6):  # register-staged kernel; the ring-buffer LDS-DMA variants (BK=64, 4-wave and 8-wave BK=32)
+    for variant in (0, 2, 3):  # register-staged kernel; 256x256x64 / 128x128x64 LDS-DMA tiles wherever legal
         cx.lib.call("hv_set_tuning", 3, variant)
         try:
             kc.case_gemm(cx, M=300, N=132, K=128, seed=21, residual=True)
@@ -61,7 +61,7 @@ def test_gemm_lds_dma_kernel_variants(cx):
             kc.case_gemm_geglu(cx, M=257, C=64, seed=26)
             kc.case_gemm_lnfold(cx, B=2, Fr=3, P=50, C=128, N=192, seed=25)
         finally:
-            cx.lib.call("hv_set_tuning", 3, 9)
+            cx.lib.call("hv_set_tuning", 3, 1)
 
 
 def test_gemm_fast_epilogue_forms(cx):
@@ -74,12 +74,12 @@ def test_gemm_fast_epilogue_forms(cx):
     kc.case_gemm_forms(cx, M=300, C=64, N=96, P=64, form="ln", seed=33)        # fits 64-row but not 128-row wave tiles
     cx.lib.call("hv_set_tuning", 2, 8)
     try:
-        for variant in (9, 2, 1, 4, 6):
+        for variant in (1, 2, 3):
             cx.lib.call("hv_set_tuning", 3, variant)
             for form in ("ln", "ln_yt", "ln_geglu", "res", "plain"):
                 kc.case_gemm_forms(cx, M=900, C=192, N=320, P=128, form=form, seed=34)
     finally:
-        cx.lib.call("hv_set_tuning", 3, 9)
+        cx.lib.call("hv_set_tuning", 3, 1)
         cx.lib.call("hv_set_tuning", 2, 512)
 
 
@@ -89,112 +89,71 @@ def test_affine_apply(cx):
 
 
 def test_gemm_grouped_tile_raster(cx):
-    """tile raster with gm m-blocks per n-step (default for N > 1024; forced here), ragged last group"""
-    cx.lib.call("hv_set_tuning", 6, 2)
-    cx.lib.call("hv_set_tuning", 2, 8)
-    cx.lib.call("hv_set_tuning", 8, 0)  # the grouped raster belongs to the strided tile walk
-    try:
-        kc.case_gemm(cx, M=1300, N=320, K=64, seed=61)            # 6 m-blocks x 3 n-tiles, groups of 2
-        kc.case_gemm(cx, M=1100, N=260, K=128, seed=62)           # 5 m-blocks: last group has one row
-        kc.case_gemm_lnfold(cx, B=2, Fr=4, P=150, C=128, N=192, seed=63)
-        cx.lib.call("hv_set_tuning", 6, 8)
-        kc.case_gemm(cx, M=800, N=384, K=64, seed=64)             # fewer m-blocks than the group size
-    finally:
-        cx.lib.call("hv_set_tuning", 2, 512)
-        cx.lib.call("hv_set_tuning", 6, 0)
-        cx.lib.call("hv_set_tuning", 8, 0)
-
-
-def test_gemm_tile_walks(cx):
-    """contiguous (default) and strided tile walks, few persistent workgroups so that each walks several tiles, ragged
-    tile counts per workgroup"""
+    """tile raster with 8 m-blocks per n-step (wide outputs: N spans more than eight 128-column tiles), ragged last group,
+    few persistent workgroups so that each walks several tiles"""
     cx.lib.call("hv_set_tuning", 2, 8)
     try:
-        for walk in (1, 0):
-            cx.lib.call("hv_set_tuning", 8, walk)
-            kc.case_gemm_forms(cx, M=1300, C=128, N=320, P=128, form="res", seed=81)      # 128x128 tiles: 11 x 3
-            kc.case_gemm_forms(cx, M=1300, C=128, N=1024, P=128, form="ln", seed=82)      # 256x256 tiles: 6 x 4
-            kc.case_gemm_forms(cx, M=700, C=64, N=2048, P=128, form="ln_geglu", seed=83)  # 3 x 8
-        # tile policy 10: 256x256 tiles only when they fill the last round over the 256 CUs to >= 90 %
-        cx.lib.call("hv_set_tuning", 3, 10)
-        kc.case_gemm_forms(cx, M=1300, C=64, N=1024, P=128, form="ln", seed=84)           # 24 tiles: 128x128x64 kernel
-        kc.case_gemm_forms(cx, M=256 * 58, C=64, N=1024, P=128, form="plain", seed=85)    # 232 of 256: 256x256x64 kernel
+        for variant in (1, 2, 3):
+            cx.lib.call("hv_set_tuning", 3, variant)
+            kc.case_gemm(cx, M=2400, N=1152, K=64, seed=61)            # 10 m-blocks of 256 (19 of 128): last group shorter
+            kc.case_gemm_lnfold(cx, B=2, Fr=4, P=150, C=128, N=1280, seed=63)
+            kc.case_gemm(cx, M=800, N=1536, K=64, seed=64)             # fewer m-blocks than the group size
     finally:
-        cx.lib.call("hv_set_tuning", 3, 9)
         cx.lib.call("hv_set_tuning", 2, 512)
-        cx.lib.call("hv_set_tuning", 8, 0)
+        cx.lib.call("hv_set_tuning", 3, 1)
 
 
-def test_gemm_two_group_k_loop(cx):
-    """tile policies 11 / 12 (13 / 14): the 256x256x64 kernel with its LDS-DMA issued as two readiness groups under counted
-    vmcnt (hv_gemm_glds_kernel<..., PH = 1>; PH = 2: one DMA instruction in front of every 8 MFMAs).  The emulator checks the indexing of the split issue / split fragment halves and the
-    tile hand-over (one k-step per tile, several, a second K source); results must equal the one-burst kernel bit for bit
-    (same MFMA order per accumulator)."""
+def test_gemm_tile_selection_and_k_loop(cx):
+    """the two LDS-DMA instantiations (256x256x64 with burst issue of its two readiness groups, 128x128x64 at the
+    eight-phase cadence) under counted vmcnt: indexing of the split issue / split fragment halves, the tile hand-over (one
+    k-step per tile, several, a second K source), the fill test of the default selection.  Every output element accumulates
+    its k-slices in the same order under every selection: results must agree bit for bit."""
     import torch
 
     from humanvid_amd import ops
 
     cx.lib.call("hv_set_tuning", 2, 8)  # few persistent workgroups: several tiles each
     try:
-        cx.lib.call("hv_set_tuning", 3, 11)
-        for form in ("ln", "ln_yt", "ln_geglu", "res", "plain"):
-            kc.case_gemm_forms(cx, M=1300, C=192, N=1024, P=128, form=form, seed=91)         # 3 k-steps per tile
-        kc.case_gemm_forms(cx, M=700, C=64, N=1024, P=128, form="res", seed=92)               # one k-step per tile
-        kc.case_gemm(cx, M=520, N=1024, K=256, seed=93, two_source=True)                      # second source from k-tile 2 on
-        cx.lib.call("hv_set_tuning", 3, 13)                                                   # eight-phase issue cadence
-        for form in ("ln_yt", "ln_geglu", "res"):
-            kc.case_gemm_forms(cx, M=1300, C=192, N=1024, P=128, form=form, seed=91)
-        kc.case_gemm_forms(cx, M=700, C=64, N=1024, P=128, form="res", seed=92)
-        kc.case_gemm(cx, M=520, N=1024, K=256, seed=93, two_source=True)
-        cx.lib.call("hv_set_tuning", 3, 12)                                                   # 11 + the fill test of 10
-        kc.case_gemm_forms(cx, M=256 * 58, C=64, N=1024, P=128, form="plain", seed=85)        # 232 of 256 tiles: 256x256 kernel
-        kc.case_gemm_forms(cx, M=700, C=64, N=1024, P=128, form="res", seed=92)               # 12 tiles: 128x128x64 kernel
-        for policy in (15, 16):  # the same k-loop in the 128x128x64 kernel (N < 960, or 256-tiles that would not fill the CUs)
-            cx.lib.call("hv_set_tuning", 3, policy)
+        for variant in (1, 2, 3):
+            cx.lib.call("hv_set_tuning", 3, variant)
             for form in ("ln", "ln_yt", "ln_geglu", "res", "plain"):
-                kc.case_gemm_forms(cx, M=900, C=192, N=320, P=128, form=form, seed=95)
-            kc.case_gemm_forms(cx, M=520, C=64, N=192, P=64, form="ln", seed=96)        # one k-step per tile, 64-row table period
-            kc.case_gemm(cx, M=520, N=320, K=256, seed=97, two_source=True)
+                kc.case_gemm_forms(cx, M=1300, C=192, N=1024, P=128, form=form, seed=91)     # 3 k-steps per tile
+            kc.case_gemm_forms(cx, M=700, C=64, N=1024, P=128, form="res", seed=92)           # one k-step per tile
+            kc.case_gemm(cx, M=520, N=1024, K=256, seed=93, two_source=True)                  # second source from k-tile 2 on
+            kc.case_gemm_forms(cx, M=520, C=64, N=192, P=64, form="ln", seed=96)              # 64-row table period
+        cx.lib.call("hv_set_tuning", 3, 1)
+        kc.case_gemm_forms(cx, M=256 * 58, C=64, N=1024, P=128, form="plain", seed=85)        # 232 of 256 tiles: 256x256 kernel
         g = torch.Generator().manual_seed(94)
         x = cx.bf(torch.randn(1100, 320, generator=g))
         w = cx.bf(torch.randn(1280, 320, generator=g) * 320**-0.5)
         bias = cx.dev(torch.randn(1280, generator=g) * 0.1)
         outs = []
-        for policy in (9, 11, 13):
-            cx.lib.call("hv_set_tuning", 3, policy)
+        for variant in (1, 2, 3):
+            cx.lib.call("hv_set_tuning", 3, variant)
             y = torch.zeros(1100, 1280, dtype=torch.bfloat16, device=cx.device)
             ops.gemm(cx.lib, cx.stream, x, w, y, bias=bias)
             cx.sync()
             outs.append(y.clone())
         assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
-        w2 = cx.bf(torch.randn(320, 320, generator=g) * 320**-0.5)
-        outs = []
-        for policy in (9, 15, 16):  # N = 320: the 128x128x64 kernel
-            cx.lib.call("hv_set_tuning", 3, policy)
-            y = torch.zeros(1100, 320, dtype=torch.bfloat16, device=cx.device)
-            ops.gemm(cx.lib, cx.stream, x, w2, y, bias=bias[:320].contiguous())
-            cx.sync()
-            outs.append(y.clone())
-        assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
     finally:
-        cx.lib.call("hv_set_tuning", 3, 9)
+        cx.lib.call("hv_set_tuning", 3, 1)
         cx.lib.call("hv_set_tuning", 2, 512)
 
 
 def test_gemm_lds_dma_256x256_tiles(cx):
-    """variant 3: 256x256 tiles, 4-slot ring (3 k-tiles in flight), waves own 128x64"""
-    cx.lib.call("hv_set_tuning", 3, 3)
+    """selection 2: 256x256x64 tiles wherever the shape allows them (N >= 960), waves own 128x64"""
+    cx.lib.call("hv_set_tuning", 3, 2)
     try:
-        kc.case_gemm(cx, M=300, N=512, K=64, seed=41, residual=True)        # single k-step per tile pair
-        kc.case_gemm(cx, M=520, N=768, K=192, seed=42, two_source=True)
-        kc.case_gemm(cx, M=256, N=512, K=128, seed=43, transposed=True)
-        kc.case_gemm_lnfold(cx, B=2, Fr=3, P=50, C=128, N=512, seed=44)
-        kc.case_gemm_geglu(cx, M=257, C=64, seed=45)                        # N = 512
+        kc.case_gemm(cx, M=300, N=1024, K=64, seed=41, residual=True)       # single k-step per tile
+        kc.case_gemm(cx, M=520, N=1000, K=192, seed=42, two_source=True)    # ragged N
+        kc.case_gemm(cx, M=256, N=1024, K=128, seed=43, transposed=True)
+        kc.case_gemm_lnfold(cx, B=2, Fr=3, P=50, C=128, N=1024, seed=44)
+        kc.case_gemm_geglu(cx, M=257, C=128, seed=45)                       # N = 1024
         cx.lib.call("hv_set_tuning", 2, 8)                                  # several tiles per workgroup
         kc.case_gemm(cx, M=1200, N=1024, K=96 + 32, seed=46)
     finally:
         cx.lib.call("hv_set_tuning", 2, 512)
-        cx.lib.call("hv_set_tuning", 3, 9)
+        cx.lib.call("hv_set_tuning", 3, 1)
 
 
 def test_gemm_prologue(cx):

@@ -13,7 +13,7 @@ thread_local HvProfile* g_hv_prof = nullptr;
 thread_local char g_hv_note[192] = "";
 
 int main(int argc, char** argv) {
-    int M = 294912, N = 960, K = 320, form = 1, policy = 9;
+    int M = 294912, N = 960, K = 320, form = 1, policy = 1;
     if (argc > 3) M = atoi(argv[1]), N = atoi(argv[2]), K = atoi(argv[3]);
     if (argc > 4) form = atoi(argv[4]);
     if (argc > 5) policy = atoi(argv[5]);

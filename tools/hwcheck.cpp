@@ -1,9 +1,10 @@
 // Seconds-long hardware check through the C ABI alone (no Python, no torch: runs in the last seconds of a GPU budget):
 //  1. hv_groupnorm_affine (partial sums + the wave-merge finalize) against a double-precision host reference,
-//  2. hv_gemm under tile policy 10 against policy 9 (same inputs) and against sampled host rows, at the level-2 / level-3
-//     shapes that policy 10 moves from the 256x256x64 to the 128x128x64 kernel.
-// Options: --experimental adds the variants that have not yet run on hardware (tile policies 11 / 12 / 13 against 9 / 10, bit
-// for bit; the 64-channel-chunk convolution against the default one); --bench prints ms per launch of the step's GEMM shapes under policies 9, 10, 11, 13, 15, 16 (HIP events, no Python start-up).
+//  2. hv_gemm under the kernel selections of HV_TUNE_GEMM_GLDS (1 default / 2 = 256x256x64 / 3 = 128x128x64 / 0 = register
+//     staged) against each other (bit for bit) and against sampled host rows, at shapes of the denoising step,
+//  3. the 3x3 convolution with 64-channel reduction chunks against the 32-channel kernel.
+// Option: --bench prints ms per launch of the step's GEMM shapes under selections 1 / 2 / 3 and of the convolution under both
+// chunk sizes (HIP events, no Python start-up).
 // Build: hipcc -O2 -Wno-unused-value tools/hwcheck.cpp -Iinclude -Lhumanvid_amd/lib -lhumanvid_hip -Wl,-rpath,'$ORIGIN/../../humanvid_amd/lib' -o tools/bin/hwcheck
 #include <hip/hip_runtime.h>
 #include <cmath>
@@ -92,7 +93,7 @@ static int check_gn(int n, int pixels, int C1, int C2, int splits, float offset,
     return !(rc == 0 && worst < 2e-4);
 }
 
-static int check_gemm(int M, int N, int K, int form, int pol_a = 9, int pol_b = 10) {  // form 0: bias + residual in place; 1: LayerNorm fold + V^T tail
+static int check_gemm(int M, int N, int K, int form, int pol_a = 2, int pol_b = 1) {  // form 0: bias + residual in place; 1: LayerNorm fold + V^T tail
     std::vector<uint16_t> x((size_t)M * K), w((size_t)N * K), res((size_t)M * N);
     const float ws = 1.0f / sqrtf((float)K);
     for (auto& v : x) v = f2b(rnd() + 0.25f);
@@ -133,7 +134,7 @@ static int check_gemm(int M, int N, int K, int form, int pol_a = 9, int pol_b = 
         if (N > ns) hipMemcpy(outt[pol].data(), dyt, outt[pol].size() * 2, hipMemcpyDeviceToHost);
         hipFree(dy), hipFree(dyt);
     }
-    hv_set_tuning(HV_TUNE_GEMM_GLDS, 9);
+    hv_set_tuning(HV_TUNE_GEMM_GLDS, 1);
     double dmax = 0;
     for (size_t i = 0; i < out[0].size(); ++i) dmax = fmax(dmax, fabs(b2f(out[0][i]) - b2f(out[1][i])));
     for (size_t i = 0; i < outt[0].size(); ++i) dmax = fmax(dmax, fabs(b2f(outt[0][i]) - b2f(outt[1][i])));
@@ -168,7 +169,7 @@ static void bench_gemm(int M, int N, int K, int form, const char* what) {  // fo
     hipEvent_t e0, e1;
     hipEventCreate(&e0), hipEventCreate(&e1);
     printf("%-34s M=%6d N=%5d K=%4d:", what, M, N, K);
-    for (int pol : {9, 10, 11, 13, 15, 16}) {
+    for (int pol : {1, 2, 3}) {
         hv_set_tuning(HV_TUNE_GEMM_GLDS, pol);
         hv_gemm_params p;
         memset(&p, 0, sizeof p);
@@ -191,7 +192,7 @@ static void bench_gemm(int M, int N, int K, int form, const char* what) {  // fo
         if (rc != 0) printf("  p%d rc=%d", pol, rc);
         else printf("  p%d %.4f ms %6.0f TF/s", pol, ms / 10, 2.0 * M * N * K / (ms / 10) / 1e9);
     }
-    hv_set_tuning(HV_TUNE_GEMM_GLDS, 9);
+    hv_set_tuning(HV_TUNE_GEMM_GLDS, 1);
     printf("\n");
     fflush(stdout);
     hipFree(dx), hipFree(dw), hipFree(dy), hipFree(dyt);
@@ -258,9 +259,8 @@ static int conv_ab(int n, int H, int W, int Cin, int Cout, int tune_a, int tune_
 }
 
 int main(int argc, char** argv) {
-    bool experimental = false, bench = false;
+    bool bench = false;
     for (int i = 1; i < argc; ++i) {
-        if (!strcmp(argv[i], "--experimental")) experimental = true;  // variants that have not yet run on hardware
         if (!strcmp(argv[i], "--bench")) bench = true;
     }
     int bad = 0;
@@ -268,34 +268,25 @@ int main(int argc, char** argv) {
     bad += check_gn(4, 384, 1280, 640, 8, -2.0f, {0, 3});
     bad += check_gn(2, 9, 640, 0, 4, 0.3f, {0, 1});
     bad += check_gn(3, 96, 2560, 0, 2, 5.0f, {1});
-    bad += check_gemm(18432, 1280, 1280, 0);
-    bad += check_gemm(4608, 1280, 1280, 0);
-    bad += check_gemm(18432, 3840, 1280, 1);
-    if (experimental) {  // tile policy 11: the 256x256x64 k-loop with two readiness groups / counted vmcnt (must equal 9 bit for bit)
-        bad += check_gemm(36864, 960, 320, 1, 9, 11);
-        bad += check_gemm(36864, 1280, 320, 0, 9, 11);
-        bad += check_gemm(18432, 3840, 1280, 1, 9, 11);
-        bad += check_gemm(4608, 2560, 64, 0, 9, 11);  // one k-step per tile: an epilogue after every step
-        bad += check_gemm(18432, 3840, 1280, 1, 10, 12);
-        bad += check_gemm(36864, 960, 320, 1, 9, 13);  // 13: the same loop at the eight-phase issue cadence
-        bad += check_gemm(18432, 3840, 1280, 1, 9, 13);
-        bad += check_gemm(4608, 2560, 64, 0, 9, 13);
-        bad += check_gemm(36864, 320, 320, 0, 9, 15);   // 15 / 16: the two-group loop in the 128 x 128 x 64 kernel
-        bad += check_gemm(36864, 320, 1280, 0, 9, 16);
-        bad += check_gemm(18432, 640, 64, 0, 9, 15);    // one k-step per tile
-        bad += check_gemm(18432, 1280, 1280, 0, 10, 16);
-    }
-    if (experimental) {  // 64-channel reduction chunks (HV_TUNE_CONV_BIG = 3) against the default convolution kernel
-        bad += conv_ab(4, 96, 64, 320, 320, 1, 3, false);
-        bad += conv_ab(3, 21, 13, 128, 200, 1, 3, false);  // ragged patches and output channels
-        bad += conv_ab(6, 12, 8, 1280, 1280, 1, 3, false);  // narrow images: 8 x 16 patches
+    // selection 1 (default: the fill test sends these level-2 / level-3 shapes to the 128x128x64 kernel) against 2
+    // (256x256x64 wherever legal) and against sampled host rows: bit-identical by construction
+    bad += check_gemm(18432, 1280, 1280, 0, 2, 1);
+    bad += check_gemm(4608, 1280, 1280, 0, 2, 1);
+    bad += check_gemm(18432, 3840, 1280, 1, 2, 1);
+    bad += check_gemm(36864, 960, 320, 1, 3, 1);    // the streamed level-0 projection: 128x128x64 against the default 256x256x64
+    bad += check_gemm(4608, 2560, 64, 0, 3, 2);     // one k-step per tile: an epilogue after every step
+    bad += check_gemm(36864, 320, 1280, 0, 0, 1);   // register-staged kernel against the LDS-DMA kernel
+    {  // 64-channel reduction chunks (HV_TUNE_CONV_BIG = 3 forces them) against the 32-channel kernel (0)
+        bad += conv_ab(4, 96, 64, 320, 320, 0, 3, false);
+        bad += conv_ab(3, 21, 13, 128, 200, 0, 3, false);  // ragged patches and output channels
+        bad += conv_ab(6, 12, 8, 1280, 1280, 0, 3, false);  // narrow images: 8 x 16 patches
     }
     if (bench) {
-        conv_ab(48, 96, 64, 320, 320, 1, 3, true);
-        conv_ab(48, 48, 32, 640, 640, 1, 3, true);
-        conv_ab(48, 24, 16, 1280, 1280, 1, 3, true);
-        conv_ab(48, 12, 8, 1280, 1280, 1, 3, true);
-        conv_ab(48, 96, 64, 640, 320, 1, 3, true);
+        conv_ab(48, 96, 64, 320, 320, 0, 3, true);
+        conv_ab(48, 48, 32, 640, 640, 0, 3, true);
+        conv_ab(48, 24, 16, 1280, 1280, 0, 3, true);
+        conv_ab(48, 12, 8, 1280, 1280, 0, 3, true);
+        conv_ab(48, 96, 64, 640, 320, 0, 3, true);
         const int M0 = 48 * 6144, M1 = 48 * 1536, M2 = 48 * 384, M3 = 48 * 96;
         bench_gemm(M0, 960, 320, 1, "level-0 spatial QKV (LN, V^T)");
         bench_gemm(M0, 960, 320, 3, "level-0 temporal QKV (LN)");

@@ -266,6 +266,10 @@ def main():
         from humanvid_amd import lib as hvlib
 
         hvlib.load().call("hv_set_tuning", 3, int(os.environ["HUMANVID_GEMM_GLDS"]))
+    if os.environ.get("HUMANVID_GEMM_PERM"):  # same-box A/B of the 16-byte GEMM epilogue (hv_set_tuning key 6)
+        from humanvid_amd import lib as hvlib
+
+        hvlib.load().call("hv_set_tuning", 6, int(os.environ["HUMANVID_GEMM_PERM"]))
     if os.environ.get("HUMANVID_CONV_BIG"):
         from humanvid_amd import lib as hvlib
 
@@ -327,6 +331,20 @@ def main():
     def after_loop(one_step):
         if world == 1 and not args.no_profile:
             prof["kernels"] = profile_step(one_step)
+        if world > 1:
+            # one more, eagerly launched step outside the timed region with every collective counted and bracketed by
+            # events: collectives per step, bytes this rank sends, and the exchange time the step is exposed to
+            sh = pipe.shard
+            sync_barrier()
+            sh.reset_stats()
+            sh.measure = True
+            t0 = time.perf_counter()
+            one_step()
+            torch.cuda.synchronize()
+            wall = (time.perf_counter() - t0) * 1e3
+            sh.measure = False
+            prof["exchange"] = dict(collectives_per_step=sh.stats["collectives"], bytes_sent_per_rank=sh.stats["bytes_sent"],
+                                    exposed_exchange_ms=sh.exposed_ms(), eager_step_ms=wall)
 
     if SETUP + Wm == 0:
         sync_barrier()
@@ -339,6 +357,14 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax)
 
+    exchange = None
+    if world > 1 and "exchange" in prof:
+        ex = prof["exchange"]
+        t = torch.tensor([ex["exposed_exchange_ms"], ex["eager_step_ms"]], device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        exchange = dict(ex, exposed_exchange_ms=float(t[0]), eager_step_ms=float(t[1]),
+                        note="one eagerly launched step after the timed region, max over ranks; exposed = event distance around "
+                             "every collective on the compute stream (nothing overlaps the exchange yet)")
     if rank == 0:
         cfg = dict(DEFAULT_UNET3D_CONFIG)
         cfg.update(SD15_INFERENCE_V2)
@@ -361,6 +387,8 @@ def main():
             "step_tflops_per_gpu": fl_total / 1e12 / (ms_step / 1e3) / world,
             "step_frac_of_mfma_peak": fl_total / 1e12 / (ms_step / 1e3) / world / PEAK_BF16_TFLOPS,
         }
+        if exchange is not None:
+            out["exchange"] = exchange
         if "kernels" in prof:
             roof, table = roofline_from_profile(prof["kernels"], os.path.join(REPO, "profiles", "r02_pmc_traffic.json"))
             out["roofline"] = roof

@@ -35,6 +35,30 @@ HV_DEV int hv_swz(int row, int chunk) {
     return row * (BK * 2) + ((chunk ^ ((row / RPB) % CPR)) << 4);
 }
 
+// Channel permutation of a wave's 64-channel block (round 3, LDS-DMA kernel, plain / residual / LayerNorm-fold outputs).
+// The MFMA gives a lane 4 consecutive rows of the A operand per 16x16 fragment; with the natural assignment "fragment nf,
+// row i <-> channel 16 nf + i" a lane owns 4-channel pieces 16 channels apart: 8-byte residual loads and output stores, 16
+// token rows x 32 bytes per wave-instruction -- the epilogue of a K = 320 tile is store-ISSUE-bound (7400 of ~29 000 cycles,
+// profiles/r02_gemm_trace.txt).  Assigning  fragment nf, row i <-> channel 32 (nf >> 1) + 8 (i >> 2) + 4 (nf & 1) + (i & 3)
+// instead makes the fragment pair (2j, 2j+1) of a lane 8 CONSECUTIVE channels 32 j + 8 quad + 0..7: 16-byte loads and
+// stores, 64 contiguous bytes per token and instruction, half the instructions.  It is only a different LDS row per
+// (fragment, lane) in the W-fragment reads; the W tile gets its own XOR swizzle so that those reads stay conflict-free
+// (checked per ds_read_b128 lane group: the X swizzle would make them 2-way).
+HV_DEV int hv_perm_row(int f, int i) { return 32 * (f >> 1) + 8 * (i >> 2) + 4 * (f & 1) + (i & 3); }
+// GEGLU (weight rows packed in 16-row [h | g] blocks, packing.geglu_row_order): fragment nf, row i = 4 q + e <-> packed row
+// of  h (nf even) / g (nf odd)  of the wave's output channel o = 8 q + e + 4 (nf >> 1)  -- a lane's two gated results per
+// row fragment are then the 8 consecutive output channels 8 quad + 0..7: one 16-byte store instead of two 8-byte ones.
+HV_DEV int hv_perm_row_geglu(int f, int i) {
+    const int o = 8 * (i >> 2) + (i & 3) + 4 * (f >> 1);
+    return 32 * (o >> 4) + 16 * (f & 1) + (o & 15);
+}
+// XOR swizzle of the W tile under either permuted assignment: conflict-free for every ds_read_b128 lane group of both
+// (searched over bit-parity swizzles; the X tile keeps hv_swz)
+HV_DEV int hv_wperm_swizzle(int row) { return (row & 1) | (((row >> 1) & 1) << 1) | (((row >> 3) & 1) << 2); }
+HV_DEV int hv_swz_wperm(int row, int chunk) {  // BK = 64: 128-byte rows, 8 chunks
+    return row * 128 + ((chunk ^ hv_wperm_swizzle(row)) << 4);
+}
+
 // erf with |error| < 1.5e-7 (Abramowitz & Stegun 7.1.26): one exp2 + one rcp + 5 FMA, vs ~60
 // instructions of libm erff in every GEGLU output element
 HV_DEV float hv_erf_fast(float x) {
@@ -368,6 +392,190 @@ HV_DEV void hv_gemm_epilogue_fast(const HvGemmParams& p, f32x4 (&acc)[4][NMF], i
     HV_TRACE(11);
 }
 
+// The same epilogue for the permuted channel assignment (hv_perm_row): plain bf16 row-major output with optional LayerNorm
+// fold / residual; the fragment pair (2j, 2j+1) of a lane is 8 consecutive channels n_base + 32 j + 8 quad.  N % 8 == 0.
+template <int NMF, bool LN, bool RES>
+HV_DEV void hv_gemm_epilogue_fast_perm(const HvGemmParams& p, f32x4 (&acc)[4][NMF], int m_base, int n_base, int r16, int quad,
+                                       const float* tab_row HV_TRACE_PARAM) {
+    constexpr int G = NMF < HV_GEMM_EPI_G ? NMF : HV_GEMM_EPI_G;  // row fragments per load group
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    int nc[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) nc[j] = min(n_base + 32 * j + 8 * quad, p.N - 8);
+    f32x4 add4[4], cs4[4];  // [2 j + h]: channels nc[j] + 4 h .. + 3
+#pragma unroll
+    for (int nf = 0; nf < 4; ++nf) add4[nf] = cs4[nf] = zero4;
+    auto ld4 = [&](const float* base, unsigned byte_ofs) __attribute__((always_inline)) {
+        return *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(base) + byte_ofs);
+    };
+    if (p.bias != nullptr) {
+#pragma unroll
+        for (int nf = 0; nf < 4; ++nf) add4[nf] = ld4(p.bias, 4u * (unsigned)(nc[nf >> 1] + 4 * (nf & 1)));
+    }
+    if (LN) {
+#pragma unroll
+        for (int nf = 0; nf < 4; ++nf) cs4[nf] = ld4(p.colsum, 4u * (unsigned)(nc[nf >> 1] + 4 * (nf & 1)));
+    }
+    if (tab_row != nullptr) {
+        f32x4 t4[4];
+#pragma unroll
+        for (int nf = 0; nf < 4; ++nf) t4[nf] = ld4(tab_row, 4u * (unsigned)(nc[nf >> 1] + 4 * (nf & 1)));
+#pragma unroll
+        for (int nf = 0; nf < 4; ++nf) add4[nf] += t4[nf];
+    }
+    u32x4 outp[NMF][2];
+#pragma unroll
+    for (int g = 0; g < NMF; g += G) {
+        float mean[G], rstd[G];
+        u32x4 res4[G][RES ? 2 : 1];
+#pragma unroll
+        for (int j = 0; j < G; ++j) {
+            const int mc = min(m_base + 16 * (g + j) + r16, p.M - 1);
+            if (LN) {
+                mean[j] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(p.row_mean) + 4u * (unsigned)mc);
+                rstd[j] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(p.row_rstd) + 4u * (unsigned)mc);
+            }
+            if (RES) {
+                const unsigned ro = (unsigned)mc * (unsigned)p.ldr * 2u;
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+                    res4[j][h] = hv_ld16(reinterpret_cast<const char*>(p.residual) + (ro + 2u * (unsigned)nc[h]));
+            }
+        }
+#if !defined(HV_EMU) && HV_GEMM_EPI_SB
+        __builtin_amdgcn_sched_barrier(0);  // the group's loads stay together, ahead of its arithmetic
+#endif
+        if (g == 0) HV_TRACE(7);
+#pragma unroll
+        for (int j = 0; j < G; ++j) {
+            const int mf = g + j;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                u32x4 o;
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    const int nf = 2 * h + k;
+                    f32x4 v = acc[nf][mf];
+                    if (LN) v = rstd[j] * (v - mean[j] * cs4[nf]);
+                    v += add4[nf];
+                    if (RES) {
+                        const unsigned r0 = res4[j][RES ? h : 0][2 * k], r1 = res4[j][RES ? h : 0][2 * k + 1];
+                        v += f32x4{hv_bf2f((bf16_t)(r0 & 0xffff)), hv_bf2f((bf16_t)(r0 >> 16)), hv_bf2f((bf16_t)(r1 & 0xffff)),
+                                   hv_bf2f((bf16_t)(r1 >> 16))};
+                    }
+                    o[2 * k] = hv_pack2(v[0], v[1]);
+                    o[2 * k + 1] = hv_pack2(v[2], v[3]);
+                }
+                outp[mf][h] = o;
+            }
+        }
+#if !defined(HV_EMU) && HV_GEMM_EPI_SB
+        __builtin_amdgcn_sched_barrier(0);  // ... and the next group's loads are not hoisted over it (register budget)
+#endif
+    }
+    HV_TRACE(12);
+#ifndef HV_EMU
+    // (pinned results + "no load outstanding": see hv_gemm_epilogue_fast)
+#pragma unroll
+    for (int mf = 0; mf < NMF; ++mf)
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+            asm volatile("" : "+v"(outp[mf][h][0]), "+v"(outp[mf][h][1]), "+v"(outp[mf][h][2]), "+v"(outp[mf][h][3]));
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+#endif
+    char* const yb = reinterpret_cast<char*>(p.Y);
+#pragma unroll
+    for (int mf = 0; mf < NMF; ++mf) {
+        const int m = m_base + 16 * mf + r16;
+        if (m >= p.M) continue;
+        const unsigned yo = (unsigned)m * (unsigned)p.ldy * 2u;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int n = n_base + 32 * h + 8 * quad;
+            if (n >= p.N) continue;
+            hv_st16(yb + (yo + 2u * (unsigned)n), outp[mf][h]);
+        }
+    }
+    HV_TRACE(13);
+    HV_TRACE(11);
+}
+
+// LayerNorm fold + GEGLU under hv_perm_row_geglu: fragments (0, 1) = h, g of output channels n_base / 2 + 8 quad + 0..3,
+// fragments (2, 3) = h, g of the next four.  N % 32 == 0 (checked by hv_gemm_launch for every GEGLU problem).
+template <int NMF>
+HV_DEV void hv_gemm_epilogue_fast_perm_geglu(const HvGemmParams& p, f32x4 (&acc)[4][NMF], int m_base, int n_base, int r16, int quad,
+                                             const float* tab_row HV_TRACE_PARAM) {
+    constexpr int G = NMF < HV_GEMM_EPI_G ? NMF : HV_GEMM_EPI_G;
+    f32x4 add4[4], cs4[4];
+    auto ld4 = [&](const float* base, unsigned byte_ofs) __attribute__((always_inline)) {
+        return *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(base) + byte_ofs);
+    };
+    unsigned nb[4];  // packed column of the fragment's first row of this lane (4 consecutive packed columns follow)
+#pragma unroll
+    for (int nf = 0; nf < 4; ++nf) nb[nf] = 4u * (unsigned)min(n_base + hv_perm_row_geglu(nf, 4 * quad), p.N - 4);
+#pragma unroll
+    for (int nf = 0; nf < 4; ++nf) {
+        add4[nf] = p.bias != nullptr ? ld4(p.bias, nb[nf]) : f32x4{0.f, 0.f, 0.f, 0.f};
+        cs4[nf] = ld4(p.colsum, nb[nf]);
+    }
+    if (tab_row != nullptr) {
+        f32x4 t4[4];
+#pragma unroll
+        for (int nf = 0; nf < 4; ++nf) t4[nf] = ld4(tab_row, nb[nf]);
+#pragma unroll
+        for (int nf = 0; nf < 4; ++nf) add4[nf] += t4[nf];
+    }
+    u32x4 outp[NMF];
+#pragma unroll
+    for (int g = 0; g < NMF; g += G) {
+        float mean[G], rstd[G];
+#pragma unroll
+        for (int j = 0; j < G; ++j) {
+            const int mc = min(m_base + 16 * (g + j) + r16, p.M - 1);
+            mean[j] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(p.row_mean) + 4u * (unsigned)mc);
+            rstd[j] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(p.row_rstd) + 4u * (unsigned)mc);
+        }
+#if !defined(HV_EMU) && HV_GEMM_EPI_SB
+        __builtin_amdgcn_sched_barrier(0);
+#endif
+        if (g == 0) HV_TRACE(7);
+#pragma unroll
+        for (int j = 0; j < G; ++j) {
+            const int mf = g + j;
+            u32x4 o;
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                f32x4 h = rstd[j] * (acc[2 * k][mf] - mean[j] * cs4[2 * k]) + add4[2 * k];
+                const f32x4 gt = rstd[j] * (acc[2 * k + 1][mf] - mean[j] * cs4[2 * k + 1]) + add4[2 * k + 1];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) h[r] *= hv_gelu_fast(gt[r]);
+                o[2 * k] = hv_pack2(h[0], h[1]);
+                o[2 * k + 1] = hv_pack2(h[2], h[3]);
+            }
+            outp[mf] = o;
+        }
+#if !defined(HV_EMU) && HV_GEMM_EPI_SB
+        __builtin_amdgcn_sched_barrier(0);
+#endif
+    }
+    HV_TRACE(12);
+#ifndef HV_EMU
+#pragma unroll
+    for (int mf = 0; mf < NMF; ++mf) asm volatile("" : "+v"(outp[mf][0]), "+v"(outp[mf][1]), "+v"(outp[mf][2]), "+v"(outp[mf][3]));
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+#endif
+    char* const yb = reinterpret_cast<char*>(p.Y);
+    const int no = (n_base >> 1) + 8 * quad;  // output channel of the lane's first result
+#pragma unroll
+    for (int mf = 0; mf < NMF; ++mf) {
+        const int m = m_base + 16 * mf + r16;
+        if (m >= p.M || 2 * no >= p.N) continue;
+        hv_st16(yb + ((unsigned)m * (unsigned)p.ldy * 2u + 2u * (unsigned)no), outp[mf]);
+    }
+    HV_TRACE(13);
+    HV_TRACE(11);
+}
+
 template <int NMF>
 HV_DEV void hv_gemm_epilogue(const HvGemmParams& p, f32x4 (&acc)[4][NMF], int m_base, int n_base, int r16, int quad HV_TRACE_PARAM) {
     const bool lean = p.out_act == HV_ACT_NONE && !p.out_f32 && p.perm_p == 0;
@@ -399,7 +607,7 @@ static inline int hv_gemm_fast_form(const HvGemmParams& p, int rows_per_wave) {
     return res ? HV_FORM_RES : HV_FORM_PLAIN;
 }
 
-template <int NMF>
+template <int NMF, bool PERM = false>
 HV_DEV void hv_gemm_epilogue_form(int form, const HvGemmParams& p, f32x4 (&acc)[4][NMF], int m_base, int n_base, int r16,
                                   int quad HV_TRACE_PARAM) {
 #if !HV_GEMM_DEFER
@@ -413,6 +621,15 @@ HV_DEV void hv_gemm_epilogue_form(int form, const HvGemmParams& p, f32x4 (&acc)[
     const float* tab = nullptr;
     if (p.pe != nullptr) tab = p.pe + (long)((m_first / p.pe_period) % p.pe_frames) * p.N;
     else if (p.rowvec != nullptr) tab = p.rowvec + (long)(m_first / p.rowvec_period) * p.N;
+    if constexpr (PERM) {  // the launcher sends only the plain-output forms here
+        switch (form) {
+            case HV_FORM_LN_GEGLU: hv_gemm_epilogue_fast_perm_geglu<NMF>(p, acc, m_base, n_base, r16, quad, tab HV_TRACE_ARG); break;
+            case HV_FORM_LN: hv_gemm_epilogue_fast_perm<NMF, true, false>(p, acc, m_base, n_base, r16, quad, tab HV_TRACE_ARG); break;
+            case HV_FORM_RES: hv_gemm_epilogue_fast_perm<NMF, false, true>(p, acc, m_base, n_base, r16, quad, tab HV_TRACE_ARG); break;
+            default: hv_gemm_epilogue_fast_perm<NMF, false, false>(p, acc, m_base, n_base, r16, quad, tab HV_TRACE_ARG); break;
+        }
+        return;
+    }
     switch (form) {
         case HV_FORM_LN: hv_gemm_epilogue_fast<NMF, true, false, 0>(p, acc, m_base, n_base, r16, quad, tab HV_TRACE_ARG); break;
         case HV_FORM_LN_YT: hv_gemm_epilogue_fast<NMF, true, false, 1>(p, acc, m_base, n_base, r16, quad, tab HV_TRACE_ARG); break;
@@ -602,7 +819,8 @@ __global__ __launch_bounds__(256, 2) void hv_gemm_kernel(HvGemmParams p) {
 // Both are bit-identical to the round-2 one-burst loop (same MFMA order per accumulator; hardware-checked in
 // profiles/r03_hwcheck.txt), which is deleted together with the BK = 32 / 3-slot / contiguous-walk / L2-prefetch variants
 // that never won a same-box A/B.
-template <int BN, int NW, int BM, int PH>
+//   PERM: the permuted channel assignment of a wave's 64-channel block (hv_perm_row) for the plain-output forms.
+template <int BN, int NW, int BM, int PH, bool PERM = false>
 __global__ __launch_bounds__(NW * 64, 2) void hv_gemm_glds_kernel(HvGemmParams p, int gm, int form) {
     constexpr int BK = 64, NS = 2;
     constexpr int WAVES_N = BN / 64, WAVES_M = NW / WAVES_N;
@@ -702,7 +920,11 @@ __global__ __launch_bounds__(NW * 64, 2) void hv_gemm_glds_kernel(HvGemmParams p
             constexpr int q = decltype(Q)::value;
             const int j = wave + NW * q;
             const int n = min(i_n0 + RPI * j + sub, p.N - 1);
-            hv_pick4<q>(wo0, wo1, wo2, wo3) = ((unsigned)n * (unsigned)p.K + (unsigned)chunk_ofs_s(j, sub)) * 2u;
+            // source-side swizzle of the lane's 16-byte chunk: LDS chunk slot (lane % CPR) of tile row RPI j + sub holds
+            // the chunk whose index is slot ^ swizzle(row) -- the W tile's own swizzle under PERM
+            const int trow = RPI * j + sub;
+            const int wsw = PERM ? hv_wperm_swizzle(trow) : ((trow / RPB) % CPR);
+            hv_pick4<q>(wo0, wo1, wo2, wo3) = ((unsigned)n * (unsigned)p.K + (unsigned)(((lane & (CPR - 1)) ^ wsw) * 8)) * 2u;
         });
     };
     set_tile();
@@ -787,7 +1009,12 @@ __global__ __launch_bounds__(NW * 64, 2) void hv_gemm_glds_kernel(HvGemmParams p
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
-            for (int f = 0; f < 4; ++f) wf[kk][f] = hv_as_bf16x8(hv_ld16(ws + hv_swz<BK>(64 * wn + 16 * f + r16, kk * 4 + quad)));
+            for (int f = 0; f < 4; ++f) {
+                // PERM: the lane's W-tile row per fragment depends on the output form (wave-uniform, loop-invariant)
+                const int wrow = !PERM ? 16 * f + r16 : (form == HV_FORM_LN_GEGLU ? hv_perm_row_geglu(f, r16) : hv_perm_row(f, r16));
+                wf[kk][f] = hv_as_bf16x8(hv_ld16(ws + (PERM ? hv_swz_wperm(64 * wn + wrow, kk * 4 + quad)
+                                                            : hv_swz<BK>(64 * wn + wrow, kk * 4 + quad))));
+            }
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
             bf16x8 xf[HMF];
@@ -852,7 +1079,7 @@ __global__ __launch_bounds__(NW * 64, 2) void hv_gemm_glds_kernel(HvGemmParams p
             {
                 int m0, n0;
                 tile_origin(c_tile, m0, n0);
-                hv_gemm_epilogue_form<NMF>(form, p, acc, m0 + WTM * wm, n0 + 64 * wn, r16, quad HV_TRACE_ARG);
+                hv_gemm_epilogue_form<NMF, PERM>(form, p, acc, m0 + WTM * wm, n0 + 64 * wn, r16, quad HV_TRACE_ARG);
                 landed = 1;
             }
             c_tile += tstep;
@@ -870,6 +1097,7 @@ static int g_hv_gemm_max_grid = 512;  // tuning knob (hv_set_tuning): persistent
 //   2: 256 x 256 x 64 wherever its tile shape is legal (A/Bs), 3: 128 x 128 x 64 everywhere (A/Bs)
 //   0: the register-staged kernel for everything (A/Bs; also what problems outside the fast epilogue forms run on)
 static int g_hv_gemm_glds = 1;
+static int g_hv_gemm_perm = 1;  // tuning knob (hv_set_tuning key 6): 16-byte epilogue through the permuted channel assignment (A/B)
 
 static inline int hv_gemm_launch(const HvGemmParams& p, hipStream_t stream) {
     if (p.M <= 0 || p.N <= 0 || p.K <= 0) return -1;
@@ -907,16 +1135,31 @@ static inline int hv_gemm_launch(const HvGemmParams& p, hipStream_t stream) {
             int grid = ((t256 + 7) / 8) * 8;
             if (grid > 256) grid = 256;
             if (grid > g_hv_gemm_max_grid) grid = g_hv_gemm_max_grid;
-            hv_note("hv_gemm_glds_kernel<256,8,256,1> | %s", shape);
-            hv_launch(hv_gemm_glds_kernel<256, 8, 256, 1>, dim3(grid), dim3(512), stream, p, gm, form128);
+            const bool perm256 = g_hv_gemm_perm && p.N % 8 == 0 && (form128 == HV_FORM_RES || form128 == HV_FORM_PLAIN ||
+                                                                    form128 == HV_FORM_LN || form128 == HV_FORM_LN_GEGLU);
+            if (perm256) {
+                hv_note("hv_gemm_glds_kernel<256,8,256,1,perm> | %s", shape);
+                hv_launch(hv_gemm_glds_kernel<256, 8, 256, 1, true>, dim3(grid), dim3(512), stream, p, gm, form128);
+            } else {
+                hv_note("hv_gemm_glds_kernel<256,8,256,1> | %s", shape);
+                hv_launch(hv_gemm_glds_kernel<256, 8, 256, 1, false>, dim3(grid), dim3(512), stream, p, gm, form128);
+            }
             return 0;
         }
         const int tiles6 = ((p.M + 127) / 128) * (n128 / 128);
         int grid6 = ((tiles6 + 7) / 8) * 8;
         if (grid6 > 512) grid6 = 512;
         if (grid6 > g_hv_gemm_max_grid) grid6 = g_hv_gemm_max_grid;
-        hv_note("hv_gemm_glds_kernel<128,4,128,2> | %s", shape);
-        hv_launch(hv_gemm_glds_kernel<128, 4, 128, 2>, dim3(grid6), dim3(256), stream, p, gm, form64);
+        // plain bf16 outputs (plain / residual / LayerNorm fold) and GEGLU with N % 8 == 0: permuted channel assignment, 16-byte epilogue
+        const bool perm = g_hv_gemm_perm && p.N % 8 == 0 &&
+                          (form64 == HV_FORM_RES || form64 == HV_FORM_PLAIN || form64 == HV_FORM_LN || form64 == HV_FORM_LN_GEGLU);
+        if (perm) {
+            hv_note("hv_gemm_glds_kernel<128,4,128,2,perm> | %s", shape);
+            hv_launch(hv_gemm_glds_kernel<128, 4, 128, 2, true>, dim3(grid6), dim3(256), stream, p, gm, form64);
+        } else {
+            hv_note("hv_gemm_glds_kernel<128,4,128,2> | %s", shape);
+            hv_launch(hv_gemm_glds_kernel<128, 4, 128, 2, false>, dim3(grid6), dim3(256), stream, p, gm, form64);
+        }
         return 0;
     }
     const int tiles = ((p.N + 127) / 128) * ((p.M + 127) / 128);

@@ -24,7 +24,7 @@ from . import lib as hvlib
 from . import ops
 from .reference_control import ReferenceAttentionControl
 from .runner import FrameShard
-from .scheduler import get_context_scheduler
+from .scheduler import fused_step_coefficients, get_context_scheduler
 
 F32 = torch.float32
 BF16 = torch.bfloat16
@@ -229,7 +229,10 @@ class Pose2VideoPipeline:
         for c in windows:
             pose_w = pose_cond_tensor[:, :, c]
             pose_fea = self.pose_guider.forward_nhwc(pose_w)  # [(1 f), h, w, 320]
-            if camera_embedding is None or self.camera_pose_encoder is None:
+            if camera_embedding is not None and self.camera_pose_encoder is None:
+                raise ValueError("a camera embedding was passed to a pipeline built without camera_pose_encoder: it would be "
+                                 "dropped silently (pass camera_embedding=None for the Animate-Anyone mode)")
+            if camera_embedding is None:
                 feat = pose_fea  # pipeline_pose2vid.py (Animate-Anyone mode): pose feature only
             elif isinstance(camera_embedding, (tuple, list)):
                 K, c2w = camera_embedding
@@ -265,12 +268,12 @@ class Pose2VideoPipeline:
         do_cfg = guidance_scale > 1.0
         rep = 2 if do_cfg else 1
         sched = self.scheduler
-        if getattr(sched, "prediction_type", "v_prediction") != "v_prediction" or not hasattr(sched, "step_coefficients"):
-            # hv_cfg_ddim_step fuses the v-prediction DDIM update (inference_v2.yaml:24-33); anything else would
-            # silently follow a wrong trajectory
-            raise NotImplementedError("the fused CFG + DDIM step implements DDIMScheduler(prediction_type='v_prediction') only")
         sched.set_timesteps(num_inference_steps)
         timesteps = [int(t) for t in sched.timesteps.tolist()]
+        # hv_cfg_ddim_step fuses CFG with the DDIM update (eta = 0); its four coefficients cover v- and epsilon-prediction
+        # and are derived from the scheduler's alphas_cumprod -- this module's DDIMScheduler or a diffusers-style one
+        # (raises NotImplementedError for anything the fused step would follow wrongly)
+        step_coeffs = [fused_step_coefficients(sched, t, num_inference_steps) for t in timesteps]
         latents = latents.to(device=dev, dtype=F32).contiguous()
         if latents.ndim != 5 or latents.shape[0] != 1:
             # pack / accumulate / cfg_ddim size their buffers for one clip (rep = CFG halves only)
@@ -288,6 +291,15 @@ class Pose2VideoPipeline:
         if self.shard is not None and self.shard.window_groups > 1:
             # window-parallel: this rank's sub-group takes every G-th window of the step; the others contribute theirs
             # through the accumulator all-reduce
+            G = self.shard.window_groups
+            if G > len(windows):
+                raise ValueError(f"{G} window groups for {len(windows)} context windows per step: "
+                                 f"{G - len(windows)} sub-group(s) would only take part in the all-reduce")
+            if len(windows) % G:
+                import warnings
+
+                warnings.warn(f"{len(windows)} context windows per step do not split evenly over {G} window groups: "
+                              f"the step lasts as long as the group with {-(-len(windows) // G)} windows", stacklevel=2)
             windows = [c for i, c in enumerate(windows) if i % self.shard.window_groups == self.shard.window_group]
         plans = []  # per window: (frame index tensor of this rank, local frame count)
         for c in windows:
@@ -302,12 +314,14 @@ class Pose2VideoPipeline:
                 else camera_embedding.to(dev)
             conds.extend(self.build_conditioning(pose_cond_tensor.to(dev), cam, [c], f0, fl))
 
-        acc = torch.zeros(rep, C, F_, h, w, dtype=F32, device=dev)
-        counter = torch.zeros(F_, dtype=F32, device=dev)
+        # noise accumulator and per-frame window counter in ONE buffer: the sharded step all-reduces both with one collective
+        acc_cnt = torch.zeros(rep * C * F_ * h * w + F_, dtype=F32, device=dev)
+        acc = acc_cnt[:rep * C * F_ * h * w].view(rep, C, F_, h, w)
+        counter = acc_cnt[rep * C * F_ * h * w:]
         t_dev = torch.zeros(rep, dtype=F32, device=dev)
         coeffs = torch.zeros(5, dtype=F32, device=dev)
         t_table = torch.tensor(timesteps, dtype=F32, device=dev)
-        c_table = torch.tensor([[guidance_scale, *sched.step_coefficients(t)] for t in timesteps], dtype=F32, device=dev)
+        c_table = torch.tensor([[guidance_scale, *c] for c in step_coeffs], dtype=F32, device=dev)
         x_in = [eng.ws.get(f"pipe_x_in_{i}", (rep * fl, h, w, 32)) for i, (_, fl, _) in enumerate(plans)]
         for x in x_in:
             x.zero_()
@@ -319,8 +333,7 @@ class Pose2VideoPipeline:
                 y = eng.forward_nhwc(xi, t_dev, cond, B=rep, F=fl)
                 ops.accumulate_window(L, st, y, rep, C, frames, acc, counter)
             if self.shard is not None and (world > 1 or self.shard.window_groups > 1):
-                self.shard.all_reduce(acc)
-                self.shard.all_reduce(counter)
+                self.shard.all_reduce(acc_cnt)
             ops.cfg_ddim_step(L, st, latents, acc, counter, rep, coeffs)
 
         graph = None

@@ -75,6 +75,32 @@ class FrameShard:
         # 7/8 of its own q|k|v and gets its output back: 1.5 GB per rank and step at config #4), "allgather" replicates
         # K/V of all frames on every rank (6.0 GB); SURVEY.md section 8(e)
         self.exchange = os.environ.get("HUMANVID_TEMPORAL_EXCHANGE", "alltoall")
+        # diagnostics for the scaling runs (bench.py --gpus N): with `measure` on, every collective is counted with the bytes
+        # this rank sends and bracketed by two events on the compute stream -- the kernels behind a collective wait for
+        # it, so the event distance is the exchange time the step is EXPOSED to (nothing overlaps it yet)
+        self.measure = False
+        self.stats = dict(collectives=0, bytes_sent=0, events=[])
+
+    def _timed(self, nbytes: int, fn):
+        if not self.measure:
+            return fn()
+        self.stats["collectives"] += 1
+        self.stats["bytes_sent"] += int(nbytes)
+        if torch.cuda.is_available():
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            out = fn()
+            e1.record()
+            self.stats["events"].append((e0, e1))
+            return out
+        return fn()
+
+    def reset_stats(self):
+        self.stats = dict(collectives=0, bytes_sent=0, events=[])
+
+    def exposed_ms(self) -> float:
+        """sum of the event distances around the measured collectives (call after a stream synchronisation)"""
+        return float(sum(a.elapsed_time(b) for a, b in self.stats["events"]))
 
     def all_gather(self, out: torch.Tensor, inp: torch.Tensor):
         if self.recorder is not None:
@@ -89,12 +115,14 @@ class FrameShard:
     def all_to_all(self, out: torch.Tensor, inp: torch.Tensor):
         """equal-split all-to-all of flat, contiguous buffers: chunk r of `inp` goes to rank r, chunk s of `out` comes
         from rank s (runs immediately: callers wrap whole exchange closures with `deferred`)"""
+        sent = inp.numel() * inp.element_size() * (self.world - 1) // max(1, self.world)
         if self.staged and inp.device.type != "cpu":
-            host_in, host_out = inp.cpu(), torch.empty(out.numel(), dtype=inp.dtype)
-            self.dist.all_to_all_single(host_out, host_in.reshape(-1), group=self.group)
-            out.view(-1).copy_(host_out)
-            return
-        self.dist.all_to_all_single(out.view(-1), inp.view(-1), group=self.group)
+            def staged():
+                host_in, host_out = inp.cpu(), torch.empty(out.numel(), dtype=inp.dtype)
+                self.dist.all_to_all_single(host_out, host_in.reshape(-1), group=self.group)
+                out.view(-1).copy_(host_out)
+            return self._timed(sent, staged)
+        self._timed(sent, lambda: self.dist.all_to_all_single(out.view(-1), inp.view(-1), group=self.group))
 
     def deferred(self, fn):
         """run `fn` (host-side exchange code: torch copies + a collective) now, or -- while a step is being recorded
@@ -104,21 +132,26 @@ class FrameShard:
         return fn()
 
     def _all_gather(self, out: torch.Tensor, inp: torch.Tensor):
+        sent = inp.numel() * inp.element_size() * (self.world - 1)
         if self.staged and inp.device.type != "cpu":
-            host_out = torch.empty(out.numel(), dtype=inp.dtype)
-            self.dist.all_gather_into_tensor(host_out, inp.cpu().reshape(-1), group=self.group)
-            out.view(-1).copy_(host_out)
-            return
-        self.dist.all_gather_into_tensor(out, inp, group=self.group)
+            def staged():
+                host_out = torch.empty(out.numel(), dtype=inp.dtype)
+                self.dist.all_gather_into_tensor(host_out, inp.cpu().reshape(-1), group=self.group)
+                out.view(-1).copy_(host_out)
+            return self._timed(sent, staged)
+        self._timed(sent, lambda: self.dist.all_gather_into_tensor(out, inp, group=self.group))
 
     def _all_reduce(self, t: torch.Tensor):
         # over ALL ranks of the job: with window groups the other groups hold the other windows' contributions
+        total = self.dist.get_world_size(self.all_group)
+        sent = 2 * t.numel() * t.element_size() * (total - 1) // max(1, total)  # ring: reduce-scatter + all-gather
         if self.staged and t.device.type != "cpu":
-            h = t.cpu()
-            self.dist.all_reduce(h, group=self.all_group)
-            t.copy_(h)
-            return
-        self.dist.all_reduce(t, group=self.all_group)
+            def staged():
+                h = t.cpu()
+                self.dist.all_reduce(h, group=self.all_group)
+                t.copy_(h)
+            return self._timed(sent, staged)
+        self._timed(sent, lambda: self.dist.all_reduce(t, group=self.all_group))
 
     def frame_range(self, n_frames: int):
         if n_frames % self.world:

@@ -94,6 +94,50 @@ class DDIMScheduler:
         return DDIMSchedulerOutput(prev_sample=sap * x0 + s1ap * eps)
 
 
+def fused_step_coefficients(sched, timestep: int, num_inference_steps: int):
+    """(c1, c2, c3, c4) for hv_cfg_ddim_step, which evaluates  x0 = c1 x - c2 m,  eps = c1 m + c2 x,  x' = c3 x0 + c4 eps
+    on the guided model output m (eta = 0, no sample clipping):
+
+      v_prediction (inference_v2.yaml:24-33):  (sqrt a_t, sqrt(1 - a_t), sqrt a_prev, sqrt(1 - a_prev))
+      epsilon (inference_v1.yaml:18-23, diffusers' default):  x' = sqrt a_prev (x - sqrt(1 - a_t) m) / sqrt a_t
+          + sqrt(1 - a_prev) m is linear in (x, m) too:  (1, 0, sqrt a_prev / sqrt a_t,
+          sqrt(1 - a_prev) - sqrt a_prev sqrt(1 - a_t) / sqrt a_t)  -- the same kernel, no second code path.
+
+    `sched` is this module's DDIMScheduler or any object with diffusers' DDIMScheduler attributes (`alphas_cumprod`,
+    `final_alpha_cumprod`, and `prediction_type` / `num_train_timesteps` / `clip_sample` either directly or under `.config`),
+    which is what the reference's scripts construct (scripts/pose2vid.py:157-158)."""
+    def attr(name, default=None):
+        if hasattr(sched, name):
+            return getattr(sched, name)
+        cfg = getattr(sched, "config", None)
+        if cfg is not None:
+            return cfg[name] if isinstance(cfg, dict) and name in cfg else getattr(cfg, name, default)
+        return default
+
+    pred = attr("prediction_type", "epsilon")
+    if pred not in ("v_prediction", "epsilon"):
+        raise NotImplementedError(f"prediction_type {pred!r}: the fused CFG + DDIM step knows v_prediction and epsilon")
+    if attr("clip_sample", False) or attr("thresholding", False):
+        raise NotImplementedError("clip_sample / thresholding are not used by the CamAnimate configs and not fused")
+    abar = getattr(sched, "alphas_cumprod", None)
+    if abar is None:
+        raise NotImplementedError("the scheduler has no alphas_cumprod: a DDIM-style scheduler is required")
+    T = int(attr("num_train_timesteps", len(abar)))
+    t = int(timestep)
+    prev = t - T // int(num_inference_steps)
+    a = abar[t].float() if isinstance(abar, torch.Tensor) else torch.tensor(float(abar[t]))
+    final = getattr(sched, "final_alpha_cumprod", torch.tensor(1.0))
+    ap = (abar[prev] if prev >= 0 else final)
+    ap = ap.float() if isinstance(ap, torch.Tensor) else torch.tensor(float(ap))
+    sa, s1a, sap, s1ap = float(a.sqrt()), float((1 - a).sqrt()), float(ap.sqrt()), float((1 - ap).sqrt())
+    if pred == "v_prediction":
+        return sa, s1a, sap, s1ap
+    if sa == 0.0:
+        raise ValueError("epsilon prediction at a timestep with zero signal (alpha_bar = 0): the zero-terminal-SNR schedule "
+                         "needs prediction_type='v_prediction'")
+    return 1.0, 0.0, sap / sa, s1ap - sap * s1a / sa
+
+
 # ---------------------------------------------------------------------------------- context windows
 # Behavioural contract: /root/reference/src/pipelines/context.py:7-76 (pinned by tests/golden/context_windows.json, which
 # the reference's own generator produced).  Stated here as a closed-form window table:

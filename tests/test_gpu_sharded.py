@@ -74,8 +74,24 @@ def _worker(rank, world, port, out_path, backend="gloo", frames=4, window_groups
     eng.set_reference_banks({k: v.cuda() for k, v in banks.items()}, do_cfg=True)
     eng._banks_from_modules = lambda: None
     got = []
+
+    def diagnostics(one_step):  # what bench.py --gpus N reports per step: collectives, bytes sent, exposed exchange time
+        sh = pipe.shard
+        sh.reset_stats()
+        sh.measure = True
+        one_step()
+        torch.cuda.synchronize()
+        sh.measure = False
+        windows = -(-frames // max(1, context_frames - context_overlap)) if frames > context_frames else 1
+        assert sh.stats["collectives"] >= 1 and sh.stats["bytes_sent"] > 0 and sh.exposed_ms() > 0.0, sh.stats
+        if window_groups == 1:  # 2 exchanges per temporal attention block (all-to-all) or 1 (all-gather) + ONE all-reduce
+            per_attn = 2 if sh.exchange == "alltoall" else 1
+            n_attn = sum(1 for k in eng.w if k.endswith(".qkv.w") and "motion_modules" in k)
+            assert sh.stats["collectives"] == windows * per_attn * n_attn + 1, (sh.stats["collectives"], n_attn)
+
     pipe.denoise(lat.clone().cuda(), pose.cuda(), pl.cuda(), clip.cuda(), 4, 3.5, max_steps=3, context_frames=context_frames,
-                 context_overlap=context_overlap, callback=lambda i, t, x: got.append(x.detach().float().cpu().clone()))
+                 context_overlap=context_overlap, callback=lambda i, t, x: got.append(x.detach().float().cpu().clone()),
+                 after_loop=diagnostics)
     torch.cuda.synchronize()
     if rank == 0:
         torch.save(got, out_path)

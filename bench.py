@@ -98,6 +98,41 @@ def price_launch(key: str):
     return 0.0, 0.0
 
 
+def price_launch_rw(key: str):
+    """-> (algorithmic bytes read, written) of ONE launch: the split of price_launch's byte count that the per-shape counter
+    table (tools/pmc_by_shape.py) compares FETCH_SIZE / WRITE_SIZE with"""
+    kern, _, shape = key.partition(" | ")
+    a = _kv(shape) if shape else {}
+    _, total = price_launch(key)
+    if kern.startswith("hv_gemm"):
+        n_out = a["N"] // 2 if a["geglu"] else a["N"]
+        wr = a["M"] * n_out * (4.0 if a["f32"] else 2.0)
+    elif kern.startswith("hv_conv3x3"):
+        wr = 2.0 * a["n"] * a["Ho"] * a["Wo"] * a["Cout"]
+    elif kern.startswith("hv_attention_fp8_quant"):
+        wr = 2.0 * a["n"] * a["L"] * a["heads"] * int(kern.split("<")[1].split(">")[0])
+    elif kern.startswith("hv_attention") and "amax" not in kern:
+        wr = 2.0 * a["heads"] * a["D"] * a["n"] * a["Lq"]
+    elif kern.startswith("hv_temporal"):
+        wr = 2.0 * 8 * int(kern.split("<")[1].split(">")[0]) * a["B"] * a["P"] * a["Fq"]
+    else:
+        wr = 0.0
+    return total - wr, wr
+
+
+def csrc_digest() -> str:
+    """content hash of the kernel sources: what a committed counter summary is valid for (the GPU box has no .git)"""
+    import hashlib
+
+    h = hashlib.sha256()
+    d = os.path.join(REPO, "humanvid_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".h", ".hip", ".cpp")):
+            h.update(f.encode())
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
 def profile_step(run_step):
     """run_step() launches one denoising step eagerly on the current stream -> per-kernel-variant totals"""
     import ctypes
@@ -122,6 +157,8 @@ def profile_step(run_step):
         with open(os.environ["HV_PROFILE_DUMP"], "w") as fh:
             fh.write("launches\ttotal_ms\tkernel | shape\n" + buf.value.decode())
     for line in buf.value.decode().splitlines():
+        if line.startswith("#"):  # "#seq": launch order, for tools/pmc_by_shape.py
+            continue
         cnt, ms, key = line.split("\t", 2)
         fl, by = price_launch(key)
         k = kernels.setdefault(key.partition(" | ")[0], dict(launches=0, ms=0.0, flops=0.0, bytes=0.0))
@@ -143,13 +180,21 @@ def roofline_from_profile(kernels, traffic_file):
             "source": "hv_profile_begin/end: HIP events around every launch of one eagerly launched step after the timed "
                       "region (real epilogues, variants and multiplicities); shapes priced by bench.price_launch",
             "sum_of_kernel_ms_per_step": total_ms}
+    # roofline.traffic: HBM-side bytes per launch of the dominant kernel from the committed counter passes (PMC counters
+    # cannot be read inside the timed run).  A summary made from OTHER kernel sources is refused: the file carries the
+    # content hash of humanvid_amd/csrc it was collected with (tools/pmc_by_shape.py).
     if os.path.exists(traffic_file):
         t = json.load(open(traffic_file))
-        if t.get("kernel", "").replace(" ", "").startswith(name.replace(" ", "").rstrip(">")):
-            roof["traffic"] = t["bytes_per_launch"]
-            roof["traffic_detail"] = dict(t, note="PMC counters cannot be read inside the timed run: this is the committed "
-                                          "summary of the separate rocprofv3 --pmc passes named in `source`; STALE unless "
-                                          "re-collected at this commit (see `commit`)")
+        if t.get("csrc_digest") != csrc_digest():
+            roof["traffic_note"] = (f"refused {os.path.basename(traffic_file)}: collected with kernel sources "
+                                    f"{t.get('csrc_digest')}, this build is {csrc_digest()} (re-run tools/final_r03.sh)")
+        else:
+            k = t.get("kernels", {}).get(name)
+            if k is not None:
+                roof["traffic"] = k["fetch_bytes_per_launch"] + k["write_bytes_per_launch"]
+                roof["traffic_detail"] = dict(k, source=t.get("source"), corrections=t.get("corrections"),
+                                              csrc_digest=t["csrc_digest"])
+                roof["traffic_by_shape"] = [s_ for s_ in t.get("shapes", []) if s_["key"].startswith(name + " | ")]
     table = []
     for n, k in sorted(kernels.items(), key=lambda kv: -kv[1]["ms"])[:10]:
         table.append({"kernel": n, "launches": k["launches"], "ms": round(k["ms"], 3),
@@ -390,7 +435,7 @@ def main():
         if exchange is not None:
             out["exchange"] = exchange
         if "kernels" in prof:
-            roof, table = roofline_from_profile(prof["kernels"], os.path.join(REPO, "profiles", "r02_pmc_traffic.json"))
+            roof, table = roofline_from_profile(prof["kernels"], os.path.join(REPO, "profiles", "r03_pmc_traffic.json"))
             out["roofline"] = roof
             out["kernels"] = table
         if world == 1 and not args.no_cpu_baseline:

@@ -230,6 +230,7 @@ int hv_profile_end(char* out, int capacity) {
         std::vector<std::string> keys;
         std::vector<double> ms;
         std::vector<int> cnt;
+        std::string seq;  // launch order as indices into `keys` (tools/pmc_by_shape.py lines rocprofv3 dispatches up with it)
         for (auto& en : pr->entries) {
             float t = 0.f;
             (void)hipEventSynchronize(en.e1);
@@ -246,6 +247,7 @@ int hv_profile_end(char* out, int capacity) {
             }
             ms[i] += t;
             cnt[i] += 1;
+            seq += (seq.empty() ? "" : ",") + std::to_string(i);
         }
         delete pr;
         delete g_hv_prof_text;
@@ -255,6 +257,7 @@ int hv_profile_end(char* out, int capacity) {
             snprintf(line, sizeof(line), "%d\t%.6f\t%s\n", cnt[i], ms[i], keys[i].c_str());
             *g_hv_prof_text += line;
         }
+        *g_hv_prof_text += "#seq\t" + seq + "\n";
     }
     const int need = (int)g_hv_prof_text->size() + 1;
     if (out && capacity >= need) {

@@ -269,7 +269,8 @@ int hv_cmdlist_destroy(void* list);
 /* ---- launch profile -----------------------------------------------------------------------------
  * Between hv_profile_begin() and hv_profile_end() every kernel launch of this thread is bracketed by two HIP events
  * on its own stream.  hv_profile_end() waits for them and writes one text line per distinct "kernel variant | shape"
- * key: "<launches>\t<total milliseconds>\t<key>\n".  Returns the buffer size needed, negative on error.  When the
+ * key: "<launches>\t<total milliseconds>\t<key>\n", followed by one line "#seq\t<i>,<i>,..." = the launch order as
+ * 0-based indices into those lines.  Returns the buffer size needed, negative on error.  When the
  * size exceeds `capacity` (or out == NULL, capacity >= 0: a size query) nothing is written, recording has stopped and the
  * text is kept: call again with a buffer of the returned size to collect it (out == NULL with capacity < 0 drops it).  bench.py builds its roofline block from one profiled,
  * eagerly launched denoising step (the real epilogues / multiplicities / variants of the step). */

@@ -1,0 +1,27 @@
+#!/bin/bash
+# The round's closing measurement, all at the built tree that is shipped (run LAST, with >= 12 GPU-minutes left):
+#   gpurun --timeout 1500 -- 'bash tools/final_r03.sh'
+#  1. the -m gpu suite, serially          -> gpurun_out/r03_final_pytest.txt
+#  2. the bench line (+ step profile)     -> gpurun_out/r03_bench_line_final.json, r03_step_profile_final.tsv
+#  3. rocprofv3 --kernel-trace --stats    -> gpurun_out/r03_final_kernel_stats.csv
+#  4. three counter passes, per shape     -> gpurun_out/r03_pmc_traffic.json
+# Copy 2-4 into profiles/ and commit them with the same tree.
+mkdir -p gpurun_out
+export TMPDIR=/tmp
+if [ "$1" != "--no-tests" ]; then
+  timeout 900 python -m pytest tests -m gpu -q -x > gpurun_out/r03_final_pytest.txt 2>&1
+  tail -3 gpurun_out/r03_final_pytest.txt
+fi
+HV_PROFILE_DUMP=gpurun_out/r03_step_profile_final.tsv timeout 400 python bench.py > gpurun_out/r03_bench_line_final.json 2> gpurun_out/r03_bench_final.err
+tail -c 300 gpurun_out/r03_bench_final.err; cut -c1-400 gpurun_out/r03_bench_line_final.json
+bash tools/prof_bench.sh r03_final --no-profile | head -12
+REPO=$(pwd)
+cd /tmp
+CMD="python $REPO/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-profile"
+for pass in "fetch FETCH_SIZE" "write WRITE_SIZE" "mfma SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE"; do
+  set -- $pass; tag=$1; shift
+  rm -rf /tmp/pmc_$tag
+  timeout 400 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d /tmp/pmc_$tag -- $CMD < /dev/null > $REPO/gpurun_out/r03_pmc_$tag.log 2>&1
+done
+cd $REPO
+python tools/pmc_by_shape.py gpurun_out/r03_step_profile_final.tsv gpurun_out/r03_pmc_traffic.json /tmp/pmc_fetch /tmp/pmc_write /tmp/pmc_mfma 2>&1 | tail -22

@@ -275,7 +275,9 @@ def main():
     ap.add_argument("--height", type=int, default=None)
     ap.add_argument("--width", type=int, default=None)
     ap.add_argument("--fp8-attention", type=int, default=None, choices=[0, 1],
-                    help="spatial attention on the fp8 (e4m3) MFMA; default: 1 for --config 5 (BASELINE.json configs[4]), else 0")
+                    help="spatial attention on the fp8 (e4m3) MFMA (what BASELINE.json configs[4] names); default 0 for every "
+                         "config: on gfx950 the non-scaled fp8 MFMA runs at the bf16 rate and the kernel pays an extra scaling "
+                         "multiply per score, so it is a precision / footprint option, not the fast path (DESIGN.md section 3)")
     ap.add_argument("--window-groups", type=int, default=1,
                     help="N > 1 GPUs: split the ranks into this many groups that take different context windows of a step "
                          "(window-parallel x frame-shard; clips with several windows per step, e.g. --config 5)")
@@ -285,7 +287,7 @@ def main():
     args = ap.parse_args()
 
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    fp8_attn = (args.config == 5) if args.fp8_attention is None else bool(args.fp8_attention)
+    fp8_attn = bool(args.fp8_attention)
     os.environ["HUMANVID_ATTENTION_FP8"] = "1" if fp8_attn else "0"  # read by UNet3DEngine at construction
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         _self_launch(args)

@@ -40,6 +40,7 @@ class GemmParams(_S):
         ("residual", P), ("ldr", L),
         ("geglu", I), ("out_act", I),
         ("perm_x", I), ("perm_y", I), ("perm_p", I),
+        ("gn_part", P), ("gn_rows_per_image", I),
     ]
 
 
@@ -51,6 +52,7 @@ class Conv3x3Params(_S):
         ("pro_scale", P), ("pro_shift", P), ("pro_act", I),
         ("bias", P), ("rowvec", P), ("images_per_rowvec", I), ("rowvec_ld", L),
         ("residual", P), ("residual_images", I), ("out_act", I),
+        ("gn_part", P),
     ]
 
 
@@ -60,6 +62,14 @@ class GroupNormParams(_S):
         ("n_images", I), ("pixels", I), ("groups", I), ("eps", F),
         ("gamma", P), ("beta", P), ("partial", P), ("splits", I),
         ("scale", P), ("shift", P),
+    ]
+
+
+class GnPartsParams(_S):
+    _fields_ = [
+        ("part1", P), ("parts1", I), ("C1", I), ("part2", P), ("parts2", I), ("C2", I),
+        ("n_images", I), ("pixels", I), ("groups", I), ("eps", F),
+        ("gamma", P), ("beta", P), ("scale", P), ("shift", P),
     ]
 
 
@@ -82,7 +92,7 @@ class TemporalAttentionParams(_S):
     ]
 
 
-_STRUCTS = (GemmParams, Conv3x3Params, GroupNormParams, AttentionParams, TemporalAttentionParams)
+_STRUCTS = (GemmParams, Conv3x3Params, GroupNormParams, AttentionParams, TemporalAttentionParams, GnPartsParams)
 
 # every symbol include/humanvid_hip.h declares: name -> (restype, argtypes)
 PROTOTYPES = {
@@ -92,6 +102,9 @@ PROTOTYPES = {
     "hv_gemm": (I, [C.POINTER(GemmParams), P]),
     "hv_conv3x3": (I, [C.POINTER(Conv3x3Params), P]),
     "hv_groupnorm_affine": (I, [C.POINTER(GroupNormParams), P]),
+    "hv_gemm_gn_parts": (I, [C.POINTER(GemmParams)]),
+    "hv_conv3x3_gn_parts": (I, [C.POINTER(Conv3x3Params)]),
+    "hv_groupnorm_from_parts": (I, [C.POINTER(GnPartsParams), P]),
     "hv_layernorm_stats": (I, [P, L, I, I, F, P, P, P]),
     "hv_attention": (I, [C.POINTER(AttentionParams), P]),
     "hv_attention_fp8_quantize": (I, [P, L, P, L, I, I, I, I, P, P, P, P, L, P, L, I, P]),

@@ -33,12 +33,12 @@ static int hv_check_launch(const char* what) {
 extern "C" {
 
 const char* hv_last_error(void) { return g_err; }
-int hv_abi_version(void) { return 1; }
+int hv_abi_version(void) { return 2; }  // 2: gn_part fields, hv_groupnorm_from_parts (round 3)
 
 int hv_struct_sizes(int* out, int capacity) {
     const int s[] = {(int)sizeof(hv_gemm_params),      (int)sizeof(hv_conv3x3_params),
                      (int)sizeof(hv_groupnorm_params), (int)sizeof(hv_attention_params),
-                     (int)sizeof(hv_temporal_attention_params)};
+                     (int)sizeof(hv_temporal_attention_params), (int)sizeof(hv_gn_parts_params)};
     const int n = (int)(sizeof(s) / sizeof(s[0]));
     for (int i = 0; i < n && i < capacity; ++i) out[i] = s[i];
     return n;
@@ -47,7 +47,7 @@ int hv_struct_sizes(int* out, int capacity) {
 int hv_gemm(const hv_gemm_params* p, void* stream) {
     if (!p || !p->X || !p->W || !p->Y) return hv_fail(HV_EINVAL, "hv_gemm: null operand");
     if (hvk_gemm(*p, (hipStream_t)stream) != 0)
-        return hv_fail(HV_EINVAL, "hv_gemm: need K % 64 == 0, N % 4 == 0 (geglu: N % 32 == 0)");
+        return hv_fail(HV_EINVAL, "hv_gemm: need K % 64 == 0, N % 4 == 0 (geglu: N % 32 == 0); gn_part only where hv_gemm_gn_parts() > 0");
     return hv_check_launch("hv_gemm");
 }
 
@@ -63,6 +63,15 @@ int hv_groupnorm_affine(const hv_groupnorm_params* p, void* stream) {
     if (hvk_groupnorm(*p, (hipStream_t)stream) != 0)
         return hv_fail(HV_EINVAL, "hv_groupnorm: need C1 % 8 == 0, C2 % 8 == 0, C % groups == 0, C <= 4096");
     return hv_check_launch("hv_groupnorm_affine");
+}
+
+int hv_gemm_gn_parts(const hv_gemm_params* p) { return p ? hvk_gemm_gn_parts(*p) : 0; }
+int hv_conv3x3_gn_parts(const hv_conv3x3_params* p) { return p ? hvk_conv3x3_gn_parts(*p) : 0; }
+int hv_groupnorm_from_parts(const hv_gn_parts_params* p, void* stream) {
+    if (!p || !p->part1 || !p->scale || !p->shift || !p->gamma || !p->beta) return hv_fail(HV_EINVAL, "hv_groupnorm_from_parts: null");
+    if (hvk_gn_from_parts(*p, (hipStream_t)stream) != 0)
+        return hv_fail(HV_EINVAL, "hv_groupnorm_from_parts: need (C1 + C2) % groups == 0, parts >= 1, pixels >= 1");
+    return hv_check_launch("hv_groupnorm_from_parts");
 }
 
 int hv_layernorm_stats(const uint16_t* X, long ldx, int M, int C, float eps, float* mean, float* rstd,

@@ -163,7 +163,57 @@ __global__ __launch_bounds__(256, (HvAttnOcc<D, QT>::value)) void hv_attention_k
         krow[i] = id / CPRK, kcol[i] = (id % CPRK) * 16 + sub;
         vrow[i] = id >> 3, vcol[i] = (id & 7) * 16 + sub;
     }
-    auto load_tile = [&](int ti) {
+    // Tile source state, advanced one 64-key tile per load: wave-uniform base pointers of the next K / V^T tile (SGPR pairs:
+    // the loads take them as scalar bases, the per-lane part is a 32-bit offset register) and the per-lane offsets of the
+    // CURRENT source tensor (own keys, then the bank: other row strides -> recomputed once at the switch).  Round 2
+    // re-derived all of this from the kernel arguments in every tile: ~40 scalar instructions and four s_load round trips
+    // (whose lgkmcnt wait also waits for the wave's LDS traffic) per tile.
+    const char* kbase = nullptr;
+    const char* vbase = nullptr;
+    unsigned kstep = 0;  // bytes from one K tile to the next (64 rows)
+    int src_kv0 = 0, src_L = 0;
+    unsigned koff[G::FIT + 1], voff[G::FIT + 1];
+    auto set_source = [&](bool bank) {
+        const unsigned rowbase = bank ? (unsigned)sel * (unsigned)p.L2 : (unsigned)img * (unsigned)p.L1;
+        const unsigned ldk2 = (unsigned)(bank ? p.ldk2 : p.ldk) * 2u, ldv2 = (unsigned)(bank ? p.ldvt2 : p.ldvt) * 2u;  // bytes
+        kbase = reinterpret_cast<const char*>(bank ? p.K2 : p.K) + ((size_t)rowbase * ldk2 + (size_t)(head * D) * 2u);
+        vbase = reinterpret_cast<const char*>(bank ? p.Vt2 : p.Vt) + ((size_t)(head * D) * ldv2 + (size_t)rowbase * 2u);
+        kstep = 64u * ldk2;
+        src_kv0 = 0;
+        src_L = bank ? p.L2 : p.L1;
+#pragma unroll
+        for (int i = 0; i <= G::FIT; ++i) {
+            koff[i] = hv_umul24(krow[i], ldk2) + (unsigned)kcol[i];
+            voff[i] = hv_umul24(vrow[i], ldv2) + (unsigned)vcol[i];
+        }
+    };
+    auto load_tile_inc = [&](int ti) {
+        if (ti == T1) set_source(true);  // (rare, wave-uniform) the bank follows the own keys
+        const int kv0 = src_kv0;
+        const int L = src_L;
+#pragma unroll
+        for (int i = 0; i < G::FIT; ++i) {
+            u32x4 kv = {0u, 0u, 0u, 0u}, vv = {0u, 0u, 0u, 0u};
+            if (!MASK || kv0 + krow[i] < L) kv = hv_ld16(kbase + koff[i]);
+            if (!MASK || kv0 + (vcol[i] >> 1) < L) vv = hv_ld16(vbase + voff[i]);
+            kreg[i] = kv, vreg[i] = vv;
+        }
+        if (G::PB) {
+            kpc = vpc = u32x2{0u, 0u};
+            if (!MASK || kv0 + krow[G::FIT] < L) {
+                if (G::PB == 8) kpc = hv_ld8(kbase + koff[G::FIT]);
+                else kpc[0] = *reinterpret_cast<const unsigned*>(kbase + koff[G::FIT]);
+            }
+            if (!MASK || kv0 + (vcol[G::FIT] >> 1) < L) {  // (pieces never straddle the 8-key granule of the MASK contract)
+                if (G::PB == 8) vpc = hv_ld8(vbase + voff[G::FIT]);
+                else vpc[0] = *reinterpret_cast<const unsigned*>(vbase + voff[G::FIT]);
+            }
+        }
+        kbase += kstep;
+        vbase += 128;
+        src_kv0 += 64;
+    };
+    auto load_tile_abs = [&](int ti) {  // d = 80 / 160: addresses from the tile index (measured faster there than the running pointers)
         const bool bank = ti >= T1;
         const int kv0 = (bank ? ti - T1 : ti) * 64;
         const int L = bank ? p.L2 : p.L1;
@@ -194,6 +244,11 @@ __global__ __launch_bounds__(256, (HvAttnOcc<D, QT>::value)) void hv_attention_k
                 else vpc[0] = *reinterpret_cast<const unsigned*>(va);
             }
         }
+    };
+    constexpr bool INC = D == 40;  // running-pointer loads: -2.8 % at d = 40, +12 % at d = 80 (same-box A/B, round 3)
+    auto load_tile = [&](int ti) {
+        if constexpr (INC) load_tile_inc(ti);
+        else load_tile_abs(ti);
     };
     // key kv = 32a + 8b + 4c' + e  ->  LDS row 32a + 16c' + 4b + e
     auto key_row = [](int r) { return (r & ~0x1c) | ((r & 4) << 2) | ((r & 0x18) >> 1); };
@@ -230,6 +285,7 @@ __global__ __launch_bounds__(256, (HvAttnOcc<D, QT>::value)) void hv_attention_k
 #ifdef HV_GEMM_TRACE
     int hv_ti = 0;
 #endif
+    if (INC) set_source(false);
     load_tile(0);
     __syncthreads();  // LDS initialisation complete before the first tile store
     for (int ti = 0; ti < ntiles; ++ti) {

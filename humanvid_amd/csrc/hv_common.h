@@ -67,6 +67,23 @@ HV_DEV unsigned hv_umul24(unsigned a, unsigned b) {
 #endif
 }
 
+// sum over the 16 lanes of a DPP row (lanes with equal lane >> 4), returned in every lane: four v_add_f32 with DPP operands
+// (quad_perm [1,0,3,2], quad_perm [2,3,0,1], row_half_mirror, row_mirror) -- no LDS round trips (__shfl_xor is ds_bpermute)
+HV_DEV float hv_row16_sum(float x) {
+#ifndef HV_EMU
+    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0xB1, 0xf, 0xf, true));
+    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x4E, 0xf, 0xf, true));
+    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x141, 0xf, 0xf, true));
+    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x140, 0xf, 0xf, true));
+#else
+    x += __shfl_xor(x, 1);
+    x += __shfl_xor(x, 2);
+    x += __shfl_xor(x, 4);
+    x += __shfl_xor(x, 8);
+#endif
+    return x;
+}
+
 HV_DEV float hv_silu(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504089f * x)); }
 
 HV_DEV float hv_gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }

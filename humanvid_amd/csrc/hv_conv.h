@@ -301,49 +301,63 @@ __global__ __launch_bounds__(2 * 64 * (NPIX / WPX), (WPX == 128 ? 2 : 1)) void h
         });
     }
 
-    // ---- epilogue.  Loads are batched (all bias / time-embedding vectors, then all residual fragments of
-    // a pixel row) before their first use: see the note on hv_gemm_epilogue.
+    // ---- epilogue, one 16-channel fragment column (nf) at a time: its bias / time-embedding vector, the residual fragments
+    // of all pixel rows (loads batched before their first use: see the note on hv_gemm_epilogue), arithmetic + stores, and --
+    // optional, p.gn_part -- the GroupNorm partial statistics of what was stored: per channel the sum and the sum of squares
+    // over this wave's valid pixels, in-lane over the pixel fragments, then over the 16 lanes of the DPP row.  (Column-major
+    // order keeps eight statistics registers live instead of 32: the row-major form of this epilogue with the statistics
+    // came out at 304 registers.)
     const float* rv = p.rowvec ? p.rowvec + (long)(img / p.images_per_rowvec) * p.rowvec_ld : nullptr;
     const int rimg = p.residual ? (p.residual_images > 0 ? img % p.residual_images : img) : 0;
-    f32x4 add4[4];
+    const int gn_parts = tiles_y * tiles_x * WM;
+    float* const gn_dst = p.gn_part ? p.gn_part + ((long)img * gn_parts + ((y0 / TH) * tiles_x + x0 / TW) * WM + wm) * p.Cout * 2
+                                    : nullptr;
 #pragma unroll
     for (int nf = 0; nf < 4; ++nf) {
         const int n = n0 + 64 * wn + 16 * nf + 4 * quad;
-        f32x4 a = {0.f, 0.f, 0.f, 0.f};
-        if (n < p.Cout) {
-            if (p.bias) a += *reinterpret_cast<const f32x4*>(p.bias + n);
-            if (rv) a += *reinterpret_cast<const f32x4*>(rv + n);
-        }
-        add4[nf] = a;
-    }
+        if (n >= p.Cout) continue;
+        f32x4 add = {0.f, 0.f, 0.f, 0.f};
+        if (p.bias) add += *reinterpret_cast<const f32x4*>(p.bias + n);
+        if (rv) add += *reinterpret_cast<const f32x4*>(rv + n);
+        u32x2 res2[NMF];
+        long opix[NMF];
 #pragma unroll
-    for (int mf = 0; mf < NMF; ++mf) {
-        const int opx = WPX * wm + 16 * mf + r16;  // recomputed: py / px need not stay live through the k-loop
-        const int oy = y0 + opx / TW, ox = x0 + opx % TW;
-        if (oy >= p.Ho || ox >= p.Wo) continue;
-        const long opix = (long)(img * p.Ho + oy) * p.Wo + ox;
-        const long rpix = (long)(rimg * p.Ho + oy) * p.Wo + ox;
-        u32x2 res2[4];
-#pragma unroll
-        for (int nf = 0; nf < 4; ++nf) {
-            const int n = n0 + 64 * wn + 16 * nf + 4 * quad;
+        for (int mf = 0; mf < NMF; ++mf) {
+            const int opx = WPX * wm + 16 * mf + r16;  // recomputed: py / px need not stay live through the k-loop
+            const int oy = y0 + opx / TW, ox = x0 + opx % TW;
+            const bool valid = oy < p.Ho && ox < p.Wo;
+            opix[mf] = valid ? (long)(img * p.Ho + oy) * p.Wo + ox : -1;
             u32x2 r = {0u, 0u};
-            if (p.residual && n < p.Cout) r = hv_ld8(p.residual + rpix * p.Cout + n);
-            res2[nf] = r;
+            if (p.residual && valid) r = hv_ld8(p.residual + ((long)(rimg * p.Ho + oy) * p.Wo + ox) * p.Cout + n);
+            res2[mf] = r;
         }
+        f32x4 gs = {0.f, 0.f, 0.f, 0.f}, gq = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int nf = 0; nf < 4; ++nf) {
-            const int n = n0 + 64 * wn + 16 * nf + 4 * quad;
-            if (n >= p.Cout) continue;
-            f32x4 v = acc[nf][mf] + add4[nf];
-            v[0] += hv_bf2f((bf16_t)(res2[nf][0] & 0xffff));
-            v[1] += hv_bf2f((bf16_t)(res2[nf][0] >> 16));
-            v[2] += hv_bf2f((bf16_t)(res2[nf][1] & 0xffff));
-            v[3] += hv_bf2f((bf16_t)(res2[nf][1] >> 16));
+        for (int mf = 0; mf < NMF; ++mf) {
+            if (opix[mf] < 0) continue;
+            f32x4 v = acc[nf][mf] + add;
+            v[0] += hv_bf2f((bf16_t)(res2[mf][0] & 0xffff));
+            v[1] += hv_bf2f((bf16_t)(res2[mf][0] >> 16));
+            v[2] += hv_bf2f((bf16_t)(res2[mf][1] & 0xffff));
+            v[3] += hv_bf2f((bf16_t)(res2[mf][1] >> 16));
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[r] = hv_act(v[r], p.out_act);
             u32x2 o = {hv_pack2(v[0], v[1]), hv_pack2(v[2], v[3])};
-            hv_st8(p.Y + opix * p.Cout + n, o);
+            hv_st8(p.Y + opix[mf] * p.Cout + n, o);
+            gs += v;
+            gq += v * v;
+        }
+        if (gn_dst != nullptr) {  // (wave-uniform)
+            f32x4 a, b;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                a[e] = hv_row16_sum(gs[e]);
+                b[e] = hv_row16_sum(gq[e]);
+            }
+            if (r16 == 0) {  // channels n .. n+3: {sum, sumsq} interleaved
+                *reinterpret_cast<f32x4*>(gn_dst + 2 * n) = f32x4{a[0], b[0], a[1], b[1]};
+                *reinterpret_cast<f32x4*>(gn_dst + 2 * n + 4) = f32x4{a[2], b[2], a[3], b[3]};
+            }
         }
     }
 }
@@ -365,6 +379,23 @@ static inline void hv_conv3x3_launch_t(const hv_conv3x3_params& p, hipStream_t s
         hv_launch(hv_conv3x3_kernel<TW, MODE, true, NPIX, WPX, CK>, dim3(grid), dim3(NT), stream, p);
     else if constexpr (CK == 32)
         hv_launch(hv_conv3x3_kernel<TW, MODE, false, NPIX, WPX, CK>, dim3(grid), dim3(NT), stream, p);
+}
+
+// (tile rows, tile columns, pixel halves per tile) of the kernel hv_conv3x3_launch selects for this problem: the layout of
+// gn_part is [n_images][tiles_y * tiles_x * WM][Cout][2]
+static inline void hv_conv3x3_tile_shape(const hv_conv3x3_params& p, int& TH, int& TW, int& WM) {
+    const bool narrow = p.Wo <= 8;
+    const bool big = g_hv_conv_big && !narrow && p.Ho >= 16 && p.mode == HV_CONV_UP2;
+    TW = narrow ? 8 : 16;
+    const int npix = big ? 256 : 128;
+    TH = npix / TW;
+    WM = npix / 64;
+}
+static inline int hv_conv3x3_gn_parts_of(const hv_conv3x3_params& p) {
+    if (p.Cout % 4 != 0 || p.Ho <= 0 || p.Wo <= 0) return 0;
+    int TH, TW, WM;
+    hv_conv3x3_tile_shape(p, TH, TW, WM);
+    return ((p.Ho + TH - 1) / TH) * ((p.Wo + TW - 1) / TW) * WM;
 }
 
 static inline int hv_conv3x3_launch(const hv_conv3x3_params& p, hipStream_t stream) {

@@ -394,7 +394,9 @@ HV_DEV void hv_gemm_epilogue_fast(const HvGemmParams& p, f32x4 (&acc)[4][NMF], i
 
 // The same epilogue for the permuted channel assignment (hv_perm_row): plain bf16 row-major output with optional LayerNorm
 // fold / residual; the fragment pair (2j, 2j+1) of a lane is 8 consecutive channels n_base + 32 j + 8 quad.  N % 8 == 0.
-template <int NMF, bool LN, bool RES>
+// STATS: additionally leaves the GroupNorm partial statistics of the stored tile in p.gn_part (per channel: sum and sum of
+// squares over the wave's rows; see hv_gemm_params) -- in-lane over the row fragments, then over the 16 lanes of the DPP row.
+template <int NMF, bool LN, bool RES, bool STATS = false>
 HV_DEV void hv_gemm_epilogue_fast_perm(const HvGemmParams& p, f32x4 (&acc)[4][NMF], int m_base, int n_base, int r16, int quad,
                                        const float* tab_row HV_TRACE_PARAM) {
     constexpr int G = NMF < HV_GEMM_EPI_G ? NMF : HV_GEMM_EPI_G;  // row fragments per load group
@@ -424,6 +426,9 @@ HV_DEV void hv_gemm_epilogue_fast_perm(const HvGemmParams& p, f32x4 (&acc)[4][NM
         for (int nf = 0; nf < 4; ++nf) add4[nf] += t4[nf];
     }
     u32x4 outp[NMF][2];
+    f32x4 gs[4], gq[4];  // STATS: per-channel partial sums of this lane ([2 h + k]: channels nc[h] + 4 k .. + 3)
+#pragma unroll
+    for (int nf = 0; nf < 4; ++nf) gs[nf] = gq[nf] = zero4;
 #pragma unroll
     for (int g = 0; g < NMF; g += G) {
         float mean[G], rstd[G];
@@ -465,6 +470,10 @@ HV_DEV void hv_gemm_epilogue_fast_perm(const HvGemmParams& p, f32x4 (&acc)[4][NM
                     }
                     o[2 * k] = hv_pack2(v[0], v[1]);
                     o[2 * k + 1] = hv_pack2(v[2], v[3]);
+                    if (STATS && m_base + 16 * mf + r16 < p.M) {
+                        gs[nf] += v;
+                        gq[nf] += v * v;
+                    }
                 }
                 outp[mf][h] = o;
             }
@@ -494,6 +503,25 @@ HV_DEV void hv_gemm_epilogue_fast_perm(const HvGemmParams& p, f32x4 (&acc)[4][NM
             const int n = n_base + 32 * h + 8 * quad;
             if (n >= p.N) continue;
             hv_st16(yb + (yo + 2u * (unsigned)n), outp[mf][h]);
+        }
+    }
+    if (STATS && p.gn_part != nullptr) {  // (wave-uniform) rows [m_base, + 16 NMF) lie in one image: hv_gemm_gn_parts
+        const int rows = 16 * NMF, parts = p.gn_rows_per_image / rows;
+        const int img = m_base / p.gn_rows_per_image, part = (m_base - img * p.gn_rows_per_image) / rows;
+        float* dst = p.gn_part + ((long)img * parts + part) * p.N * 2;
+#pragma unroll
+        for (int nf = 0; nf < 4; ++nf) {
+            f32x4 a, b;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                a[e] = hv_row16_sum(gs[nf][e]);
+                b[e] = hv_row16_sum(gq[nf][e]);
+            }
+            const int n = n_base + 32 * (nf >> 1) + 8 * quad + 4 * (nf & 1);
+            if (r16 == 0 && n < p.N) {
+                *reinterpret_cast<f32x4*>(dst + 2 * n) = f32x4{a[0], b[0], a[1], b[1]};
+                *reinterpret_cast<f32x4*>(dst + 2 * n + 4) = f32x4{a[2], b[2], a[3], b[3]};
+            }
         }
     }
     HV_TRACE(13);
@@ -607,7 +635,7 @@ static inline int hv_gemm_fast_form(const HvGemmParams& p, int rows_per_wave) {
     return res ? HV_FORM_RES : HV_FORM_PLAIN;
 }
 
-template <int NMF, bool PERM = false>
+template <int NMF, bool PERM = false, bool STATS = false>
 HV_DEV void hv_gemm_epilogue_form(int form, const HvGemmParams& p, f32x4 (&acc)[4][NMF], int m_base, int n_base, int r16,
                                   int quad HV_TRACE_PARAM) {
 #if !HV_GEMM_DEFER
@@ -625,8 +653,8 @@ HV_DEV void hv_gemm_epilogue_form(int form, const HvGemmParams& p, f32x4 (&acc)[
         switch (form) {
             case HV_FORM_LN_GEGLU: hv_gemm_epilogue_fast_perm_geglu<NMF>(p, acc, m_base, n_base, r16, quad, tab HV_TRACE_ARG); break;
             case HV_FORM_LN: hv_gemm_epilogue_fast_perm<NMF, true, false>(p, acc, m_base, n_base, r16, quad, tab HV_TRACE_ARG); break;
-            case HV_FORM_RES: hv_gemm_epilogue_fast_perm<NMF, false, true>(p, acc, m_base, n_base, r16, quad, tab HV_TRACE_ARG); break;
-            default: hv_gemm_epilogue_fast_perm<NMF, false, false>(p, acc, m_base, n_base, r16, quad, tab HV_TRACE_ARG); break;
+            case HV_FORM_RES: hv_gemm_epilogue_fast_perm<NMF, false, true, STATS>(p, acc, m_base, n_base, r16, quad, tab HV_TRACE_ARG); break;
+            default: hv_gemm_epilogue_fast_perm<NMF, false, false, STATS>(p, acc, m_base, n_base, r16, quad, tab HV_TRACE_ARG); break;
         }
         return;
     }
@@ -820,7 +848,8 @@ __global__ __launch_bounds__(256, 2) void hv_gemm_kernel(HvGemmParams p) {
 // profiles/r03_hwcheck.txt), which is deleted together with the BK = 32 / 3-slot / contiguous-walk / L2-prefetch variants
 // that never won a same-box A/B.
 //   PERM: the permuted channel assignment of a wave's 64-channel block (hv_perm_row) for the plain-output forms.
-template <int BN, int NW, int BM, int PH, bool PERM = false>
+//   STATS (with PERM): the plain / residual epilogue also leaves GroupNorm partial statistics of its tile (p.gn_part).
+template <int BN, int NW, int BM, int PH, bool PERM = false, bool STATS = false>
 __global__ __launch_bounds__(NW * 64, 2) void hv_gemm_glds_kernel(HvGemmParams p, int gm, int form) {
     constexpr int BK = 64, NS = 2;
     constexpr int WAVES_N = BN / 64, WAVES_M = NW / WAVES_N;
@@ -1079,7 +1108,7 @@ __global__ __launch_bounds__(NW * 64, 2) void hv_gemm_glds_kernel(HvGemmParams p
             {
                 int m0, n0;
                 tile_origin(c_tile, m0, n0);
-                hv_gemm_epilogue_form<NMF, PERM>(form, p, acc, m0 + WTM * wm, n0 + 64 * wn, r16, quad HV_TRACE_ARG);
+                hv_gemm_epilogue_form<NMF, PERM, STATS>(form, p, acc, m0 + WTM * wm, n0 + 64 * wn, r16, quad HV_TRACE_ARG);
                 landed = 1;
             }
             c_tile += tstep;
@@ -1099,6 +1128,52 @@ static int g_hv_gemm_max_grid = 512;  // tuning knob (hv_set_tuning): persistent
 static int g_hv_gemm_glds = 1;
 static int g_hv_gemm_perm = 1;  // tuning knob (hv_set_tuning key 6): 16-byte epilogue through the permuted channel assignment (A/B)
 
+// Which kernel hv_gemm_launch takes for a problem: 0 register-staged, 1 = 256x256x64, 2 = 128x128x64 (LDS-DMA); perm = the
+// permuted channel assignment.  Shared with hv_gemm_gn_parts so that the caller sizes gn_part for the kernel that will run.
+struct HvGemmChoice {
+    int kernel, form, gm;
+    bool perm;
+};
+static inline HvGemmChoice hv_gemm_choose(const HvGemmParams& p);
+
+// parts per image of the GroupNorm partial statistics (0 = this problem's kernel cannot emit them)
+static inline int hv_gemm_gn_parts_of(const HvGemmParams& p) {
+    const HvGemmChoice c = hv_gemm_choose(p);
+    if (c.kernel != 2 || !c.perm || (c.form != HV_FORM_RES && c.form != HV_FORM_PLAIN)) return 0;
+    if (p.gn_rows_per_image <= 0 || p.gn_rows_per_image % 64 != 0 || p.M % p.gn_rows_per_image != 0) return 0;
+    return p.gn_rows_per_image / 64;
+}
+
+static inline HvGemmChoice hv_gemm_choose(const HvGemmParams& p) {
+    HvGemmChoice c{0, HV_FORM_NONE, 1, false};
+    const bool prologue = p.pro_scale != nullptr || p.pro_act != HV_ACT_NONE;
+    // the LDS-DMA kernel addresses its operands with 32-bit byte offsets and only knows the hot epilogue forms
+    const long lim = 1L << 32;
+    const bool span_ok = (long)p.M * p.ldx * 2 < lim && (long)p.N * p.K * 2 < lim && (long)p.M * p.ldy * 2 < lim &&
+                         (p.X2 == nullptr || (long)p.M * p.ldx2 * 2 < lim) &&
+                         (p.residual == nullptr || (long)p.M * p.ldr * 2 < lim) &&
+                         (p.Yt == nullptr || (long)(p.N - p.n_split) * p.ldyt * 2 < lim);
+    const int form128 = hv_gemm_fast_form(p, 128), form64 = hv_gemm_fast_form(p, 64);
+    if (!(g_hv_gemm_glds && !prologue && p.M >= 256 && span_ok && form64 != HV_FORM_NONE)) return c;
+    const int tm = (p.M + 255) / 256;
+    const int n128 = ((p.N + 127) / 128) * 128, n256 = ((p.N + 255) / 256) * 256;
+    c.gm = n128 / 128 > 8 ? 8 : 1;  // grouped raster for wide outputs (see the kernel)
+    const bool ok128 = form128 != HV_FORM_NONE;  // a per-row table may fit 64-row but not 128-row wave sub-tiles
+    // 256 x 256 tiles when N fills them about as well as 128-column tiles would, and when they fill the 256 CUs' last
+    // round to >= 90 % (one workgroup per CU: 360 tiles are two rounds at 70 %); otherwise the 128 x 128 x 64 kernel,
+    // whose 512 slots quantise four times finer
+    const int t256 = tm * (n256 / 256), rounds256 = (t256 + 255) / 256;
+    const bool fills256 = t256 * 10 >= rounds256 * 256 * 9;
+    const bool shape256 = ok128 && p.N >= 960 && (n256 - p.N) * 8 <= p.N;
+    const bool big = g_hv_gemm_glds != 3 && shape256 && (fills256 || g_hv_gemm_glds == 2);
+    c.kernel = big ? 1 : 2;
+    c.form = big ? form128 : form64;
+    // plain bf16 outputs (plain / residual / LayerNorm fold) and GEGLU with N % 8 == 0: permuted channel assignment, 16-byte epilogue
+    c.perm = g_hv_gemm_perm && p.N % 8 == 0 &&
+             (c.form == HV_FORM_RES || c.form == HV_FORM_PLAIN || c.form == HV_FORM_LN || c.form == HV_FORM_LN_GEGLU);
+    return c;
+}
+
 static inline int hv_gemm_launch(const HvGemmParams& p, hipStream_t stream) {
     if (p.M <= 0 || p.N <= 0 || p.K <= 0) return -1;
     if (p.K % 64 != 0 || p.N % 4 != 0) return -1;
@@ -1108,57 +1183,41 @@ static inline int hv_gemm_launch(const HvGemmParams& p, hipStream_t stream) {
     if (p.perm_p != 0 && (p.perm_p < 0 || p.perm_x <= 0 || p.perm_y <= 0 || (long)p.perm_x * p.perm_y * p.perm_p != p.M ||
                           p.Yt != nullptr || p.geglu))
         return -1;
+    if (p.gn_part != nullptr && hv_gemm_gn_parts_of(p) == 0) return -1;  // statistics wanted from a kernel that cannot emit them
     const bool prologue = p.pro_scale != nullptr || p.pro_act != HV_ACT_NONE;
     char shape[128] = "";
     if (g_hv_prof)
         snprintf(shape, sizeof(shape), "M=%d N=%d K=%d geglu=%d res=%d yt=%d f32=%d x2=%d", p.M, p.N, p.K, p.geglu,
                  p.residual != nullptr, p.Yt != nullptr ? p.N - p.n_split : 0, p.out_f32, p.X2 != nullptr);
-    // the LDS-DMA kernel addresses its operands with 32-bit byte offsets and only knows the hot epilogue forms
-    const long lim = 1L << 32;
-    const bool span_ok = (long)p.M * p.ldx * 2 < lim && (long)p.N * p.K * 2 < lim && (long)p.M * p.ldy * 2 < lim &&
-                         (p.X2 == nullptr || (long)p.M * p.ldx2 * 2 < lim) &&
-                         (p.residual == nullptr || (long)p.M * p.ldr * 2 < lim) &&
-                         (p.Yt == nullptr || (long)(p.N - p.n_split) * p.ldyt * 2 < lim);
-    const int form128 = hv_gemm_fast_form(p, 128), form64 = hv_gemm_fast_form(p, 64);
-    if (g_hv_gemm_glds && !prologue && p.M >= 256 && span_ok && form64 != HV_FORM_NONE) {
-        const int tm = (p.M + 255) / 256;
-        const int n128 = ((p.N + 127) / 128) * 128, n256 = ((p.N + 255) / 256) * 256;
-        const int gm = n128 / 128 > 8 ? 8 : 1;  // grouped raster for wide outputs (see the kernel)
-        const bool ok128 = form128 != HV_FORM_NONE;  // a per-row table may fit 64-row but not 128-row wave sub-tiles
-        // 256 x 256 tiles when N fills them about as well as 128-column tiles would, and when they fill the 256 CUs' last
-        // round to >= 90 % (one workgroup per CU: 360 tiles are two rounds at 70 %); otherwise the 128 x 128 x 64 kernel,
-        // whose 512 slots quantise four times finer
-        const int t256 = tm * (n256 / 256), rounds256 = (t256 + 255) / 256;
-        const bool fills256 = t256 * 10 >= rounds256 * 256 * 9;
-        const bool shape256 = ok128 && p.N >= 960 && (n256 - p.N) * 8 <= p.N;
-        if (g_hv_gemm_glds != 3 && shape256 && (fills256 || g_hv_gemm_glds == 2)) {
-            int grid = ((t256 + 7) / 8) * 8;
-            if (grid > 256) grid = 256;
-            if (grid > g_hv_gemm_max_grid) grid = g_hv_gemm_max_grid;
-            const bool perm256 = g_hv_gemm_perm && p.N % 8 == 0 && (form128 == HV_FORM_RES || form128 == HV_FORM_PLAIN ||
-                                                                    form128 == HV_FORM_LN || form128 == HV_FORM_LN_GEGLU);
-            if (perm256) {
-                hv_note("hv_gemm_glds_kernel<256,8,256,1,perm> | %s", shape);
-                hv_launch(hv_gemm_glds_kernel<256, 8, 256, 1, true>, dim3(grid), dim3(512), stream, p, gm, form128);
-            } else {
-                hv_note("hv_gemm_glds_kernel<256,8,256,1> | %s", shape);
-                hv_launch(hv_gemm_glds_kernel<256, 8, 256, 1, false>, dim3(grid), dim3(512), stream, p, gm, form128);
-            }
-            return 0;
+    const HvGemmChoice c = hv_gemm_choose(p);
+    if (c.kernel == 1) {
+        const int t256 = ((p.M + 255) / 256) * ((p.N + 255) / 256);
+        int grid = ((t256 + 7) / 8) * 8;
+        if (grid > 256) grid = 256;
+        if (grid > g_hv_gemm_max_grid) grid = g_hv_gemm_max_grid;
+        if (c.perm) {
+            hv_note("hv_gemm_glds_kernel<256,8,256,1,perm> | %s", shape);
+            hv_launch(hv_gemm_glds_kernel<256, 8, 256, 1, true>, dim3(grid), dim3(512), stream, p, c.gm, c.form);
+        } else {
+            hv_note("hv_gemm_glds_kernel<256,8,256,1> | %s", shape);
+            hv_launch(hv_gemm_glds_kernel<256, 8, 256, 1, false>, dim3(grid), dim3(512), stream, p, c.gm, c.form);
         }
-        const int tiles6 = ((p.M + 127) / 128) * (n128 / 128);
+        return 0;
+    }
+    if (c.kernel == 2) {
+        const int tiles6 = ((p.M + 127) / 128) * ((p.N + 127) / 128);
         int grid6 = ((tiles6 + 7) / 8) * 8;
         if (grid6 > 512) grid6 = 512;
         if (grid6 > g_hv_gemm_max_grid) grid6 = g_hv_gemm_max_grid;
-        // plain bf16 outputs (plain / residual / LayerNorm fold) and GEGLU with N % 8 == 0: permuted channel assignment, 16-byte epilogue
-        const bool perm = g_hv_gemm_perm && p.N % 8 == 0 &&
-                          (form64 == HV_FORM_RES || form64 == HV_FORM_PLAIN || form64 == HV_FORM_LN || form64 == HV_FORM_LN_GEGLU);
-        if (perm) {
+        if (c.perm && p.gn_part != nullptr) {
+            hv_note("hv_gemm_glds_kernel<128,4,128,2,perm,stats> | %s", shape);
+            hv_launch(hv_gemm_glds_kernel<128, 4, 128, 2, true, true>, dim3(grid6), dim3(256), stream, p, c.gm, c.form);
+        } else if (c.perm) {
             hv_note("hv_gemm_glds_kernel<128,4,128,2,perm> | %s", shape);
-            hv_launch(hv_gemm_glds_kernel<128, 4, 128, 2, true>, dim3(grid6), dim3(256), stream, p, gm, form64);
+            hv_launch(hv_gemm_glds_kernel<128, 4, 128, 2, true>, dim3(grid6), dim3(256), stream, p, c.gm, c.form);
         } else {
             hv_note("hv_gemm_glds_kernel<128,4,128,2> | %s", shape);
-            hv_launch(hv_gemm_glds_kernel<128, 4, 128, 2, false>, dim3(grid6), dim3(256), stream, p, gm, form64);
+            hv_launch(hv_gemm_glds_kernel<128, 4, 128, 2, false>, dim3(grid6), dim3(256), stream, p, c.gm, c.form);
         }
         return 0;
     }

@@ -181,6 +181,66 @@ static inline int hv_groupnorm_launch(const hv_groupnorm_params& p, hipStream_t 
     return 0;
 }
 
+// ---- GroupNorm scale / shift from the partial statistics the producing kernels left (hv_conv3x3 / hv_gemm gn_part) ---------
+// grid (ceil(groups / 4), n_images), one wavefront per (image, group).  The group's items -- (part, channel) pairs of {sum, sum
+// of squares}, from one or two sources (channel concat) -- are spread over the lanes and summed in double precision: the
+// partial sums are fp32 over at most a few hundred values each, the merge over up to ~10^4 of them must not lose the digits
+// that  var = Q / n - mean^2  cancels.
+typedef hv_gn_parts_params HvGnPartsParams;
+__global__ __launch_bounds__(256) void hv_gn_from_parts_kernel(HvGnPartsParams p) {
+    const int C = p.C1 + p.C2;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int g = blockIdx.x * 4 + wave, img = blockIdx.y;
+    const int cg = C / p.groups;
+    const bool live = g < p.groups;  // no early return: every lane takes part in the wave shuffles below
+    double S = 0.0, Q = 0.0;
+    if (live) {
+        const int c_lo = g * cg, c_hi = c_lo + cg;
+        // source 1: channels [c_lo, min(c_hi, C1)), source 2: the rest
+        const int a1 = min(c_lo, p.C1), b1 = min(c_hi, p.C1);
+        const int n1 = (b1 - a1) * p.parts1;
+        for (int i = lane; i < n1; i += 64) {
+            const int part = i / (b1 - a1), c = a1 + i % (b1 - a1);
+            const float* src = p.part1 + (((long)img * p.parts1 + part) * p.C1 + c) * 2;
+            S += (double)src[0];
+            Q += (double)src[1];
+        }
+        const int a2 = max(c_lo, p.C1) - p.C1, b2 = max(c_hi, p.C1) - p.C1;
+        const int n2 = (b2 - a2) * p.parts2;
+        for (int i = lane; i < n2; i += 64) {
+            const int part = i / (b2 - a2), c = a2 + i % (b2 - a2);
+            const float* src = p.part2 + (((long)img * p.parts2 + part) * p.C2 + c) * 2;
+            S += (double)src[0];
+            Q += (double)src[1];
+        }
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+        S += __shfl_xor(S, o);
+        Q += __shfl_xor(Q, o);
+    }
+    const double n = (double)cg * (double)p.pixels;
+    const double mean = S / n;
+    double var = Q / n - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const float rstd = 1.0f / sqrtf((float)var + p.eps);
+    if (!live) return;
+    for (int c = g * cg + lane; c < (g + 1) * cg; c += 64) {
+        const float sc = rstd * p.gamma[c];
+        p.scale[(long)img * C + c] = sc;
+        p.shift[(long)img * C + c] = p.beta[c] - (float)mean * sc;
+    }
+}
+
+static inline int hv_gn_from_parts_launch(const HvGnPartsParams& p, hipStream_t stream) {
+    const int C = p.C1 + p.C2;
+    if (p.C1 <= 0 || p.C2 < 0 || C % p.groups != 0 || p.parts1 <= 0 || p.part1 == nullptr || p.pixels <= 0) return -1;
+    if (p.C2 > 0 && (p.part2 == nullptr || p.parts2 <= 0)) return -1;
+    hv_note("hv_gn_from_parts_kernel | n=%d C=%d parts=%d+%d", p.n_images, C, p.parts1, p.C2 > 0 ? p.parts2 : 0);
+    hv_launch(hv_gn_from_parts_kernel, dim3((p.groups + 3) / 4, p.n_images), dim3(256), stream, p);
+    return 0;
+}
+
 // ---- LayerNorm statistics: one wavefront per row -----------------------------------------------
 #define HV_LN_MAXV 4  // 16-byte vectors per lane: C <= 64 * 8 * 4 = 2048
 

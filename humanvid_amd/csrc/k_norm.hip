@@ -6,3 +6,4 @@ int hvk_groupnorm(const hv_groupnorm_params& p, hipStream_t s) { return hv_group
 void hvk_layernorm(const bf16_t* X, long ldx, int M, int C, float eps, float* mean, float* rstd, hipStream_t s) {
     hv_layernorm_launch(X, ldx, M, C, eps, mean, rstd, s);
 }
+int hvk_gn_from_parts(const hv_gn_parts_params& p, hipStream_t s) { return hv_gn_from_parts_launch(p, s); }

@@ -345,6 +345,11 @@ class UNet3DEngine:
         ops.gemm(L, st, emb, w["temb_all.w"], temb, bias=w["temb_all.bias"], pro_act=A.ACT_SILU)
 
         gn_affine, ln_stats, feed_forward = self.run.gn_affine, self.run.ln_stats, self.run.feed_forward
+        # every activation a GroupNorm reads is written by a 3x3 convolution or by a projection-out GEMM: both leave the
+        # GroupNorm partial statistics of what they store (Runner.conv_with_stats / gemm_with_stats), so gn_affine needs no
+        # pass over the activation.  The statistics belong to THIS forward's buffers: start from an empty table.
+        self.run.gn_parts.clear()
+        conv = self.run.conv_with_stats
         sharded = self.shard is not None and self.shard.world > 1
 
         def resnet(prefix, x, skip, out_name):
@@ -354,9 +359,8 @@ class UNet3DEngine:
             sc, sh = gn_affine(x, prefix + ".norm1", self.eps, skip)
             h1 = ws.get(f"res_h1_{h}x{ww}x{cout}", (n, h, ww, cout))
             off = self.temb_off[prefix]
-            ops.conv3x3(L, st, x, w[prefix + ".conv1.w"], h1, x2=skip, pro_scale=sc, pro_shift=sh, pro_act=A.ACT_SILU,
-                        bias=w[prefix + ".conv1.bias"], rowvec=temb[:, off:], images_per_rowvec=F,
-                        rowvec_ld=self.temb_total)
+            conv(x, w[prefix + ".conv1.w"], h1, x2=skip, pro_scale=sc, pro_shift=sh, pro_act=A.ACT_SILU,
+                 bias=w[prefix + ".conv1.bias"], rowvec=temb[:, off:], images_per_rowvec=F, rowvec_ld=self.temb_total)
             if (prefix + ".conv_shortcut.w") in w:
                 res = ws.get(f"res_sc_{h}x{ww}x{cout}", (n, h, ww, cout))
                 c1 = x.shape[3]
@@ -368,8 +372,8 @@ class UNet3DEngine:
                 res = x
             sc, sh = gn_affine(h1, prefix + ".norm2", self.eps)
             out = ws.get(out_name, (n, h, ww, cout))
-            ops.conv3x3(L, st, h1, w[prefix + ".conv2.w"], out, pro_scale=sc, pro_shift=sh, pro_act=A.ACT_SILU,
-                        bias=w[prefix + ".conv2.bias"], residual=res)
+            conv(h1, w[prefix + ".conv2.w"], out, pro_scale=sc, pro_shift=sh, pro_act=A.ACT_SILU,
+                 bias=w[prefix + ".conv2.bias"], residual=res)
             return out
 
         def proj_in(x2d, sc, sh, N, wt, bias, hid):
@@ -454,7 +458,7 @@ class UNet3DEngine:
             ops.gemm(L, st, o, w[t + ".attn1.to_out.0.w"], hid, bias=w[t + ".attn1.to_out.0.bias"],
                      rowvec=self.cross_const[prefix], rowvec_period=F * N, residual=hid)
             feed_forward(t + ".ff1", t + ".ff.net.2", hid)
-            ops.gemm(L, st, hid, w[prefix + ".proj_out.w"], x2d, bias=w[prefix + ".proj_out.bias"], residual=x2d)
+            self.run.gemm_with_stats(hid, w[prefix + ".proj_out.w"], x, N, bias=w[prefix + ".proj_out.bias"], residual=x2d)
             return x
 
         def motion(prefix, x):
@@ -473,7 +477,7 @@ class UNet3DEngine:
                 for ai in range(len(mmk["attention_block_types"])):
                     self.run.temporal_attention_block(f"{b}.attention_blocks.{ai}", hid, B, F, N, sharded)
                 feed_forward(b + ".ff1", b + ".ff.net.2", hid)
-            ops.gemm(L, st, hid, w[mm + ".proj_out.w"], x2d, bias=w[mm + ".proj_out.bias"], residual=x2d)
+            self.run.gemm_with_stats(hid, w[mm + ".proj_out.w"], x, N, bias=w[mm + ".proj_out.bias"], residual=x2d)
             return x
 
         def tap(name, v):
@@ -482,7 +486,7 @@ class UNet3DEngine:
 
         # ---- conv_in (+ pose/camera conditioning)  unet_3d.py:482-484
         x = ws.get("conv_in", (n, H, W, boc[0]))
-        ops.conv3x3(L, st, x_in, w["conv_in.w"], x, bias=w["conv_in.bias"], residual=cond)
+        conv(x_in, w["conv_in.w"], x, bias=w["conv_in.bias"], residual=cond)
         skips: List[torch.Tensor] = [x]
         for spec in self.unet.specs:
             p = spec.prefix
@@ -500,8 +504,7 @@ class UNet3DEngine:
                 if spec.resample:
                     _, h, ww, C = x.shape
                     y = ws.get(f"{p}.down", (n, (h + 1) // 2, (ww + 1) // 2, C))
-                    ops.conv3x3(L, st, x, w[f"{p}.downsamplers.0.conv.w"], y, mode=A.CONV_S2,
-                                bias=w[f"{p}.downsamplers.0.conv.bias"])
+                    conv(x, w[f"{p}.downsamplers.0.conv.w"], y, mode=A.CONV_S2, bias=w[f"{p}.downsamplers.0.conv.bias"])
                     x = y
                     skips.append(x)
             elif spec.kind == "mid":
@@ -522,8 +525,7 @@ class UNet3DEngine:
                 if spec.resample:
                     _, h, ww, C = x.shape
                     y = ws.get(f"{p}.up", (n, 2 * h, 2 * ww, C))
-                    ops.conv3x3(L, st, x, w[f"{p}.upsamplers.0.conv.w"], y, mode=A.CONV_UP2,
-                                bias=w[f"{p}.upsamplers.0.conv.bias"])
+                    conv(x, w[f"{p}.upsamplers.0.conv.w"], y, mode=A.CONV_UP2, bias=w[f"{p}.upsamplers.0.conv.bias"])
                     x = y
         if self.kind == "reference":
             return x  # conv_norm_out / conv_out are removed in the ReferenceNet (unet_2d_condition.py:1295-1299)

@@ -30,9 +30,12 @@ def _chk(t: torch.Tensor, dtype, what: str):
 def gemm(lib, stream, x, w, y, *, x2=None, k1=0, yt=None, n_split=0, pro_scale=None, pro_shift=None,
          rows_per_image=1, pro_act=A.ACT_NONE, bias=None, row_mean=None, row_rstd=None, colsum=None, pe=None,
          pe_period=1, pe_frames=1, rowvec=None, rowvec_period=1, residual=None, geglu=False, out_act=A.ACT_NONE,
-         M=None, ldx=None, ldy=None, ldr=None, ldx2=None, row_perm=None):
+         M=None, ldx=None, ldy=None, ldr=None, ldx2=None, row_perm=None, gn_part=None, gn_rows_per_image=0,
+         query_gn_parts=False):
     """y[M, N(/2)] = epi(pro(x)[M, K] @ w[N, K]^T); x/x2/y/residual may be row-strided views.
-    row_perm=(X, Y, P): output (and residual) row (x*Y + y)*P + p is taken at (y*X + x)*P + p."""
+    row_perm=(X, Y, P): output (and residual) row (x*Y + y)*P + p is taken at (y*X + x)*P + p.
+    gn_part [M / gn_rows_per_image, parts, N, 2] fp32: GroupNorm partial statistics of the output (hv_gemm_gn_parts);
+    query_gn_parts=True only asks how many parts per image this problem would write (0 = cannot) and launches nothing."""
     N, K = w.shape
     M = x.shape[0] if M is None else M
     p = A.GemmParams(
@@ -47,7 +50,10 @@ def gemm(lib, stream, x, w, y, *, x2=None, k1=0, yt=None, n_split=0, pro_scale=N
         geglu=int(geglu), out_act=out_act,
         perm_x=row_perm[0] if row_perm else 0, perm_y=row_perm[1] if row_perm else 0,
         perm_p=row_perm[2] if row_perm else 0,
+        gn_part=_p(gn_part), gn_rows_per_image=gn_rows_per_image,
     )
+    if query_gn_parts:
+        return int(lib.cdll.hv_gemm_gn_parts(C.byref(p)))
     lib.call("hv_gemm", C.byref(p), stream)
 
 
@@ -60,8 +66,10 @@ def affine_apply(lib, stream, x, scale, shift, y, *, rows_per_image, act=A.ACT_N
 
 
 def conv3x3(lib, stream, x, w, y, *, x2=None, mode=A.CONV_S1, pro_scale=None, pro_shift=None, pro_act=A.ACT_NONE,
-            bias=None, rowvec=None, images_per_rowvec=1, rowvec_ld=None, residual=None, out_act=A.ACT_NONE):
-    """x [n,Hs,Ws,C1] (+x2 [n,Hs,Ws,C2]); w packed [Cout, 9, C1+C2]; y [n,Ho,Wo,Cout]."""
+            bias=None, rowvec=None, images_per_rowvec=1, rowvec_ld=None, residual=None, out_act=A.ACT_NONE,
+            gn_part=None, query_gn_parts=False):
+    """x [n,Hs,Ws,C1] (+x2 [n,Hs,Ws,C2]); w packed [Cout, 9, C1+C2]; y [n,Ho,Wo,Cout].
+    gn_part [n, parts, Cout, 2] fp32: GroupNorm partial statistics of the output; query_gn_parts=True only returns `parts`."""
     n, Hs, Ws, C1 = x.shape
     _, Ho, Wo, Cout = y.shape
     p = A.Conv3x3Params(
@@ -70,8 +78,10 @@ def conv3x3(lib, stream, x, w, y, *, x2=None, mode=A.CONV_S1, pro_scale=None, pr
         pro_scale=_p(pro_scale), pro_shift=_p(pro_shift), pro_act=pro_act, bias=_p(bias),
         rowvec=_p(rowvec), images_per_rowvec=images_per_rowvec,
         rowvec_ld=(Cout if rowvec_ld is None else rowvec_ld), residual=_p(residual),
-        residual_images=0 if residual is None else residual.shape[0], out_act=out_act,
+        residual_images=0 if residual is None else residual.shape[0], out_act=out_act, gn_part=_p(gn_part),
     )
+    if query_gn_parts:
+        return int(lib.cdll.hv_conv3x3_gn_parts(C.byref(p)))
     lib.call("hv_conv3x3", C.byref(p), stream)
 
 
@@ -86,6 +96,17 @@ def groupnorm_affine(lib, stream, x, gamma, beta, groups, eps, partial, scale, s
         scale=_p(scale), shift=_p(shift),
     )
     lib.call("hv_groupnorm_affine", C.byref(p), stream)
+
+
+def groupnorm_from_parts(lib, stream, part1, gamma, beta, groups, eps, pixels, scale, shift, *, part2=None):
+    """scale / shift [n, C1 + C2] from the partial statistics the producing kernels left: part [n, parts, C, 2] fp32."""
+    n, parts1, C1, _ = part1.shape
+    p = A.GnPartsParams(
+        part1=_p(part1), parts1=parts1, C1=C1, part2=_p(part2), parts2=0 if part2 is None else part2.shape[1],
+        C2=0 if part2 is None else part2.shape[2], n_images=n, pixels=pixels, groups=groups, eps=eps,
+        gamma=_p(gamma), beta=_p(beta), scale=_p(scale), shift=_p(shift),
+    )
+    lib.call("hv_groupnorm_from_parts", C.byref(p), stream)
 
 
 def layernorm_stats(lib, stream, x, mean, rstd, eps=1e-5, M=None):

@@ -173,18 +173,59 @@ class Runner:
         if self.temporal_heads != 8:
             raise NotImplementedError(f"hv_temporal_attention is built for 8 heads, the config asks for {self.temporal_heads}")
         self._pe_split: Dict[tuple, tuple] = {}
+        self.gn_parts: Dict[int, torch.Tensor] = {}
+        # HUMANVID_GN_FUSED=0: every GroupNorm reads its input again (hv_groupnorm_affine), for A/Bs
+        self.gn_fused = os.environ.get("HUMANVID_GN_FUSED", "1") == "1"
 
     @property
     def st(self) -> int:
         return hvlib.current_stream()
 
     # ---- normalisation statistics ---------------------------------------------------------------
+    # GroupNorm partial statistics left by the kernel that PRODUCED an activation (hv_conv3x3 / hv_gemm gn_part), keyed by
+    # the activation's address: gn_affine then needs no pass over the activation.  An entry is valid for the buffer's
+    # current contents only: every producer either refreshes it (conv_with_stats / gemm_with_stats) or drops it.
+    def conv_with_stats(self, x, wt, y, **kw):
+        """ops.conv3x3 that also leaves the GroupNorm partial statistics of y"""
+        if not self.gn_fused:
+            ops.conv3x3(self.lib, self.st, x, wt, y, **kw)
+            return
+        parts = ops.conv3x3(self.lib, self.st, x, wt, y, query_gn_parts=True, **kw)
+        if parts <= 0:
+            self.gn_parts.pop(y.data_ptr(), None)
+            ops.conv3x3(self.lib, self.st, x, wt, y, **kw)
+            return
+        part = self.ws.get(f"gnp_{y.data_ptr()}", (y.shape[0], parts, y.shape[3], 2), F32)
+        ops.conv3x3(self.lib, self.st, x, wt, y, gn_part=part, **kw)
+        self.gn_parts[y.data_ptr()] = part
+
+    def gemm_with_stats(self, x2d, wt, y4d, rows_per_image, **kw):
+        """ops.gemm writing the [n, h, w, C] activation y4d (as rows) that also leaves its GroupNorm partial statistics
+        where the problem allows (hv_gemm_gn_parts), and drops stale ones where it does not"""
+        y2d = y4d.view(-1, y4d.shape[3])
+        parts = 0
+        if self.gn_fused:
+            parts = ops.gemm(self.lib, self.st, x2d, wt, y2d, gn_rows_per_image=rows_per_image, query_gn_parts=True, **kw)
+        if parts <= 0:
+            self.gn_parts.pop(y4d.data_ptr(), None)
+            ops.gemm(self.lib, self.st, x2d, wt, y2d, **kw)
+            return
+        part = self.ws.get(f"gnp_{y4d.data_ptr()}", (y4d.shape[0], parts, y4d.shape[3], 2), F32)
+        ops.gemm(self.lib, self.st, x2d, wt, y2d, gn_part=part, gn_rows_per_image=rows_per_image, **kw)
+        self.gn_parts[y4d.data_ptr()] = part
+
     def gn_affine(self, x, prefix, eps, x2=None):
         n = x.shape[0]
         C = x.shape[3] + (0 if x2 is None else x2.shape[3])
         sc = self.ws.get("gn_scale", (n, C), F32)
         sh = self.ws.get("gn_shift", (n, C), F32)
         pixels = x.shape[1] * x.shape[2]
+        p1 = self.gn_parts.get(x.data_ptr())
+        p2 = None if x2 is None else self.gn_parts.get(x2.data_ptr())
+        if p1 is not None and (x2 is None or p2 is not None):
+            ops.groupnorm_from_parts(self.lib, self.st, p1, self.w[prefix + ".g"], self.w[prefix + ".b"], self.groups, eps,
+                                     pixels, sc, sh, part2=p2)
+            return sc, sh
         splits = max(1, min(64, pixels // 48))
         part = self.ws.get("gn_partial", (n * 64 * self.groups * 2,), F32)
         ops.groupnorm_affine(self.lib, self.st, x, self.w[prefix + ".g"], self.w[prefix + ".b"], self.groups, eps, part,

@@ -78,7 +78,15 @@ typedef struct hv_gemm_params {
      * of an [x][y][perm_p] row index.  Lets the frame-sharded motion module write the all-to-all send layout straight
      * from the QKV projection and fold the inverse re-ordering into the output projection. */
     int perm_x, perm_y, perm_p;
+    /* optional GroupNorm partial statistics of the OUTPUT (round 3): per (image, part, channel) {sum, sum of squares} of the
+     * stored values, fp32 [M / gn_rows_per_image][parts][N][2], parts = hv_gemm_gn_parts(p) row ranges per image -- what
+     * hv_groupnorm_from_parts turns into the scale / shift of the next GroupNorm, so that the activation is not read again
+     * by a statistics pass.  NULL: not wanted.  Only for problems hv_gemm_gn_parts() accepts (plain bf16 output on the
+     * 128x128x64 LDS-DMA kernel, whole wave sub-tiles per image). */
+    float* gn_part;
+    int gn_rows_per_image;
 } hv_gemm_params;
+int hv_gemm_gn_parts(const hv_gemm_params* p); /* parts per image hv_gemm would write for this problem, 0 = cannot */
 int hv_gemm(const hv_gemm_params* p, void* stream);
 
 /* ---- 3x3 convolution (implicit GEMM, LDS halo tile) ---------------------------------------
@@ -109,8 +117,12 @@ typedef struct hv_conv3x3_params {
     const uint16_t* residual; /* [residual_images][Ho][Wo][Cout], image index taken modulo */
     int residual_images;
     int out_act;
+    /* optional GroupNorm partial statistics of the OUTPUT: fp32 [n_images][parts][Cout][2] = {sum, sum of squares} over the
+     * pixels of one wave's share of an output patch, parts = hv_conv3x3_gn_parts(p); NULL: not wanted (see hv_gemm_params) */
+    float* gn_part;
 } hv_conv3x3_params;
 int hv_conv3x3(const hv_conv3x3_params* p, void* stream);
+int hv_conv3x3_gn_parts(const hv_conv3x3_params* p); /* parts per image for this problem (kernel selection included) */
 
 /* ---- GroupNorm statistics -> per-(image,channel) affine -----------------------------------
  * InflatedGroupNorm (src/models/resnet.py:18-26), torch.nn.GroupNorm in Transformer3DModel
@@ -132,6 +144,23 @@ typedef struct hv_groupnorm_params {
     float* shift;
 } hv_groupnorm_params;
 int hv_groupnorm_affine(const hv_groupnorm_params* p, void* stream);
+
+/* The same scale / shift from the partial statistics the PRODUCING kernels left (hv_conv3x3 / hv_gemm gn_part): no pass over
+ * the activation.  Two sources = the channel concat of the up-blocks (groups may straddle the seam).  Sums are merged in
+ * double precision: mean = S / n, var = Q / n - mean^2 over the group's channels and all parts. */
+typedef struct hv_gn_parts_params {
+    const float* part1; /* [n_images][parts1][C1][2] */
+    int parts1, C1;
+    const float* part2; /* optional second source [n_images][parts2][C2][2] */
+    int parts2, C2;
+    int n_images, pixels, groups;
+    float eps;
+    const float* gamma;
+    const float* beta;
+    float* scale; /* out [n_images][C1 + C2] */
+    float* shift;
+} hv_gn_parts_params;
+int hv_groupnorm_from_parts(const hv_gn_parts_params* p, void* stream);
 
 /* LayerNorm row statistics (nn.LayerNorm eps 1e-5; src/models/attention.py:329-360,
  * src/models/motion_module.py:228,234); normalisation itself is folded into hv_gemm.       */

@@ -325,6 +325,77 @@ def case_groupnorm(cx: Ctx, n=3, H=6, W=10, C1=320, C2=0, groups=32, seed=5, off
     return e
 
 
+def case_gn_parts_conv(cx: Ctx, n=3, H=16, W=16, Cin=64, Cout=320, C2=0, groups=32, seed=51, offset=0.4, mode=None):
+    """GroupNorm statistics emitted by the PRODUCING convolution (hv_conv3x3 gn_part) -> hv_groupnorm_from_parts must give
+    the scale / shift that a statistics pass over the stored output gives (hv_groupnorm_affine) and that torch computes from
+    the stored bf16 values; `offset` shifts the output mean away from zero (the cancellation case of sum / sum-of-squares).
+    C2 > 0: a second, independently produced activation is concatenated (the up-block norm1: groups straddle the seam)."""
+    g = torch.Generator().manual_seed(seed)
+    mode = A.CONV_S1 if mode is None else mode
+    Ho, Wo = (H, W) if mode == A.CONV_S1 else ((H + 1) // 2, (W + 1) // 2) if mode == A.CONV_S2 else (2 * H, 2 * W)
+    outs, parts = [], []
+    for co in ([Cout] if C2 == 0 else [Cout, C2]):
+        x = rnd(g, n, H, W, Cin)
+        wt = rnd(g, co, Cin, 3, 3, scale=(9 * Cin) ** -0.5)
+        bias = rnd(g, co, scale=0.1) + offset
+        y = torch.zeros(n, Ho, Wo, co, dtype=BF16, device=cx.device)
+        kw = dict(mode=mode, bias=cx.dev(bias))
+        xd, wd = cx.bf(x), cx.bf(packing.pack_conv3x3(wt))
+        np_ = ops.conv3x3(cx.lib, cx.stream, xd, wd, y, query_gn_parts=True, **kw)
+        assert np_ > 0
+        part = torch.zeros(n, np_, co, 2, device=cx.device)
+        ops.conv3x3(cx.lib, cx.stream, xd, wd, y, gn_part=part, **kw)
+        outs.append(y)
+        parts.append(part)
+    C = Cout + C2
+    gamma, beta = 1 + 0.2 * rnd(g, C), 0.1 * rnd(g, C)
+    sc1, sh1 = torch.zeros(n, C, device=cx.device), torch.zeros(n, C, device=cx.device)
+    sc2, sh2 = torch.zeros(n, C, device=cx.device), torch.zeros(n, C, device=cx.device)
+    ops.groupnorm_from_parts(cx.lib, cx.stream, parts[0], cx.dev(gamma), cx.dev(beta), groups, 1e-5, Ho * Wo, sc1, sh1,
+                             part2=parts[1] if C2 else None)
+    partial = torch.zeros(n * 64 * groups * 2, device=cx.device)
+    ops.groupnorm_affine(cx.lib, cx.stream, outs[0], cx.dev(gamma), cx.dev(beta), groups, 1e-5, partial, sc2, sh2,
+                         x2=outs[1] if C2 else None, splits=min(4, max(1, Ho * Wo // 48)))
+    cx.sync()
+    ycat = torch.cat([o.float().cpu() for o in outs], dim=3).permute(0, 3, 1, 2)
+    ref = F.group_norm(ycat, groups, gamma, beta, 1e-5)
+    got1 = ycat * sc1.cpu()[:, :, None, None] + sh1.cpu()[:, :, None, None]
+    got2 = ycat * sc2.cpu()[:, :, None, None] + sh2.cpu()[:, :, None, None]
+    e1, e2 = nrmse(got1, ref), nrmse(got2, ref)
+    # the fused statistics see the fp32 values before the bf16 store: the difference is the store's rounding noise
+    assert e1 < 2e-3 and e2 < 1e-4, f"groupnorm from conv parts nrmse {e1} (statistics pass: {e2})"
+    return e1
+
+
+def case_gn_parts_gemm(cx: Ctx, n=4, rows=128, C=320, K=128, groups=32, seed=52, offset=0.3):
+    """the same for the projection-out GEMM (bias + residual in place, 128x128x64 LDS-DMA kernel, permuted epilogue)"""
+    g = torch.Generator().manual_seed(seed)
+    M = n * rows
+    x, wt = rnd(g, M, K), rnd(g, C, K, scale=K**-0.5)
+    bias, res = rnd(g, C, scale=0.1) + offset, rnd(g, M, C)
+    y = cx.bf(res)
+    xd, wd = cx.bf(x), cx.bf(wt)
+    kw = dict(bias=cx.dev(bias), residual=y)
+    np_ = ops.gemm(cx.lib, cx.stream, xd, wd, y, gn_rows_per_image=rows, query_gn_parts=True, **kw)
+    assert np_ == rows // 64, np_
+    part = torch.zeros(n, np_, C, 2, device=cx.device)
+    ops.gemm(cx.lib, cx.stream, xd, wd, y, gn_part=part, gn_rows_per_image=rows, **kw)
+    gamma, beta = 1 + 0.2 * rnd(g, C), 0.1 * rnd(g, C)
+    sc, sh = torch.zeros(n, C, device=cx.device), torch.zeros(n, C, device=cx.device)
+    ops.groupnorm_from_parts(cx.lib, cx.stream, part, cx.dev(gamma), cx.dev(beta), groups, 1e-5, rows, sc, sh)
+    cx.sync()
+    want = r(x) @ r(wt).t() + bias + r(res)
+    assert nrmse(y, want) < TOL
+    y4 = y.float().cpu().view(n, rows, C).permute(0, 2, 1)[..., None]  # [n, C, rows, 1]
+    ref = F.group_norm(y4, groups, gamma, beta, 1e-5)
+    got = y4 * sc.cpu()[:, :, None, None] + sh.cpu()[:, :, None, None]
+    e = nrmse(got, ref)
+    assert e < 2e-3, f"groupnorm from gemm parts nrmse {e}"
+    # a problem whose kernel cannot emit statistics reports 0 parts and refuses gn_part (rows per image not whole 64-row blocks)
+    assert ops.gemm(cx.lib, cx.stream, xd, wd, y, gn_rows_per_image=96, query_gn_parts=True, **kw) == 0
+    return e
+
+
 # ----------------------------------------------------------------------------------------- attention
 def case_attention(cx: Ctx, D=40, n_img=4, Lq=72, Lb=40, seed=6, check=None, q_stride=1, row_major=False, spike=False,
                    fp8=False):

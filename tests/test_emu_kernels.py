@@ -361,3 +361,12 @@ def test_attention_and_temporal_shape_sweep(cx):
         kc.case_attention(cx, D=D, n_img=n_img, Lq=Lq, Lb=Lb, seed=seed)
     for (D, B, Fr, P, seed) in [(40, 1, 3, 5, 71), (40, 2, 17, 3, 72), (80, 1, 32, 2, 73), (160, 2, 9, 4, 74), (80, 2, 24, 3, 75)]:
         kc.case_temporal(cx, D=D, B=B, Fr=Fr, P=P, seed=seed)
+
+
+def test_groupnorm_statistics_from_the_producing_kernels(cx):
+    """hv_conv3x3 / hv_gemm gn_part + hv_groupnorm_from_parts against the statistics pass and torch (round 3)"""
+    kc.case_gn_parts_conv(cx, n=2, H=16, W=16, Cin=32, Cout=320)                       # two patches x two pixel halves
+    kc.case_gn_parts_conv(cx, n=2, H=12, W=8, Cin=32, Cout=64, offset=3.0)             # narrow image: 16 x 8 patch, ragged rows
+    kc.case_gn_parts_conv(cx, n=1, H=8, W=16, Cin=32, Cout=128, C2=64, seed=53)        # two sources: a group straddles the seam
+    kc.case_gn_parts_conv(cx, n=1, H=8, W=8, Cin=32, Cout=64, mode=A.CONV_UP2, seed=54)  # upsample-folded: 16 x 16 output
+    kc.case_gn_parts_gemm(cx, n=3, rows=128, C=320, K=64)

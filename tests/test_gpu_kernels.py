@@ -202,3 +202,16 @@ def test_errors_are_python_exceptions(cx):
     with pytest.raises(NotImplementedError):
         ops.attention(cx.lib, cx.stream, x, x, x, y, n_images=1, heads=8, D=64, Lq=8, L1=8, ldq=512, ldk=512,
                       ldvt=8, ldo=512)
+
+
+def test_groupnorm_statistics_from_the_producing_kernels(cx):
+    """hv_conv3x3 / hv_gemm gn_part + hv_groupnorm_from_parts against the statistics pass and torch, incl. bench geometries"""
+    kc.case_gn_parts_conv(cx, n=2, H=16, W=16, Cin=32, Cout=320)
+    kc.case_gn_parts_conv(cx, n=2, H=12, W=8, Cin=64, Cout=1280, offset=3.0)            # level 3: narrow, ragged rows, 64-channel chunks
+    kc.case_gn_parts_conv(cx, n=3, H=24, W=16, Cin=128, Cout=640, C2=320, seed=53)      # up-block concat, groups of 30 straddle the seam
+    kc.case_gn_parts_conv(cx, n=2, H=24, W=16, Cin=64, Cout=128, mode=A.CONV_UP2, seed=54)   # 256-pixel patches, four pixel quarters
+    kc.case_gn_parts_conv(cx, n=2, H=48, W=32, Cin=64, Cout=64, mode=A.CONV_S2, seed=55)
+    kc.case_gn_parts_conv(cx, n=4, H=96, W=64, Cin=32, Cout=320, seed=56, offset=2.0)   # level 0
+    kc.case_gn_parts_gemm(cx, n=3, rows=128, C=320, K=64)
+    kc.case_gn_parts_gemm(cx, n=6, rows=1536, C=640, K=640, seed=57)                    # level 1 projection-out
+    kc.case_gn_parts_gemm(cx, n=4, rows=6144, C=320, K=320, seed=58, offset=2.0)        # level 0

@@ -40,7 +40,7 @@ class GemmParams(_S):
         ("residual", P), ("ldr", L),
         ("geglu", I), ("out_act", I),
         ("perm_x", I), ("perm_y", I), ("perm_p", I),
-        ("gn_part", P), ("gn_rows_per_image", I),
+        ("gn_part", P), ("gn_rows_per_image", I), ("ln_part", P),
     ]
 
 
@@ -103,6 +103,8 @@ PROTOTYPES = {
     "hv_conv3x3": (I, [C.POINTER(Conv3x3Params), P]),
     "hv_groupnorm_affine": (I, [C.POINTER(GroupNormParams), P]),
     "hv_gemm_gn_parts": (I, [C.POINTER(GemmParams)]),
+    "hv_gemm_ln_parts": (I, [C.POINTER(GemmParams)]),
+    "hv_layernorm_from_parts": (I, [P, I, I, I, F, P, P, P]),
     "hv_conv3x3_gn_parts": (I, [C.POINTER(Conv3x3Params)]),
     "hv_groupnorm_from_parts": (I, [C.POINTER(GnPartsParams), P]),
     "hv_layernorm_stats": (I, [P, L, I, I, F, P, P, P]),

@@ -66,7 +66,14 @@ int hv_groupnorm_affine(const hv_groupnorm_params* p, void* stream) {
 }
 
 int hv_gemm_gn_parts(const hv_gemm_params* p) { return p ? hvk_gemm_gn_parts(*p) : 0; }
+int hv_gemm_ln_parts(const hv_gemm_params* p) { return p ? hvk_gemm_ln_parts(*p) : 0; }
 int hv_conv3x3_gn_parts(const hv_conv3x3_params* p) { return p ? hvk_conv3x3_gn_parts(*p) : 0; }
+int hv_layernorm_from_parts(const float* part, int parts, int M, int C, float eps, float* mean, float* rstd, void* stream) {
+    if (!part || !mean || !rstd) return hv_fail(HV_EINVAL, "hv_layernorm_from_parts: null");
+    if (hvk_ln_from_parts(part, parts, M, C, eps, mean, rstd, (hipStream_t)stream) != 0)
+        return hv_fail(HV_EINVAL, "hv_layernorm_from_parts: need C == 64 * parts, M >= 1");
+    return hv_check_launch("hv_layernorm_from_parts");
+}
 int hv_groupnorm_from_parts(const hv_gn_parts_params* p, void* stream) {
     if (!p || !p->part1 || !p->scale || !p->shift || !p->gamma || !p->beta) return hv_fail(HV_EINVAL, "hv_groupnorm_from_parts: null");
     if (hvk_gn_from_parts(*p, (hipStream_t)stream) != 0)

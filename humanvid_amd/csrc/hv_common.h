@@ -20,6 +20,7 @@ typedef unsigned short bf16_t;  // raw bfloat16 bits
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
 typedef short bf16x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 

@@ -396,7 +396,9 @@ HV_DEV void hv_gemm_epilogue_fast(const HvGemmParams& p, f32x4 (&acc)[4][NMF], i
 // fold / residual; the fragment pair (2j, 2j+1) of a lane is 8 consecutive channels n_base + 32 j + 8 quad.  N % 8 == 0.
 // STATS: additionally leaves the GroupNorm partial statistics of the stored tile in p.gn_part (per channel: sum and sum of
 // squares over the wave's rows; see hv_gemm_params) -- in-lane over the row fragments, then over the 16 lanes of the DPP row.
-template <int NMF, bool LN, bool RES, bool STATS = false>
+// STATS = 2: LayerNorm partial statistics instead (p.ln_part): per ROW the sum and the sum of squares over the wave's 64
+// columns -- in-lane over the lane's 16 channels, then over the four quads that share a row.
+template <int NMF, bool LN, bool RES, int STATS = 0>
 HV_DEV void hv_gemm_epilogue_fast_perm(const HvGemmParams& p, f32x4 (&acc)[4][NMF], int m_base, int n_base, int r16, int quad,
                                        const float* tab_row HV_TRACE_PARAM) {
     constexpr int G = NMF < HV_GEMM_EPI_G ? NMF : HV_GEMM_EPI_G;  // row fragments per load group
@@ -426,9 +428,12 @@ HV_DEV void hv_gemm_epilogue_fast_perm(const HvGemmParams& p, f32x4 (&acc)[4][NM
         for (int nf = 0; nf < 4; ++nf) add4[nf] += t4[nf];
     }
     u32x4 outp[NMF][2];
-    f32x4 gs[4], gq[4];  // STATS: per-channel partial sums of this lane ([2 h + k]: channels nc[h] + 4 k .. + 3)
+    f32x4 gs[4], gq[4];  // STATS = 1: per-channel partial sums of this lane ([2 h + k]: channels nc[h] + 4 k .. + 3)
 #pragma unroll
     for (int nf = 0; nf < 4; ++nf) gs[nf] = gq[nf] = zero4;
+    float rs[NMF], rq[NMF];  // STATS = 2: per-row partial sums of this lane (16 of the wave's 64 columns)
+#pragma unroll
+    for (int mf = 0; mf < NMF; ++mf) rs[mf] = rq[mf] = 0.f;
 #pragma unroll
     for (int g = 0; g < NMF; g += G) {
         float mean[G], rstd[G];
@@ -470,9 +475,13 @@ HV_DEV void hv_gemm_epilogue_fast_perm(const HvGemmParams& p, f32x4 (&acc)[4][NM
                     }
                     o[2 * k] = hv_pack2(v[0], v[1]);
                     o[2 * k + 1] = hv_pack2(v[2], v[3]);
-                    if (STATS && m_base + 16 * mf + r16 < p.M) {
+                    if (STATS == 1 && m_base + 16 * mf + r16 < p.M) {
                         gs[nf] += v;
                         gq[nf] += v * v;
+                    }
+                    if (STATS == 2 && nc[h] == n_base + 32 * h + 8 * quad) {  // (not a clamped duplicate of the ragged edge)
+                        rs[mf] += (v[0] + v[1]) + (v[2] + v[3]);
+                        rq[mf] += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
                     }
                 }
                 outp[mf][h] = o;
@@ -505,7 +514,21 @@ HV_DEV void hv_gemm_epilogue_fast_perm(const HvGemmParams& p, f32x4 (&acc)[4][NM
             hv_st16(yb + (yo + 2u * (unsigned)n), outp[mf][h]);
         }
     }
-    if (STATS && p.gn_part != nullptr) {  // (wave-uniform) rows [m_base, + 16 NMF) lie in one image: hv_gemm_gn_parts
+    if (STATS == 2 && p.ln_part != nullptr && n_base < p.N) {  // (wave-uniform; a wave beyond the ragged N edge has no block)
+        const int parts = p.N / 64, blk = n_base / 64;
+#pragma unroll
+        for (int mf = 0; mf < NMF; ++mf) {
+            float a = rs[mf], b = rq[mf];
+            a += __shfl_xor(a, 16);
+            b += __shfl_xor(b, 16);
+            a += __shfl_xor(a, 32);
+            b += __shfl_xor(b, 32);
+            const int m = m_base + 16 * mf + r16;
+            if (quad == 0 && m < p.M) *reinterpret_cast<u32x2*>(p.ln_part + ((long)m * parts + blk) * 2) =
+                u32x2{__builtin_bit_cast(unsigned, a), __builtin_bit_cast(unsigned, b)};
+        }
+    }
+    if (STATS == 1 && p.gn_part != nullptr) {  // (wave-uniform) rows [m_base, + 16 NMF) lie in one image: hv_gemm_gn_parts
         const int rows = 16 * NMF, parts = p.gn_rows_per_image / rows;
         const int img = m_base / p.gn_rows_per_image, part = (m_base - img * p.gn_rows_per_image) / rows;
         float* dst = p.gn_part + ((long)img * parts + part) * p.N * 2;
@@ -635,7 +658,7 @@ static inline int hv_gemm_fast_form(const HvGemmParams& p, int rows_per_wave) {
     return res ? HV_FORM_RES : HV_FORM_PLAIN;
 }
 
-template <int NMF, bool PERM = false, bool STATS = false>
+template <int NMF, bool PERM = false, int STATS = 0>
 HV_DEV void hv_gemm_epilogue_form(int form, const HvGemmParams& p, f32x4 (&acc)[4][NMF], int m_base, int n_base, int r16,
                                   int quad HV_TRACE_PARAM) {
 #if !HV_GEMM_DEFER
@@ -848,8 +871,9 @@ __global__ __launch_bounds__(256, 2) void hv_gemm_kernel(HvGemmParams p) {
 // profiles/r03_hwcheck.txt), which is deleted together with the BK = 32 / 3-slot / contiguous-walk / L2-prefetch variants
 // that never won a same-box A/B.
 //   PERM: the permuted channel assignment of a wave's 64-channel block (hv_perm_row) for the plain-output forms.
-//   STATS (with PERM): the plain / residual epilogue also leaves GroupNorm partial statistics of its tile (p.gn_part).
-template <int BN, int NW, int BM, int PH, bool PERM = false, bool STATS = false>
+//   STATS (with PERM): the plain / residual epilogue also leaves GroupNorm (1, p.gn_part) or LayerNorm (2, p.ln_part) partial
+//   statistics of its tile.
+template <int BN, int NW, int BM, int PH, bool PERM = false, int STATS = 0>
 __global__ __launch_bounds__(NW * 64, 2) void hv_gemm_glds_kernel(HvGemmParams p, int gm, int form) {
     constexpr int BK = 64, NS = 2;
     constexpr int WAVES_N = BN / 64, WAVES_M = NW / WAVES_N;
@@ -1174,6 +1198,13 @@ static inline HvGemmChoice hv_gemm_choose(const HvGemmParams& p) {
     return c;
 }
 
+// 64-column blocks per row of the LayerNorm partial statistics (0 = this problem's kernel cannot emit them)
+static inline int hv_gemm_ln_parts_of(const HvGemmParams& p) {
+    const HvGemmChoice c = hv_gemm_choose(p);
+    if (c.kernel != 2 || !c.perm || (c.form != HV_FORM_RES && c.form != HV_FORM_PLAIN) || p.N % 64 != 0) return 0;
+    return p.N / 64;
+}
+
 static inline int hv_gemm_launch(const HvGemmParams& p, hipStream_t stream) {
     if (p.M <= 0 || p.N <= 0 || p.K <= 0) return -1;
     if (p.K % 64 != 0 || p.N % 4 != 0) return -1;
@@ -1184,6 +1215,7 @@ static inline int hv_gemm_launch(const HvGemmParams& p, hipStream_t stream) {
                           p.Yt != nullptr || p.geglu))
         return -1;
     if (p.gn_part != nullptr && hv_gemm_gn_parts_of(p) == 0) return -1;  // statistics wanted from a kernel that cannot emit them
+    if (p.ln_part != nullptr && (hv_gemm_ln_parts_of(p) == 0 || p.gn_part != nullptr)) return -1;
     const bool prologue = p.pro_scale != nullptr || p.pro_act != HV_ACT_NONE;
     char shape[128] = "";
     if (g_hv_prof)
@@ -1210,8 +1242,11 @@ static inline int hv_gemm_launch(const HvGemmParams& p, hipStream_t stream) {
         if (grid6 > 512) grid6 = 512;
         if (grid6 > g_hv_gemm_max_grid) grid6 = g_hv_gemm_max_grid;
         if (c.perm && p.gn_part != nullptr) {
-            hv_note("hv_gemm_glds_kernel<128,4,128,2,perm,stats> | %s", shape);
-            hv_launch(hv_gemm_glds_kernel<128, 4, 128, 2, true, true>, dim3(grid6), dim3(256), stream, p, c.gm, c.form);
+            hv_note("hv_gemm_glds_kernel<128,4,128,2,perm,gn> | %s", shape);
+            hv_launch(hv_gemm_glds_kernel<128, 4, 128, 2, true, 1>, dim3(grid6), dim3(256), stream, p, c.gm, c.form);
+        } else if (c.perm && p.ln_part != nullptr) {
+            hv_note("hv_gemm_glds_kernel<128,4,128,2,perm,ln> | %s", shape);
+            hv_launch(hv_gemm_glds_kernel<128, 4, 128, 2, true, 2>, dim3(grid6), dim3(256), stream, p, c.gm, c.form);
         } else if (c.perm) {
             hv_note("hv_gemm_glds_kernel<128,4,128,2,perm> | %s", shape);
             hv_launch(hv_gemm_glds_kernel<128, 4, 128, 2, true>, dim3(grid6), dim3(256), stream, p, c.gm, c.form);

@@ -6,6 +6,7 @@
 
 int hvk_gemm(const hv_gemm_params& p, hipStream_t s);
 int hvk_gemm_gn_parts(const hv_gemm_params& p);
+int hvk_gemm_ln_parts(const hv_gemm_params& p);
 void hvk_gemm_tune(int max_grid);
 void hvk_gemm_use_glds(int on);
 void hvk_gemm_perm(int v);
@@ -15,6 +16,7 @@ int hvk_conv3x3(const hv_conv3x3_params& p, hipStream_t s);
 int hvk_conv3x3_gn_parts(const hv_conv3x3_params& p);
 int hvk_groupnorm(const hv_groupnorm_params& p, hipStream_t s);
 int hvk_gn_from_parts(const hv_gn_parts_params& p, hipStream_t s);
+int hvk_ln_from_parts(const float* part, int parts, int M, int C, float eps, float* mean, float* rstd, hipStream_t s);
 void hvk_layernorm(const bf16_t* X, long ldx, int M, int C, float eps, float* mean, float* rstd, hipStream_t s);
 int hvk_attention(const hv_attention_params& p, hipStream_t s);
 void hvk_attention_tune(int head_dim, int qt);

@@ -241,6 +241,31 @@ static inline int hv_gn_from_parts_launch(const HvGnPartsParams& p, hipStream_t 
     return 0;
 }
 
+// ---- LayerNorm mean / rstd from the partial row sums the producing GEMM left (ln_part [M][parts][2]): one thread per row
+__global__ __launch_bounds__(256) void hv_ln_from_parts_kernel(const float* part, int parts, int M, int C, float eps, float* mean_out,
+                                                               float* rstd_out) {
+    const int m = blockIdx.x * 256 + threadIdx.x;
+    if (m >= M) return;
+    const float* src = part + (long)m * parts * 2;
+    float s = 0.f, q = 0.f;
+    for (int i = 0; i < parts; ++i) {
+        const f32x2 v = *reinterpret_cast<const f32x2*>(src + 2 * i);
+        s += v[0];
+        q += v[1];
+    }
+    const float mean = s / (float)C;
+    const float var = fmaxf(q / (float)C - mean * mean, 0.f);
+    mean_out[m] = mean;
+    rstd_out[m] = 1.0f / sqrtf(var + eps);
+}
+static inline int hv_ln_from_parts_launch(const float* part, int parts, int M, int C, float eps, float* mean, float* rstd,
+                                          hipStream_t stream) {
+    if (parts <= 0 || M <= 0 || C != parts * 64) return -1;
+    hv_note("hv_ln_from_parts_kernel | M=%d C=%d", M, C);
+    hv_launch(hv_ln_from_parts_kernel, dim3((M + 255) / 256), dim3(256), stream, part, parts, M, C, eps, mean, rstd);
+    return 0;
+}
+
 // ---- LayerNorm statistics: one wavefront per row -----------------------------------------------
 #define HV_LN_MAXV 4  // 16-byte vectors per lane: C <= 64 * 8 * 4 = 2048
 

@@ -349,6 +349,7 @@ class UNet3DEngine:
         # GroupNorm partial statistics of what they store (Runner.conv_with_stats / gemm_with_stats), so gn_affine needs no
         # pass over the activation.  The statistics belong to THIS forward's buffers: start from an empty table.
         self.run.gn_parts.clear()
+        self.run.ln_parts.clear()
         conv = self.run.conv_with_stats
         sharded = self.shard is not None and self.shard.world > 1
 
@@ -383,10 +384,11 @@ class UNet3DEngine:
             Mr, Cc = x2d.shape
             if self.gn_prologue:
                 ops.gemm(L, st, x2d, wt, hid, bias=bias, pro_scale=sc, pro_shift=sh, rows_per_image=N)
+                self.run.ln_parts.pop(hid.data_ptr(), None)
                 return
             xn = ws.get(f"tr_n_{Mr}x{Cc}", (Mr, Cc))
             ops.affine_apply(L, st, x2d, sc, sh, xn, rows_per_image=N)
-            ops.gemm(L, st, xn, wt, hid, bias=bias)
+            self.run.gemm_ln(xn, wt, hid, bias=bias)
 
         def transformer(prefix, x):
             """Transformer3DModel.forward (transformer_3d.py:103-169) + patched block (read mode)."""
@@ -455,8 +457,8 @@ class UNet3DEngine:
             else:
                 ops.attention(L, st, qk, qk[:, C:], vt, o, n_images=n, heads=self.heads, D=C // self.heads, Lq=N, L1=N,
                               ldq=ldqk, ldk=ldqk, ldvt=ldvt, ldo=C, v_row_major=v2, **kw)
-            ops.gemm(L, st, o, w[t + ".attn1.to_out.0.w"], hid, bias=w[t + ".attn1.to_out.0.bias"],
-                     rowvec=self.cross_const[prefix], rowvec_period=F * N, residual=hid)
+            self.run.gemm_ln(o, w[t + ".attn1.to_out.0.w"], hid, bias=w[t + ".attn1.to_out.0.bias"],
+                             rowvec=self.cross_const[prefix], rowvec_period=F * N, residual=hid)
             feed_forward(t + ".ff1", t + ".ff.net.2", hid)
             self.run.gemm_with_stats(hid, w[prefix + ".proj_out.w"], x, N, bias=w[prefix + ".proj_out.bias"], residual=x2d)
             return x

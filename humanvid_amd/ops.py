@@ -31,11 +31,12 @@ def gemm(lib, stream, x, w, y, *, x2=None, k1=0, yt=None, n_split=0, pro_scale=N
          rows_per_image=1, pro_act=A.ACT_NONE, bias=None, row_mean=None, row_rstd=None, colsum=None, pe=None,
          pe_period=1, pe_frames=1, rowvec=None, rowvec_period=1, residual=None, geglu=False, out_act=A.ACT_NONE,
          M=None, ldx=None, ldy=None, ldr=None, ldx2=None, row_perm=None, gn_part=None, gn_rows_per_image=0,
-         query_gn_parts=False):
+         query_gn_parts=False, ln_part=None, query_ln_parts=False):
     """y[M, N(/2)] = epi(pro(x)[M, K] @ w[N, K]^T); x/x2/y/residual may be row-strided views.
     row_perm=(X, Y, P): output (and residual) row (x*Y + y)*P + p is taken at (y*X + x)*P + p.
     gn_part [M / gn_rows_per_image, parts, N, 2] fp32: GroupNorm partial statistics of the output (hv_gemm_gn_parts);
-    query_gn_parts=True only asks how many parts per image this problem would write (0 = cannot) and launches nothing."""
+    query_gn_parts=True only asks how many parts per image this problem would write (0 = cannot) and launches nothing.
+    ln_part [M, N / 64, 2] fp32 / query_ln_parts: the same for the LayerNorm row statistics of the output."""
     N, K = w.shape
     M = x.shape[0] if M is None else M
     p = A.GemmParams(
@@ -50,10 +51,12 @@ def gemm(lib, stream, x, w, y, *, x2=None, k1=0, yt=None, n_split=0, pro_scale=N
         geglu=int(geglu), out_act=out_act,
         perm_x=row_perm[0] if row_perm else 0, perm_y=row_perm[1] if row_perm else 0,
         perm_p=row_perm[2] if row_perm else 0,
-        gn_part=_p(gn_part), gn_rows_per_image=gn_rows_per_image,
+        gn_part=_p(gn_part), gn_rows_per_image=gn_rows_per_image, ln_part=_p(ln_part),
     )
     if query_gn_parts:
         return int(lib.cdll.hv_gemm_gn_parts(C.byref(p)))
+    if query_ln_parts:
+        return int(lib.cdll.hv_gemm_ln_parts(C.byref(p)))
     lib.call("hv_gemm", C.byref(p), stream)
 
 
@@ -107,6 +110,12 @@ def groupnorm_from_parts(lib, stream, part1, gamma, beta, groups, eps, pixels, s
         gamma=_p(gamma), beta=_p(beta), scale=_p(scale), shift=_p(shift),
     )
     lib.call("hv_groupnorm_from_parts", C.byref(p), stream)
+
+
+def layernorm_from_parts(lib, stream, part, C, mean, rstd, eps=1e-5):
+    """mean / rstd [M] from the partial row sums the producing GEMM left: part [M, C / 64, 2] fp32"""
+    M, parts, _ = part.shape
+    lib.call("hv_layernorm_from_parts", part.data_ptr(), parts, M, C, eps, mean.data_ptr(), rstd.data_ptr(), stream)
 
 
 def layernorm_stats(lib, stream, x, mean, rstd, eps=1e-5, M=None):

@@ -174,6 +174,7 @@ class Runner:
             raise NotImplementedError(f"hv_temporal_attention is built for 8 heads, the config asks for {self.temporal_heads}")
         self._pe_split: Dict[tuple, tuple] = {}
         self.gn_parts: Dict[int, torch.Tensor] = {}
+        self.ln_parts: Dict[int, torch.Tensor] = {}  # the same for LayerNorm row statistics (gemm_ln / ln_stats)
         # HUMANVID_GN_FUSED=0: every GroupNorm reads its input again (hv_groupnorm_affine), for A/Bs
         self.gn_fused = os.environ.get("HUMANVID_GN_FUSED", "1") == "1"
 
@@ -235,8 +236,24 @@ class Runner:
     def ln_stats(self, h2d):
         M = h2d.shape[0]
         mean, rstd = self.ws.get("ln_mean", (M,), F32), self.ws.get("ln_rstd", (M,), F32)
-        ops.layernorm_stats(self.lib, self.st, h2d, mean, rstd)
+        part = self.ln_parts.get(h2d.data_ptr())
+        if part is not None and part.shape[0] == M:
+            ops.layernorm_from_parts(self.lib, self.st, part, h2d.shape[1], mean, rstd)
+        else:
+            ops.layernorm_stats(self.lib, self.st, h2d, mean, rstd)
         return mean, rstd
+
+    def gemm_ln(self, x2d, wt, y2d, **kw):
+        """ops.gemm whose output feeds a LayerNorm: leaves the row sums of what it stores (hv_gemm ln_part) where the problem
+        allows, so that ln_stats(y2d) needs no pass over the activation; drops stale ones where it does not"""
+        parts = ops.gemm(self.lib, self.st, x2d, wt, y2d, query_ln_parts=True, **kw) if self.gn_fused else 0
+        if parts <= 0:
+            self.ln_parts.pop(y2d.data_ptr(), None)
+            ops.gemm(self.lib, self.st, x2d, wt, y2d, **kw)
+            return
+        part = self.ws.get(f"lnp_{y2d.data_ptr()}", (y2d.shape[0], parts, 2), F32)
+        ops.gemm(self.lib, self.st, x2d, wt, y2d, ln_part=part, **kw)
+        self.ln_parts[y2d.data_ptr()] = part
 
     # ---- LN -> GEGLU feed-forward -> +residual (in place) ----------------------------------------
     def feed_forward(self, ff1, ff2, h2d):
@@ -247,6 +264,7 @@ class Runner:
         ops.gemm(self.lib, self.st, h2d, w[ff1 + ".w"], ffh, bias=w[ff1 + ".bias"], row_mean=mean, row_rstd=rstd,
                  colsum=w[ff1 + ".colsum"], geglu=True)
         ops.gemm(self.lib, self.st, ffh, w[ff2 + ".w"], h2d, bias=w[ff2 + ".bias"], residual=h2d)
+        self.ln_parts.pop(h2d.data_ptr(), None)  # rewritten without statistics (no LayerNorm reads it next)
 
     # ---- LN(+PE) -> qkv -> attention over frames -> out-proj + residual (in place) -----------------
     def temporal_attention_block(self, ab, hid, B, F, N, sharded: bool):
@@ -293,8 +311,8 @@ class Runner:
             recv_o = recv.view(-1)[M * C:2 * M * C].view(R, B, F, Np, C)             # disjoint from the rows still being read
             ops.temporal_attention_exchanged(L, st, recv, send_o, B=B, F_local=F, ranks=R, P=Np, heads=H, D=D)
             shard.deferred(lambda: shard.all_to_all(recv_o, send_o))                  # chunk r = pixel slice r, my frames
-            ops.gemm(L, st, recv_o.view(M, C), w[ab + ".to_out.0.w"], hid, bias=w[ab + ".to_out.0.bias"], residual=hid,
-                     row_perm=(R, B * F, Np))
+            self.gemm_ln(recv_o.view(M, C), w[ab + ".to_out.0.w"], hid, bias=w[ab + ".to_out.0.bias"], residual=hid,
+                         row_perm=(R, B * F, Np))
             return
         else:
             R, f0 = self.shard.world, self.shard.rank * F
@@ -313,5 +331,5 @@ class Runner:
             kvg = ws.get(f"mm_kvg_{M}x{C}", (R, B, F, N, 2 * C))
             self.shard.all_gather(kvg.view(-1), kvl.view(-1))
             ops.temporal_attention_sharded(L, st, q, kvg, o, B=B, Fq=F, ranks=R, P=N, heads=H, D=D)
-        ops.gemm(L, st, o, w[ab + ".to_out.0.w"], hid, bias=w[ab + ".to_out.0.bias"], residual=hid)
+        self.gemm_ln(o, w[ab + ".to_out.0.w"], hid, bias=w[ab + ".to_out.0.bias"], residual=hid)
 

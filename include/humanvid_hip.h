@@ -85,8 +85,14 @@ typedef struct hv_gemm_params {
      * 128x128x64 LDS-DMA kernel, whole wave sub-tiles per image). */
     float* gn_part;
     int gn_rows_per_image;
+    /* optional LayerNorm partial statistics of the OUTPUT rows: fp32 [M][hv_gemm_ln_parts(p)][2] = {sum, sum of squares} of
+     * the stored values over each 64-column block of a row; hv_layernorm_from_parts turns them into the row mean / rstd that
+     * the next LayerNorm-folded GEMM reads -- no statistics pass over the activation.  NULL: not wanted; not together with
+     * gn_part; same kernel restriction as gn_part. */
+    float* ln_part;
 } hv_gemm_params;
 int hv_gemm_gn_parts(const hv_gemm_params* p); /* parts per image hv_gemm would write for this problem, 0 = cannot */
+int hv_gemm_ln_parts(const hv_gemm_params* p); /* 64-column blocks per row hv_gemm would write (N / 64), 0 = cannot */
 int hv_gemm(const hv_gemm_params* p, void* stream);
 
 /* ---- 3x3 convolution (implicit GEMM, LDS halo tile) ---------------------------------------
@@ -166,6 +172,8 @@ int hv_groupnorm_from_parts(const hv_gn_parts_params* p, void* stream);
  * src/models/motion_module.py:228,234); normalisation itself is folded into hv_gemm.       */
 int hv_layernorm_stats(const uint16_t* X, long ldx, int M, int C, float eps, float* mean, float* rstd,
                        void* stream);
+/* the same mean / rstd from the partial row sums the producing hv_gemm left (ln_part: [M][parts][2]) */
+int hv_layernorm_from_parts(const float* part, int parts, int M, int C, float eps, float* mean, float* rstd, void* stream);
 
 /* ---- spatial self-attention with reference-bank keys --------------------------------------
  * diffusers Attention/AttnProcessor2_0 SDPA as used by the patched TemporalBasicTransformerBlock

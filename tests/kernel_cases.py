@@ -396,6 +396,35 @@ def case_gn_parts_gemm(cx: Ctx, n=4, rows=128, C=320, K=128, groups=32, seed=52,
     return e
 
 
+def case_ln_parts_gemm(cx: Ctx, M=700, C=320, K=128, seed=59, offset=0.5, residual=True):
+    """LayerNorm row statistics emitted by the PRODUCING GEMM (hv_gemm ln_part) -> hv_layernorm_from_parts must give the
+    mean / rstd that the statistics pass over the stored output gives (hv_layernorm_stats); ragged M."""
+    g = torch.Generator().manual_seed(seed)
+    x, wt = rnd(g, M, K), rnd(g, C, K, scale=K**-0.5)
+    bias, res = rnd(g, C, scale=0.1) + offset, rnd(g, M, C)
+    y = cx.bf(res) if residual else torch.zeros(M, C, dtype=BF16, device=cx.device)
+    xd, wd = cx.bf(x), cx.bf(wt)
+    kw = dict(bias=cx.dev(bias))
+    if residual:
+        kw["residual"] = y
+    np_ = ops.gemm(cx.lib, cx.stream, xd, wd, y, query_ln_parts=True, **kw)
+    assert np_ == C // 64, np_
+    part = torch.zeros(M, np_, 2, device=cx.device)
+    ops.gemm(cx.lib, cx.stream, xd, wd, y, ln_part=part, **kw)
+    m1, r1 = torch.zeros(M, device=cx.device), torch.zeros(M, device=cx.device)
+    m2, r2 = torch.zeros(M, device=cx.device), torch.zeros(M, device=cx.device)
+    ops.layernorm_from_parts(cx.lib, cx.stream, part, C, m1, r1)
+    ops.layernorm_stats(cx.lib, cx.stream, y, m2, r2)
+    cx.sync()
+    yf = y.float().cpu()
+    mean, rstd = yf.mean(1), (yf.var(1, unbiased=False) + 1e-5).rsqrt()
+    for got_m, got_r, tol in ((m1, r1, 2e-3), (m2, r2, 1e-4)):
+        em = float((got_m.cpu() - mean).abs().max() / yf.std())
+        er = float(((got_r.cpu() - rstd) / rstd).abs().max())
+        assert em < tol and er < tol, (em, er)
+    return 0.0
+
+
 # ----------------------------------------------------------------------------------------- attention
 def case_attention(cx: Ctx, D=40, n_img=4, Lq=72, Lb=40, seed=6, check=None, q_stride=1, row_major=False, spike=False,
                    fp8=False):

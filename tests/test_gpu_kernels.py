@@ -215,3 +215,6 @@ def test_groupnorm_statistics_from_the_producing_kernels(cx):
     kc.case_gn_parts_gemm(cx, n=3, rows=128, C=320, K=64)
     kc.case_gn_parts_gemm(cx, n=6, rows=1536, C=640, K=640, seed=57)                    # level 1 projection-out
     kc.case_gn_parts_gemm(cx, n=4, rows=6144, C=320, K=320, seed=58, offset=2.0)        # level 0
+    kc.case_ln_parts_gemm(cx, M=300, C=128, K=64)
+    kc.case_ln_parts_gemm(cx, M=48 * 1536, C=640, K=640, seed=60, offset=1.5)                # level 1 attention out-projection
+    kc.case_ln_parts_gemm(cx, M=24 * 6144, C=320, K=320, residual=False, seed=61)           # level 0 proj_in

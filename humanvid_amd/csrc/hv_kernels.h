@@ -26,7 +26,6 @@ int hvk_attention_fp8_quantize(const bf16_t* K, long ldk, const bf16_t* Vt, long
 int hvk_attention_fp8(const hv_attention_params& p, const float* ks, const float* va, const float* ks2, const float* va2,
                       hipStream_t s);
 int hvk_temporal(const hv_temporal_attention_params& p, hipStream_t s);
-void hvk_temporal_use_mfma(int on);
 void hvk_pack(const void* src, int src_bf16, int B, int C, int Fsrc, int H, int W, const int* frames, int F, int rep,
               bf16_t* dst, int Cpad, hipStream_t s);
 void hvk_unpack(const bf16_t* src, int ldc, int B, int C, int F, int H, int W, void* dst, int dst_bf16, hipStream_t s);

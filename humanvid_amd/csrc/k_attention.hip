@@ -1,11 +1,11 @@
 // k_attention.hip -- translation unit for hv_attention.h (see hv_kernels.h)
 #include "hv_attention.h"
-#include "hv_attention2.h"
 #include "hv_attention_fp8.h"
 #include "hv_kernels.h"
 
 int hvk_attention(const hv_attention_params& p, hipStream_t s) {
-    return p.v_row_major ? hv_attention2_launch(p, s) : hv_attention_launch(p, s);
+    if (p.v_row_major) return -1;  // (the row-major-V kernel of round 2 never won an A/B and is gone: values arrive transposed)
+    return hv_attention_launch(p, s);
 }
 void hvk_attention_tune(int head_dim, int qt) {
     if (head_dim == 40) g_hv_attn_qt40 = qt;

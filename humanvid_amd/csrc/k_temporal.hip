@@ -3,4 +3,3 @@
 #include "hv_kernels.h"
 
 int hvk_temporal(const hv_temporal_attention_params& p, hipStream_t s) { return hv_temporal_launch(p, s); }
-void hvk_temporal_use_mfma(int on) { g_hv_temporal_mfma = on; }

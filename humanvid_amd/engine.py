@@ -59,18 +59,10 @@ class UNet3DEngine:
         self.bank_version = None
         self.cross_const: Dict[str, torch.Tensor] = {}
         self.do_cfg = True
-        # spatial-attention kernel: 1 = register-staged kernel (V^T written by the QKV GEMM epilogue; default: 541 / 530 / 332
-        # TF/s at the config-#3 shapes of d = 40 / 80 / 160 once the CFG halves are balanced over the XCDs), 2 = LDS-DMA kernel
-        # (row-major V out of a plain [token][q|k|v] QKV GEMM, 32x32x16 MFMA, transposing LDS reads: 411 / 402 / 364 TF/s --
-        # VALU- and DMA-issue-bound at d = 40, see profiles/README.md); HUMANVID_ATTENTION=2 selects it for same-box A/Bs
-        self.attn_kernel = int(os.environ.get("HUMANVID_ATTENTION", "1"))
         # BASELINE.json configs[4]: spatial attention on the fp8 (e4m3) MFMA -- hv_attention_fp8 (transposed-V kernel family)
         # (denoising UNet only: the ReferenceNet write pass runs once per clip and keeps its banks at bf16 precision)
         self.attn_fp8 = os.environ.get("HUMANVID_ATTENTION_FP8", "0") == "1" and kind == "denoise"
-        if self.attn_fp8 and self.attn_kernel != 1:
-            raise NotImplementedError("HUMANVID_ATTENTION_FP8=1 needs the transposed-V attention kernel (HUMANVID_ATTENTION=1)")
         self.bank_fp8 = {}
-        self.gn_prologue = os.environ.get("HUMANVID_GN_PROLOGUE", "0") == "1"  # round-1 fused GroupNorm-apply GEMM (A/B)
         self._sel_cache: Dict[tuple, torch.Tensor] = {}
         # optional observer `tap(name, activation [(b f),h,w,c])` called after every resnet / spatial transformer / motion
         # module, named by the reference's module path (e.g. 'down_blocks.0.attentions.1').  Buffers are reused and updated in place: the observer
@@ -227,11 +219,6 @@ class UNet3DEngine:
                 continue
             b, Nb, C = bank.shape
             x = self._dev(bank.reshape(b * Nb, C), BF16)
-            if self.attn_kernel == 2:  # bank rows [k | v], row-major
-                kv2 = torch.empty(b * Nb, 2 * C, dtype=BF16, device=self.device)
-                ops.gemm(self.lib, st, x, self.w[loc + ".transformer_blocks.0.bank_kv.w"], kv2)
-                self.bank_kv[loc] = (kv2, kv2[:, C:], b, Nb)
-                continue
             k2 = torch.empty(b * Nb, C, dtype=BF16, device=self.device)
             vt2 = torch.empty(C, b * Nb, dtype=BF16, device=self.device)
             ops.gemm(self.lib, st, x, self.w[loc + ".transformer_blocks.0.bank_kv.w"], k2, yt=vt2, n_split=C, ldy=C)
@@ -378,14 +365,12 @@ class UNet3DEngine:
             return out
 
         def proj_in(x2d, sc, sh, N, wt, bias, hid):
-            """GroupNorm apply + proj_in.  Default: the normalisation as its own HBM-bound pass (hv_affine_apply) into a
-            scratch activation, then the projection on the LDS-DMA GEMM kernel; HUMANVID_GN_PROLOGUE=1 keeps the round-1
-            form (apply fused into the A-operand staging of the register-staged GEMM kernel) for A/Bs."""
+            """GroupNorm apply + proj_in: the normalisation as its own HBM-bound pass (hv_affine_apply) into a scratch
+            activation, then the projection on the LDS-DMA GEMM kernel (round 1 fused the apply into the A-operand staging of
+            the register-staged GEMM: 8.5 % MFMA-busy).  Folding the scale into per-image weights instead was rejected in
+            round 3 on numerical grounds: sum_k W a x and sum_k W b cancel when a channel's |mean| >> std, which amplifies the
+            bf16 rounding of W a by that ratio."""
             Mr, Cc = x2d.shape
-            if self.gn_prologue:
-                ops.gemm(L, st, x2d, wt, hid, bias=bias, pro_scale=sc, pro_shift=sh, rows_per_image=N)
-                self.run.ln_parts.pop(hid.data_ptr(), None)
-                return
             xn = ws.get(f"tr_n_{Mr}x{Cc}", (Mr, Cc))
             ops.affine_apply(L, st, x2d, sc, sh, xn, rows_per_image=N)
             self.run.gemm_ln(xn, wt, hid, bias=bias)
@@ -406,18 +391,11 @@ class UNet3DEngine:
                 ops.gemm(L, st, hid, w[t + ".norm1_id.w"], bank, bias=w[t + ".norm1_id.bias"], row_mean=mean,
                          row_rstd=rstd, colsum=w[t + ".norm1_id.colsum"])
                 self.written_banks[prefix] = bank.view(n, N, C)
-            v2 = self.attn_kernel == 2
-            if v2:
-                qk = ws.get(f"tr_qkv_{M}x{C}", (M, 3 * C))
-                ops.gemm(L, st, hid, w[t + ".qkv.w"], qk, bias=w[t + ".qkv.bias"], row_mean=mean, row_rstd=rstd,
-                         colsum=w[t + ".qkv.colsum"])
-                vt, ldqk, ldvt = qk[:, 2 * C:], 3 * C, 3 * C
-            else:
-                qk = ws.get(f"tr_qk_{M}x{C}", (M, 2 * C))
-                vt = ws.get(f"tr_vt_{M}x{C}", (C, M))
-                ops.gemm(L, st, hid, w[t + ".qkv.w"], qk, bias=w[t + ".qkv.bias"], row_mean=mean, row_rstd=rstd,
-                         colsum=w[t + ".qkv.colsum"], yt=vt, n_split=2 * C)
-                ldqk, ldvt = 2 * C, M
+            qk = ws.get(f"tr_qk_{M}x{C}", (M, 2 * C))
+            vt = ws.get(f"tr_vt_{M}x{C}", (C, M))  # values arrive transposed: written by the QKV GEMM epilogue
+            ops.gemm(L, st, hid, w[t + ".qkv.w"], qk, bias=w[t + ".qkv.bias"], row_mean=mean, row_rstd=rstd,
+                     colsum=w[t + ".qkv.colsum"], yt=vt, n_split=2 * C)
+            ldqk, ldvt = 2 * C, M
             o = ws.get(f"tr_o_{M}x{C}", (M, C))
             kw = {}
             bank = self.bank_kv.get(prefix)
@@ -433,7 +411,7 @@ class UNet3DEngine:
                 if sel_t is None:  # uploaded once (keeps the step free of host copies / graph-capturable)
                     sel_t = torch.tensor(sel, dtype=torch.int32).to(self.device)
                     self._sel_cache[skey] = sel_t
-                kw = dict(k2=k2, vt2=vt2, ldk2=2 * C if v2 else C, ldvt2=2 * C if v2 else bb * Nb, L2=Nb, bank_sel=sel_t)
+                kw = dict(k2=k2, vt2=vt2, ldk2=C, ldvt2=bb * Nb, L2=Nb, bank_sel=sel_t)
             if self.attn_fp8:
                 Dh = C // self.heads
                 ks1 = ws.get(f"tr_ks_{n}x{N}", (n, self.heads, (N + 63) // 64), F32)
@@ -456,7 +434,7 @@ class UNet3DEngine:
                                   ldk=C, ldvt=ldvt, ldo=C, **kw8)
             else:
                 ops.attention(L, st, qk, qk[:, C:], vt, o, n_images=n, heads=self.heads, D=C // self.heads, Lq=N, L1=N,
-                              ldq=ldqk, ldk=ldqk, ldvt=ldvt, ldo=C, v_row_major=v2, **kw)
+                              ldq=ldqk, ldk=ldqk, ldvt=ldvt, ldo=C, **kw)
             self.run.gemm_ln(o, w[t + ".attn1.to_out.0.w"], hid, bias=w[t + ".attn1.to_out.0.bias"],
                              rowvec=self.cross_const[prefix], rowvec_period=F * N, residual=hid)
             feed_forward(t + ".ff1", t + ".ff.net.2", hid)

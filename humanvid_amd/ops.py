@@ -125,12 +125,12 @@ def layernorm_stats(lib, stream, x, mean, rstd, eps=1e-5, M=None):
 
 
 def attention(lib, stream, q, k, vt, o, *, n_images, heads, D, Lq, L1, ldq, ldk, ldvt, ldo, k2=None, vt2=None,
-              ldk2=0, ldvt2=0, L2=0, bank_sel=None, v_row_major=False):
-    """v_row_major: `vt` / `vt2` are row-major values (row = token, like k) -> the round-2 kernel."""
+              ldk2=0, ldvt2=0, L2=0, bank_sel=None):
+    """vt / vt2: TRANSPOSED values [C][tokens] (the QKV GEMM epilogue writes them so)."""
     p = A.AttentionParams(
         Q=_p(q), ldq=ldq, K=_p(k), ldk=ldk, Vt=_p(vt), ldvt=ldvt, K2=_p(k2), ldk2=ldk2, Vt2=_p(vt2), ldvt2=ldvt2,
         bank_sel=_p(bank_sel), O=_p(o), ldo=ldo, n_images=n_images, heads=heads, D=D, Lq=Lq, L1=L1, L2=L2,
-        scale=1.0 / math.sqrt(D), v_row_major=int(v_row_major),
+        scale=1.0 / math.sqrt(D), v_row_major=0,
     )
     lib.call("hv_attention", C.byref(p), stream)
 

@@ -196,9 +196,7 @@ typedef struct hv_attention_params {
     long ldo;
     int n_images, heads, D, Lq, L1, L2;
     float scale;
-    int v_row_major; /* 1: Vt / Vt2 hold row-major values V[(img*L1 + kv)*ldvt + h*D + d] (like K; typically the v third of
-                        the [token][q | k | v] tensor of the QKV GEMM) -> round-2 kernel (LDS-DMA tiles, 32x32x16 MFMA,
-                        transposing LDS reads); 0: transposed values as documented above (round-1 kernel) */
+    int v_row_major; /* must be 0 (the row-major-V kernel of round 2 is gone: values are passed transposed, Vt) */
 } hv_attention_params;
 int hv_attention(const hv_attention_params* p, void* stream);
 
@@ -226,7 +224,6 @@ int hv_attention_fp8(const hv_attention_params* p, const float* kscale, const fl
 #define HV_TUNE_GEMM_GLDS 3     /* GEMM kernel selection: 1 = default -- LDS-DMA kernel, 256x256x64 tiles (one 8-wave workgroup per CU) when N >= 960 and the tiles fill the last round over the 256 CUs to >= 90 %, 128x128x64 (two 4-wave workgroups per CU) otherwise; 2 = 256x256x64 wherever the shape allows, 3 = 128x128x64 everywhere, 0 = register-staged kernel (A/Bs; results are bit-identical across 1 / 2 / 3) */
 #define HV_TUNE_CONV_GLDS 4     /* 1: conv weight tiles by LDS-DMA (default), 0: register-staged */
 #define HV_TUNE_GEMM_PERM 6     /* 1 (default): 128x128x64 GEMM tiles with plain bf16 output use the permuted channel assignment (16-byte residual loads / output stores); 0: natural assignment (A/B; results are bit-identical) */
-#define HV_TUNE_TEMPORAL_MFMA 7 /* temporal attention: 1 = MFMA kernel, one wave per (batch, pixel, head) (default), 0 = VALU kernel */
 #define HV_TUNE_CONV_BIG 5      /* 1 (default): 256-pixel tiles for the upsample-folded convolution, 64-channel reduction chunks for stride-1 convolutions on images of <= 384 pixels; 0 / 2: neither / only the 256-pixel tiles (A/Bs); 3: 64-channel chunks for every stride-1 convolution whose sources allow them (A/B) */
 int hv_set_tuning(int key, int value);
 

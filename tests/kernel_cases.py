@@ -426,7 +426,7 @@ def case_ln_parts_gemm(cx: Ctx, M=700, C=320, K=128, seed=59, offset=0.5, residu
 
 
 # ----------------------------------------------------------------------------------------- attention
-def case_attention(cx: Ctx, D=40, n_img=4, Lq=72, Lb=40, seed=6, check=None, q_stride=1, row_major=False, spike=False,
+def case_attention(cx: Ctx, D=40, n_img=4, Lq=72, Lb=40, seed=6, check=None, q_stride=1, spike=False,
                    fp8=False):
     """images [0, n/2) are CFG-unconditional (own keys only); the rest append bank batch 1.
     check / q_stride: images and query rows the CPU reference is evaluated on (the kernel runs everything).
@@ -459,13 +459,7 @@ def case_attention(cx: Ctx, D=40, n_img=4, Lq=72, Lb=40, seed=6, check=None, q_s
         o = F.scaled_dot_product_attention(heads(q[i : i + 1, ::q_stride]), kk, vv)
         ref[j] = o.transpose(1, 2).reshape(-1, Cc)
     o = torch.zeros(n_img * Lq, Cc, dtype=BF16, device=cx.device)
-    if row_major:  # round-2 kernel: [token][q | k | v] rows as the QKV GEMM writes them, bank rows [k | v]
-        qkv = cx.bf(torch.cat([q, k, v], dim=-1).view(n_img * Lq, 3 * Cc))
-        kv2 = cx.bf(torch.cat([kb, vb], dim=-1).view(2 * Lb, 2 * Cc))
-        ops.attention(cx.lib, cx.stream, qkv, qkv[:, Cc:], qkv[:, 2 * Cc:], o, n_images=n_img, heads=H, D=D, Lq=Lq, L1=Lq,
-                      ldq=3 * Cc, ldk=3 * Cc, ldvt=3 * Cc, ldo=Cc, k2=kv2, vt2=kv2[:, Cc:], ldk2=2 * Cc, ldvt2=2 * Cc,
-                      L2=Lb, bank_sel=cx.dev(sel), v_row_major=True)
-    else:
+    if True:
         qkv = cx.bf(torch.cat([q, k], dim=-1).view(n_img * Lq, 2 * Cc))  # q | k interleaved rows, ld = 2C
         vt = cx.bf(v.reshape(n_img * Lq, Cc).t())  # [C][n*Lq]
         k2 = cx.bf(kb.reshape(2 * Lb, Cc))
@@ -504,7 +498,8 @@ def case_attention(cx: Ctx, D=40, n_img=4, Lq=72, Lb=40, seed=6, check=None, q_s
     # expected ~ sqrt(2 * 0.036^2 [QK^T] + 0.036^2 [P] + 0.036^2 [V]) ~ 7e-2 worst case, measured 4-5e-2; the bound on the
     # DENOISER's output with fp8 attention (residual stream, structured activations) is the one that matters and is stated
     # and tested separately (tests/test_gpu_fullwidth.py::test_fp8_attention_forward: <= 3e-2 against the fp32 oracle).
-    tol = 8e-2 if fp8 else 6e-3
+    # (measured 4.9e-2 ... 5.5e-2 on MI355X at every tested geometry; the bound is that + 20 %)
+    tol = 6.6e-2 if fp8 else 6e-3
     assert e < tol, f"attention D={D} fp8={fp8} nrmse {e}"
     return e
 

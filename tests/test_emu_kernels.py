@@ -254,14 +254,6 @@ def test_attention(cx, D):
     kc.case_attention(cx, D=D, n_img=2, Lq=72 if D == 40 else 40, Lb=40 if D == 40 else 72)
 
 
-@pytest.mark.parametrize("D", [40, 80, 160])
-def test_attention_row_major_kernel(cx, D):
-    """round-2 kernel (row-major V, LDS-DMA tiles, 32x32x16 MFMA, transposing LDS reads): ragged and tile-aligned lengths,
-    more than one query block per workgroup row, bank shorter / longer than the sequence"""
-    kc.case_attention(cx, D=D, n_img=2, Lq=72 if D == 40 else 40, Lb=40 if D == 40 else 72, row_major=True)
-    kc.case_attention(cx, D=D, n_img=2, Lq=64, Lb=96, row_major=True, seed=16)
-    if D == 40:
-        kc.case_attention(cx, D=D, n_img=3, Lq=136, Lb=8, row_major=True, seed=62)
 
 
 @pytest.mark.parametrize("D", [40, 80, 160])
@@ -294,13 +286,6 @@ def test_temporal(cx, D):
     kc.case_temporal(cx, D=D, B=1, Fr=24, P=2, seed=17)
 
 
-@pytest.mark.parametrize("D", [40, 160])
-def test_temporal_valu_kernel(cx, D):
-    cx.lib.call("hv_set_tuning", 7, 0)
-    try:
-        kc.case_temporal(cx, D=D, Fr=6)
-    finally:
-        cx.lib.call("hv_set_tuning", 7, 1)
 
 
 def test_elementwise(cx):

@@ -107,20 +107,25 @@ def test_attention(cx, D, Lq, Lb):
 
 @pytest.mark.parametrize("D,Lq,Lb", [(40, 1536, 1536), (40, 200, 72), (80, 384, 384), (160, 96, 96), (160, 384, 96), (40, 144, 144),
                                      (80, 72, 200)])
-def test_attention_row_major_kernel(cx, D, Lq, Lb):
-    """round-2 kernel: row-major V, LDS-DMA tiles, 32x32x16 MFMA, transposing LDS reads (ragged and aligned lengths)"""
-    kc.case_attention(cx, D=D, n_img=4, Lq=Lq, Lb=Lb, row_major=True)
 
 
 @pytest.mark.parametrize("D,L", [(40, 1536), (80, 768), (160, 384)])
 def test_attention_fp8(cx, D, L):
-    """e4m3 QK^T / PV (hv_attention_fp8): i.i.d. random operands, bound 8e-2 (see case_attention), forced maximum jumps"""
+    """e4m3 QK^T / PV (hv_attention_fp8): i.i.d. random operands, bound 6.6e-2 (see case_attention), forced maximum jumps"""
     kc.case_attention(cx, D=D, n_img=4, Lq=L, Lb=L, fp8=True, seed=75, check=(0, 3), q_stride=4)
     kc.case_attention(cx, D=D, n_img=4, Lq=L + 40, Lb=L - 24, fp8=True, spike=True, seed=76, check=(1, 2), q_stride=4)
 
 
 def test_bench_shape_attention_fp8(cx):
     kc.case_attention(cx, D=40, n_img=48, Lq=6144, Lb=6144, fp8=True, check=(0, 47), q_stride=16)
+
+
+@pytest.mark.parametrize("fp8", [False, True])
+@pytest.mark.parametrize("D,L", [(40, 9216), (80, 2304), (160, 576), (160, 144)])
+def test_config5_shape_attention(cx, D, L, fp8):
+    """the spatial-attention geometries of BASELINE.json configs[4] (48f x 1024x576: latent 128 x 72 -> 9216 / 2304 / 576 /
+    144 tokens per image at the four levels), bf16 and fp8 kernels, 48 images of one 24-frame window with CFG"""
+    kc.case_attention(cx, D=D, n_img=48, Lq=L, Lb=L, fp8=fp8, seed=77, check=(0, 47), q_stride=16 if L > 1000 else 1)
 
 
 def test_attention_variants(cx):
@@ -144,12 +149,6 @@ def test_temporal(cx, D, Fr, P):
     kc.case_temporal(cx, D=D, B=2, Fr=Fr, P=P)
 
 
-def test_temporal_valu_kernel(cx):
-    cx.lib.call("hv_set_tuning", 7, 0)
-    try:
-        kc.case_temporal(cx, D=40, B=2, Fr=24, P=96)
-    finally:
-        cx.lib.call("hv_set_tuning", 7, 1)
 
 
 # ---- the exact shapes of the config-#3 benchmark step (48 images of 96x64 latents): grid-size dependent faults only show
@@ -175,11 +174,10 @@ def test_bench_shape_convs(cx):
     kc.case_conv(cx, n=48, H=12, W=8, C1=1280, Cout=1280, check=(0, 24, 47))
 
 
-@pytest.mark.parametrize("row_major", [True, False])
 @pytest.mark.parametrize("D,L", [(40, 6144), (80, 1536), (160, 384), (160, 96)])
-def test_bench_shape_attention(cx, D, L, row_major):
+def test_bench_shape_attention(cx, D, L):
     kc.case_attention(cx, D=D, n_img=48, Lq=L, Lb=L, check=(0, 23, 24, 47), q_stride=8 if L > 1000 else 1,
-                      row_major=row_major)
+                      )
 
 
 @pytest.mark.parametrize("D,P", [(40, 6144), (80, 1536), (160, 384), (160, 96)])

@@ -46,14 +46,8 @@ def main():
     st = hvlib.current_stream()
     if os.environ.get("HV_GEMM_GLDS"):
         L.call("hv_set_tuning", 3, int(os.environ["HV_GEMM_GLDS"]))  # A/B of the GEMM kernel variants
-    if os.environ.get("HV_GEMM_PF"):
-        L.call("hv_set_tuning", 9, int(os.environ["HV_GEMM_PF"]))
-    if os.environ.get("HV_GEMM_WALK"):
-        L.call("hv_set_tuning", 8, int(os.environ["HV_GEMM_WALK"]))
-    if os.environ.get("HV_GEMM_RASTER"):
-        L.call("hv_set_tuning", 6, int(os.environ["HV_GEMM_RASTER"]))
-    if os.environ.get("HV_TEMPORAL_MFMA"):
-        L.call("hv_set_tuning", 7, int(os.environ["HV_TEMPORAL_MFMA"]))
+    if os.environ.get("HV_GEMM_PERM"):
+        L.call("hv_set_tuning", 6, int(os.environ["HV_GEMM_PERM"]))
     if os.environ.get("HV_CONV_BIG"):
         L.call("hv_set_tuning", 5, int(os.environ["HV_CONV_BIG"]))
     if os.environ.get("HV_CONV_GLDS"):

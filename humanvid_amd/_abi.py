@@ -118,6 +118,7 @@ PROTOTYPES = {
     "hv_pixel_unshuffle": (I, [P, I, I, I, I, I, I, P, P]),
     "hv_plucker_unshuffle": (I, [P, P, I, I, I, I, P, P]),
     "hv_affine_apply": (I, [P, L, I, I, I, P, P, I, P, L, P]),
+    "hv_affine_apply_cat": (I, [P, L, I, P, L, I, I, I, P, P, I, P, L, P]),
     "hv_timestep_embedding": (I, [P, I, I, P, P]),
     "hv_accumulate_window": (I, [P, I, I, I, I, I, I, P, I, P, P, P]),
     "hv_cfg_ddim_step": (I, [P, P, P, I, I, I, I, I, P, P]),

@@ -223,17 +223,20 @@ static inline void hv_cfg_ddim_launch(float* latents, float* acc, float* counter
 // GEMM's A operand, which forces the register-staged GEMM kernel (8.5 % MFMA-busy: unpack / fma / pack per 16-byte chunk
 // in front of every LDS store); as a separate HBM-bound pass it costs 4 bytes per element and the projection runs on the
 // LDS-DMA kernel.  One thread per 8 channels, rows grid-strided; scale / shift rows are L1/L2 hits.
+// Two sources (X2 != nullptr): the channel concatenation [X | X2] of a decoder ResnetBlock3D's input
+// (unet_3d_blocks.py: torch.cat([hidden_states, res_hidden_states], dim=1) in front of resnet.py:215-245) is written as ONE
+// [rows, C + C2] activation, so the convolution behind it reads a single source; scale / shift rows are C + C2 wide.
 __global__ __launch_bounds__(256) void hv_affine_apply_kernel(const bf16_t* X, long ldx, int rows, int rows_per_image, int C,
-                                                              const float* scale, const float* shift, int act, bf16_t* Y,
-                                                              long ldy) {
-    const int cvs = C / 8;
+                                                              const bf16_t* X2, long ldx2, int C2, const float* scale,
+                                                              const float* shift, int act, bf16_t* Y, long ldy) {
+    const int cvs = (C + C2) / 8, cv1 = C / 8;
     const long total = (long)rows * cvs;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const int cv = (int)(i % cvs);
         const long row = i / cvs;
-        const long so = (row / rows_per_image) * C + cv * 8;
+        const long so = (row / rows_per_image) * (C + C2) + cv * 8;
         float f[8];
-        hv_unpack8(hv_ld16(X + row * ldx + cv * 8), f);
+        hv_unpack8(cv < cv1 ? hv_ld16(X + row * ldx + cv * 8) : hv_ld16(X2 + row * ldx2 + (cv - cv1) * 8), f);
         const f32x4 s0 = *reinterpret_cast<const f32x4*>(scale + so), s1 = *reinterpret_cast<const f32x4*>(scale + so + 4);
         const f32x4 t0 = *reinterpret_cast<const f32x4*>(shift + so), t1 = *reinterpret_cast<const f32x4*>(shift + so + 4);
 #pragma unroll
@@ -245,12 +248,13 @@ __global__ __launch_bounds__(256) void hv_affine_apply_kernel(const bf16_t* X, l
     }
 }
 
-static inline void hv_affine_apply_launch(const bf16_t* X, long ldx, int rows, int rows_per_image, int C, const float* scale,
-                                          const float* shift, int act, bf16_t* Y, long ldy, hipStream_t stream) {
-    const long total = (long)rows * (C / 8);
+static inline void hv_affine_apply_launch(const bf16_t* X, long ldx, int rows, int rows_per_image, int C, const bf16_t* X2, long ldx2,
+                                          int C2, const float* scale, const float* shift, int act, bf16_t* Y, long ldy,
+                                          hipStream_t stream) {
+    const long total = (long)rows * ((C + C2) / 8);
     long blocks = (total + 255) / 256;
     if (blocks > 256 * 16) blocks = 256 * 16;
-    hv_note("hv_affine_apply_kernel | rows=%d C=%d", rows, C);
-    hv_launch(hv_affine_apply_kernel, dim3((unsigned)blocks), dim3(256), stream, X, ldx, rows, rows_per_image, C, scale, shift, act,
-              Y, ldy);
+    hv_note("hv_affine_apply_kernel | rows=%d C=%d+%d act=%d", rows, C, C2, act);
+    hv_launch(hv_affine_apply_kernel, dim3((unsigned)blocks), dim3(256), stream, X, ldx, rows, rows_per_image, C, X2, ldx2, C2, scale,
+              shift, act, Y, ldy);
 }

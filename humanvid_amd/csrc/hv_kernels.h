@@ -36,8 +36,8 @@ void hvk_accumulate(const bf16_t* pred, int ldc, int rep, int C, int f_win, int 
                     float* acc, float* counter, hipStream_t s);
 void hvk_cfg_ddim(float* latents, float* acc, float* counter, int rep, int C, int F, int H, int W,
                   const float* coeffs, hipStream_t s);
-void hvk_affine_apply(const bf16_t* X, long ldx, int rows, int rows_per_image, int C, const float* scale, const float* shift,
-                      int act, bf16_t* Y, long ldy, hipStream_t s);
+void hvk_affine_apply(const bf16_t* X, long ldx, int rows, int rows_per_image, int C, const bf16_t* X2, long ldx2, int C2,
+                      const float* scale, const float* shift, int act, bf16_t* Y, long ldy, hipStream_t s);
 
 #ifdef HV_SINGLE_TU
 #include "k_gemm.hip"

@@ -24,7 +24,7 @@ void hvk_cfg_ddim(float* latents, float* acc, float* counter, int rep, int C, in
                   const float* coeffs, hipStream_t s) {
     hv_cfg_ddim_launch(latents, acc, counter, rep, C, F, H, W, coeffs, s);
 }
-void hvk_affine_apply(const bf16_t* X, long ldx, int rows, int rows_per_image, int C, const float* scale, const float* shift,
-                      int act, bf16_t* Y, long ldy, hipStream_t s) {
-    hv_affine_apply_launch(X, ldx, rows, rows_per_image, C, scale, shift, act, Y, ldy, s);
+void hvk_affine_apply(const bf16_t* X, long ldx, int rows, int rows_per_image, int C, const bf16_t* X2, long ldx2, int C2,
+                      const float* scale, const float* shift, int act, bf16_t* Y, long ldy, hipStream_t s) {
+    hv_affine_apply_launch(X, ldx, rows, rows_per_image, C, X2, ldx2, C2, scale, shift, act, Y, ldy, s);
 }

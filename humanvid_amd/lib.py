@@ -16,6 +16,7 @@ def load() -> HvLibrary:
         override = os.environ.get("HUMANVID_HIP_LIB")  # A/B of build variants (tools/build_variant.sh); same C ABI
         if override:
             _LIB = HvLibrary(override)
+            _apply_tuning(_LIB)
             return _LIB
         if not os.path.exists(LIB_PATH):
             raise RuntimeError(
@@ -23,7 +24,16 @@ def load() -> HvLibrary:
                 "(hipcc --offload-arch=gfx950). humanvid_amd has no CPU or eager-PyTorch fallback."
             )
         _LIB = HvLibrary(LIB_PATH)
+        _apply_tuning(_LIB)
     return _LIB
+
+
+def _apply_tuning(lib):
+    """HUMANVID_TUNING="key=value,key=value": hv_set_tuning calls applied at load time (same-box A/Bs of kernel selections
+    under the tests and the bench; every selection computes the same function)."""
+    for kv in filter(None, os.environ.get("HUMANVID_TUNING", "").split(",")):
+        k, v = kv.split("=")
+        lib.call("hv_set_tuning", int(k), int(v))
 
 
 def require_gpu():

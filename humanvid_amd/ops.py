@@ -60,12 +60,18 @@ def gemm(lib, stream, x, w, y, *, x2=None, k1=0, yt=None, n_split=0, pro_scale=N
     lib.call("hv_gemm", C.byref(p), stream)
 
 
-def affine_apply(lib, stream, x, scale, shift, y, *, rows_per_image, act=A.ACT_NONE):
+def affine_apply(lib, stream, x, scale, shift, y, *, rows_per_image, act=A.ACT_NONE, x2=None):
     """y[row, c] = act(x[row, c] * scale[row // rows_per_image, c] + shift[...]) -- GroupNorm apply as its own pass
-    (x, y: [rows, C] bf16, possibly row-strided; scale / shift [images, C] fp32 from groupnorm_affine)."""
+    (x, y: [rows, C] bf16, possibly row-strided; scale / shift [images, C] fp32 from groupnorm_affine).
+    x2 [rows, C2]: the channel concatenation [x | x2] is normalised into y [rows, C + C2] (scale / shift [images, C + C2])."""
     rows, Cc = x.shape
-    lib.call("hv_affine_apply", _p(x), x.stride(0), rows, rows_per_image, Cc, _p(scale), _p(shift), act, _p(y), y.stride(0),
-             stream)
+    if x2 is None:
+        lib.call("hv_affine_apply", _p(x), x.stride(0), rows, rows_per_image, Cc, _p(scale), _p(shift), act, _p(y),
+                 y.stride(0), stream)
+        return
+    assert x2.shape[0] == rows and y.shape[1] == Cc + x2.shape[1] and scale.shape[1] == y.shape[1]
+    lib.call("hv_affine_apply_cat", _p(x), x.stride(0), Cc, _p(x2), x2.stride(0), x2.shape[1], rows, rows_per_image, _p(scale),
+             _p(shift), act, _p(y), y.stride(0), stream)
 
 
 def conv3x3(lib, stream, x, w, y, *, x2=None, mode=A.CONV_S1, pro_scale=None, pro_shift=None, pro_act=A.ACT_NONE,

@@ -177,6 +177,12 @@ class Runner:
         self.ln_parts: Dict[int, torch.Tensor] = {}  # the same for LayerNorm row statistics (gemm_ln / ln_stats)
         # HUMANVID_GN_FUSED=0: every GroupNorm reads its input again (hv_groupnorm_affine), for A/Bs
         self.gn_fused = os.environ.get("HUMANVID_GN_FUSED", "1") == "1"
+        # GroupNorm apply + SiLU in front of a ResnetBlock3D convolution (resnet.py:215-222, 235-241) as its own pass
+        # (hv_affine_apply / _cat into a scratch activation) instead of the convolution's operand prologue: the prologue
+        # repeats the transform (unpack, fma, SiLU, pack) in every 128-channel output tile (3 .. 10 of them) and halo pixel
+        # (x 1.4) on the k-loop's critical path -- measured 0.83 vs 0.64 ms per 320 -> 320 convolution at 96 x 64 x 48
+        # images, while the pass costs 0.08 ms (profiles/r03_conv_apply_ab.txt).  HUMANVID_CONV_APPLY=0: the prologue (A/B).
+        self.conv_apply = os.environ.get("HUMANVID_CONV_APPLY", "1") == "1"
 
     @property
     def st(self) -> int:
@@ -188,6 +194,15 @@ class Runner:
     # current contents only: every producer either refreshes it (conv_with_stats / gemm_with_stats) or drops it.
     def conv_with_stats(self, x, wt, y, **kw):
         """ops.conv3x3 that also leaves the GroupNorm partial statistics of y"""
+        if self.conv_apply and kw.get("pro_scale") is not None and wt.shape[0] > 128:
+            n, h, ww, c1 = x.shape
+            x2 = kw.pop("x2", None)
+            ctot = c1 + (0 if x2 is None else x2.shape[3])
+            xn = self.ws.get(f"conv_xn_{n}x{h}x{ww}x{ctot}", (n, h, ww, ctot))
+            ops.affine_apply(self.lib, self.st, x.view(-1, c1), kw.pop("pro_scale"), kw.pop("pro_shift"), xn.view(-1, ctot),
+                             rows_per_image=h * ww, act=kw.pop("pro_act", A.ACT_NONE),
+                             x2=None if x2 is None else x2.view(-1, x2.shape[3]))
+            x = xn
         if not self.gn_fused:
             ops.conv3x3(self.lib, self.st, x, wt, y, **kw)
             return

@@ -272,6 +272,13 @@ int hv_plucker_unshuffle(const float* K, const float* c2w, int F, int H, int W, 
  * scale / shift come from hv_groupnorm_affine. */
 int hv_affine_apply(const uint16_t* X, long ldx, int rows, int rows_per_image, int C, const float* scale, const float* shift,
                     int act, uint16_t* Y, long ldy, void* stream);
+/* The same pass over the channel concatenation [X | X2] of a decoder ResnetBlock3D's input (torch.cat([hidden_states,
+ * res_hidden_states], dim=1) in src/models/unet_3d_blocks.py CrossAttnUpBlock3D / UpBlock3D.forward, normalised by
+ * ResnetBlock3D.norm1 + SiLU, src/models/resnet.py:215-222): Y [rows][C + C2], scale / shift [images][C + C2].  The 3x3
+ * convolution behind it then reads ONE normalised source (hv_conv3x3 without pro_scale): the convolution's own prologue
+ * repeats the transform in every 128-channel output tile and in every halo pixel. */
+int hv_affine_apply_cat(const uint16_t* X, long ldx, int C, const uint16_t* X2, long ldx2, int C2, int rows, int rows_per_image,
+                        const float* scale, const float* shift, int act, uint16_t* Y, long ldy, void* stream);
 int hv_timestep_embedding(const float* t, int B, int dim, uint16_t* dst, void* stream);
 
 /* ---- window accumulation, classifier-free guidance and the DDIM v-prediction update --------

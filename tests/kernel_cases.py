@@ -134,6 +134,22 @@ def case_affine_apply(cx: Ctx, n_img=3, rows=50, C=64, act=A.ACT_NONE, seed=40):
     return e
 
 
+def case_affine_apply_cat(cx: Ctx, n_img=3, rows=50, C1=64, C2=32, seed=43):
+    """the same pass over the channel concatenation [x | x2] (decoder ResnetBlock3D input), SiLU, into one [rows, C1 + C2]
+    activation -- and what the convolution behind it then computes equals the convolution with the operand prologue"""
+    g = torch.Generator().manual_seed(seed)
+    M = n_img * rows
+    x, x2 = rnd(g, M, C1), rnd(g, M, C2)
+    sc, sh = 1 + 0.3 * rnd(g, n_img, C1 + C2), 0.2 * rnd(g, n_img, C1 + C2)
+    ref = F.silu(torch.cat([r(x), r(x2)], dim=1).view(n_img, rows, C1 + C2) * sc[:, None] + sh[:, None])
+    y = torch.zeros(M, C1 + C2, dtype=BF16, device=cx.device)
+    ops.affine_apply(cx.lib, cx.stream, cx.bf(x), cx.dev(sc), cx.dev(sh), y, rows_per_image=rows, act=A.ACT_SILU, x2=cx.bf(x2))
+    cx.sync()
+    e = nrmse(y, ref.view(M, C1 + C2))
+    assert e < TOL, f"affine_apply_cat nrmse {e}"
+    return e
+
+
 def case_layernorm_stats(cx: Ctx, M=77, C=320, seed=44, offset=3.0):
     """row statistics of hv_layernorm_stats (mean, 1/sqrt(var + eps)) against torch on the bf16-rounded rows; C = 320 / 640 /
     1280 take the several-rows-per-wave kernel, other widths the one-row-per-wave kernel; M not a multiple of the rows per

@@ -86,6 +86,7 @@ def test_gemm_fast_epilogue_forms(cx):
 def test_affine_apply(cx):
     kc.case_affine_apply(cx, n_img=3, rows=50, C=64)
     kc.case_affine_apply(cx, n_img=2, rows=33, C=320, act=A.ACT_SILU, seed=41)
+    kc.case_affine_apply_cat(cx, n_img=3, rows=50, C1=64, C2=32)
 
 
 def test_gemm_grouped_tile_raster(cx):

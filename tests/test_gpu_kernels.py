@@ -72,6 +72,7 @@ def test_bench_shape_gemm_forms(cx):
 def test_affine_apply(cx):
     kc.case_affine_apply(cx, n_img=48, rows=1536, C=640)
     kc.case_affine_apply(cx, n_img=48, rows=6144, C=320, act=A.ACT_SILU, seed=42)
+    kc.case_affine_apply_cat(cx, n_img=48, rows=1536, C1=640, C2=320)
 
 
 @pytest.mark.parametrize("mode", [A.CONV_S1, A.CONV_S2, A.CONV_UP2])

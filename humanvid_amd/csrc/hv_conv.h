@@ -20,6 +20,10 @@
 #include "hv_gemm.h"  // hv_swz
 #include "humanvid_hip.h"
 
+#ifndef HV_CONV_ABL
+#define HV_CONV_ABL 0  // timing-only ablation builds (tools/conv_ablation.sh; results are wrong): 1 no halo global loads, 2 no halo
+                       // LDS stores, 4 no weight LDS-DMA (and no waits for it), 8 no fragment ds_reads, 16 no MFMAs, 32 no stores
+#endif
 #ifndef HV_CONV_HBUFS1
 #define HV_CONV_HBUFS1 1  // one halo buffer for every variant (0: two for CK = 32, the round-2 layout; same-box A/B in profiles/r03_conv_lds_ab.txt)
 #endif
@@ -139,7 +143,7 @@ __global__ __launch_bounds__(2 * 64 * (NPIX / WPX), (WPX == 128 ? 2 : (NPIX == 2
             u32x4 v = {0u, 0u, 0u, 0u};
             if (hp < G::HP) {
                 const int iy = in_y0 + hp / G::HW, ix = in_x0 + hp % G::HW;
-                if (iy >= 0 && iy < p.Hs && ix >= 0 && ix < p.Ws)
+                if (!(HV_CONV_ABL & 1) && iy >= 0 && iy < p.Hs && ix >= 0 && ix < p.Ws)
                     v = hv_ld16(base + ((long)(img * p.Hs + iy) * p.Ws + ix) * cs + cc);
             }
             hreg[j] = v;
@@ -175,7 +179,7 @@ __global__ __launch_bounds__(2 * 64 * (NPIX / WPX), (WPX == 128 ? 2 : (NPIX == 2
                     v = hv_pack8(f);
                 }
             }
-            hv_st16(halo + buf * G::HALO_BYTES + hp * G::PS + hc * 16, v);
+            if (!(HV_CONV_ABL & 2) || v[0] == 0x12345u) hv_st16(halo + buf * G::HALO_BYTES + hp * G::PS + hc * 16, v);
         }
     };
 
@@ -229,7 +233,7 @@ __global__ __launch_bounds__(2 * 64 * (NPIX / WPX), (WPX == 128 ? 2 : (NPIX == 2
         hv_static_for<WQ>([&](auto Q) __attribute__((always_inline)) {
             constexpr int q = decltype(Q)::value;
             // base = the kernel argument: always an SGPR pair
-            hv_glds16_s(p.W, hv_pick4<q>(wofs0, wofs1, wofs2, wofs3) + step, slot + (wave_u + NW * q) * 1024);
+            if (!(HV_CONV_ABL & 4)) hv_glds16_s(p.W, hv_pick4<q>(wofs0, wofs1, wofs2, wofs3) + step, slot + (wave_u + NW * q) * 1024);
         });
         if (++iw_slot == 3) iw_slot = 0;
         if (++iw_tap == 9) {
@@ -282,7 +286,8 @@ __global__ __launch_bounds__(2 * 64 * (NPIX / WPX), (WPX == 128 ? 2 : (NPIX == 2
                 store_halo(chunk, hbuf);
             }
             if (GLDS) {
-                if (s + 1 < nsteps)
+                if (HV_CONV_ABL & 4) {
+                } else if (s + 1 < nsteps)
                     hv_vm_wait<WQ>();  // tap tile s landed, tile s+1 may stay in flight
                 else
                     hv_vm_wait<0>();
@@ -305,7 +310,12 @@ __global__ __launch_bounds__(2 * 64 * (NPIX / WPX), (WPX == 128 ? 2 : (NPIX == 2
                 bf16x8 wf[4];
 #pragma unroll
                 for (int f = 0; f < 4; ++f)
-                    wf[f] = hv_as_bf16x8(hv_ld16(wb + hv_swz_conv<CK>(64 * wn + 16 * f + r16, kk * 4 + quad)));
+                    if (HV_CONV_ABL & 8) {
+                        u32x4 z = {(unsigned)lane, (unsigned)lane, (unsigned)lane, (unsigned)lane};
+                        asm volatile("" : "+v"(z));
+                        wf[f] = hv_as_bf16x8(z);
+                    } else
+                        wf[f] = hv_as_bf16x8(hv_ld16(wb + hv_swz_conv<CK>(64 * wn + 16 * f + r16, kk * 4 + quad)));
                 // pixel fragments in groups of four (16 registers of operands at a time)
 #pragma unroll
                 for (int g = 0; g < NMF; g += 4) {
@@ -319,13 +329,20 @@ __global__ __launch_bounds__(2 * 64 * (NPIX / WPX), (WPX == 128 ? 2 : (NPIX == 2
                             lp = lpb[g + f] + dy * G::HW + dx;
                         else
                             lp = ((py[g + f] + dy + 1) >> 1) * G::HW + ((px[g + f] + dx + 1) >> 1);
-                        xf[f] = hv_as_bf16x8(hv_ld16(hb + lp * G::PS + kk * 64));
+                        if (HV_CONV_ABL & 8) {
+                            u32x4 z = {(unsigned)lp, (unsigned)lane, (unsigned)lane, (unsigned)lane};
+                            asm volatile("" : "+v"(z));
+                            xf[f] = hv_as_bf16x8(z);
+                        } else
+                            xf[f] = hv_as_bf16x8(hv_ld16(hb + lp * G::PS + kk * 64));
                     }
 #pragma unroll
                     for (int nf = 0; nf < 4; ++nf)
 #pragma unroll
                         for (int mf = 0; mf < 4; ++mf)
-                            acc[nf][g + mf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nf], xf[mf], acc[nf][g + mf], 0, 0, 0);
+                            if (HV_CONV_ABL & 16) asm volatile("" : "+v"(acc[nf][g + mf]) : "v"(wf[nf]), "v"(xf[mf]));
+                            else
+                                acc[nf][g + mf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nf], xf[mf], acc[nf][g + mf], 0, 0, 0);
                 }
             }
         });
@@ -373,7 +390,7 @@ __global__ __launch_bounds__(2 * 64 * (NPIX / WPX), (WPX == 128 ? 2 : (NPIX == 2
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[r] = hv_act(v[r], p.out_act);
             u32x2 o = {hv_pack2(v[0], v[1]), hv_pack2(v[2], v[3])};
-            hv_st8(p.Y + opix[mf] * p.Cout + n, o);
+            if (!(HV_CONV_ABL & 32) || o[0] == 0x12345u) hv_st8(p.Y + opix[mf] * p.Cout + n, o);
             gs += v;
             gq += v * v;
         }

@@ -280,6 +280,28 @@ def case_gemm_geglu(cx: Ctx, M=70, C=64, seed=3):
     return e
 
 
+def case_geglu_pointwise(cx: Ctx, M=4096, C=64, lo=-9.0, hi=9.0):
+    """the epilogue's GELU (hv_gelu_times: erfc as 2^(u q(u))) pointwise against F.gelu (exact erf form, the reference's
+    GEGLU.gelu) over [lo, hi]: value rows are 1, gate rows pass x[:, 0] through, so y[m, :] = bf16(gelu(x[m, 0])).
+    Tolerance: one bf16 rounding of the result (2^-8 relative) + 1e-6 absolute."""
+    gate = torch.linspace(lo, hi, M).to(BF16).float()  # bf16-exact gate values
+    x = torch.zeros(M, C)
+    x[:, 0], x[:, 1] = gate, 1.0
+    w = torch.zeros(8 * C, C)
+    w[: 4 * C, 1] = 1.0   # value half: h = 1
+    w[4 * C :, 0] = 1.0   # gate half: g = x[:, 0]
+    wp, bp, _ = packing.pack_geglu(w, torch.zeros(8 * C))
+    y = torch.zeros(M, 4 * C, dtype=BF16, device=cx.device)
+    ops.gemm(cx.lib, cx.stream, cx.bf(x), cx.bf(wp), y, bias=cx.dev(bp), geglu=True)
+    cx.sync()
+    ref = F.gelu(gate.double())[:, None].expand(M, 4 * C)
+    err = (y.double().cpu() - ref).abs()
+    bound = ref.abs() * 2.0**-8 + 1e-6
+    worst = float((err / bound).max())
+    assert worst <= 1.0, f"geglu pointwise: worst error / bound = {worst}"
+    return worst
+
+
 # ----------------------------------------------------------------------------------------- conv
 def case_conv(cx: Ctx, n=2, H=12, W=20, C1=32, C2=0, Cout=40, mode=A.CONV_S1, pro=True, temb=True, residual=True,
               out_act=A.ACT_NONE, seed=4, check=None):

@@ -167,6 +167,7 @@ def test_gemm_lnfold(cx):
 
 def test_gemm_geglu(cx):
     kc.case_gemm_geglu(cx)
+    kc.case_geglu_pointwise(cx, M=512)
 
 
 @pytest.mark.parametrize("mode", [A.CONV_S1, A.CONV_S2, A.CONV_UP2])

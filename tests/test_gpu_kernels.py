@@ -33,6 +33,8 @@ def test_gemm_fused(cx):
     kc.case_gemm_prologue(cx, n_img=6, rows=384, N=1280, K=1280)
     kc.case_gemm_lnfold(cx, B=2, Fr=24, P=96, C=1280, N=3840)
     kc.case_gemm_geglu(cx, M=4096, C=320)
+    kc.case_geglu_pointwise(cx, M=8192, C=320)  # the LDS-DMA kernel's GEGLU epilogue
+    kc.case_geglu_pointwise(cx, M=512, C=64)    # the register-staged kernel's
 
 
 def test_gemm_epilogue_forms(cx):

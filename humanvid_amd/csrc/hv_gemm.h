@@ -427,7 +427,12 @@ HV_DEV void hv_gemm_epilogue_fast_perm(const HvGemmParams& p, f32x4 (&acc)[4][NM
 #pragma unroll
         for (int nf = 0; nf < 4; ++nf) cs4[nf] = ld4(p.colsum, 4u * (unsigned)(nc[nf >> 1] + 4 * (nf & 1)));
     }
-    if (tab_row != nullptr) {
+    // Positional-encoding table whose period is not a multiple of the wave's row block (level 3: 96 tokens per frame under
+    // 64-row blocks) but of 16: one table row per 16-row FRAGMENT, loaded with the fragment group's other per-row terms.
+    // (LayerNorm-fold form only: the temporal QKV projection, motion_module.py:157-175 + PositionalEncoding :132-147.)
+    constexpr bool FRAG_TAB_FORM = LN && !RES && STATS == 0 && NMF <= 4;  // (the 128 x 128 kernel: the 256 x 256 one has no registers for it)
+    const bool tab_per_frag = FRAG_TAB_FORM && p.pe != nullptr && p.pe_period % (16 * NMF) != 0;
+    if (tab_row != nullptr && !tab_per_frag) {
         f32x4 t4[4];
 #pragma unroll
         for (int nf = 0; nf < 4; ++nf) t4[nf] = ld4(tab_row, 4u * (unsigned)(nc[nf >> 1] + 4 * (nf & 1)));
@@ -445,12 +450,28 @@ HV_DEV void hv_gemm_epilogue_fast_perm(const HvGemmParams& p, f32x4 (&acc)[4][NM
     for (int g = 0; g < NMF; g += G) {
         float mean[G], rstd[G];
         u32x4 res4[G][RES ? 2 : 1];
+        f32x4 tf4[FRAG_TAB_FORM ? G : 1][4];
 #pragma unroll
         for (int j = 0; j < G; ++j) {
             const int mc = min(m_base + 16 * (g + j) + r16, p.M - 1);
             if (LN) {
                 mean[j] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(p.row_mean) + 4u * (unsigned)mc);
                 rstd[j] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(p.row_rstd) + 4u * (unsigned)mc);
+            }
+            if constexpr (FRAG_TAB_FORM) {
+#pragma unroll
+                for (int nf = 0; nf < 4; ++nf) tf4[j][nf] = zero4;
+                if (tab_per_frag) {  // (wave-uniform)
+                    const int mrow = min(m_base + 16 * (g + j), p.M - 1);
+#ifndef HV_EMU
+                    const int fr = __builtin_amdgcn_readfirstlane((mrow / p.pe_period) % p.pe_frames);
+#else
+                    const int fr = (mrow / p.pe_period) % p.pe_frames;
+#endif
+                    const float* trow = p.pe + (long)fr * p.N;
+#pragma unroll
+                    for (int nf = 0; nf < 4; ++nf) tf4[j][nf] = ld4(trow, 4u * (unsigned)(nc[nf >> 1] + 4 * (nf & 1)));
+                }
             }
             if (RES) {
                 const unsigned ro = (unsigned)mc * (unsigned)p.ldr * 2u;
@@ -475,6 +496,7 @@ HV_DEV void hv_gemm_epilogue_fast_perm(const HvGemmParams& p, f32x4 (&acc)[4][NM
                     f32x4 v = acc[nf][mf];
                     if (LN) v = rstd[j] * (v - mean[j] * cs4[nf]);
                     v += add4[nf];
+                    if constexpr (FRAG_TAB_FORM) v += tf4[j][nf];
                     if (RES) {
                         const unsigned r0 = res4[j][RES ? h : 0][2 * k], r1 = res4[j][RES ? h : 0][2 * k + 1];
                         v += f32x4{hv_bf2f((bf16_t)(r0 & 0xffff)), hv_bf2f((bf16_t)(r0 >> 16)), hv_bf2f((bf16_t)(r1 & 0xffff)),
@@ -1183,7 +1205,11 @@ static inline HvGemmChoice hv_gemm_choose(const HvGemmParams& p) {
                          (p.X2 == nullptr || (long)p.M * p.ldx2 * 2 < lim) &&
                          (p.residual == nullptr || (long)p.M * p.ldr * 2 < lim) &&
                          (p.Yt == nullptr || (long)(p.N - p.n_split) * p.ldyt * 2 < lim);
-    const int form128 = hv_gemm_fast_form(p, 128), form64 = hv_gemm_fast_form(p, 64);
+    int form128 = hv_gemm_fast_form(p, 128), form64 = hv_gemm_fast_form(p, 64);
+    // a positional-encoding table with one row per 16-row fragment (period % 16 == 0 only): the permuted LayerNorm-fold
+    // epilogue of the 128 x 128 kernel loads it per fragment (hv_gemm_epilogue_fast_perm)
+    if (form64 == HV_FORM_NONE && g_hv_gemm_perm && p.N % 8 == 0 && p.pe != nullptr && hv_gemm_fast_form(p, 16) == HV_FORM_LN)
+        form64 = HV_FORM_LN;
     if (!(g_hv_gemm_glds && !prologue && p.M >= 256 && span_ok && form64 != HV_FORM_NONE)) return c;
     const int tm = (p.M + 255) / 256;
     const int n128 = ((p.N + 127) / 128) * 128, n256 = ((p.N + 255) / 256) * 256;

@@ -163,6 +163,9 @@ def test_gemm_prologue(cx):
 
 def test_gemm_lnfold(cx):
     kc.case_gemm_lnfold(cx)
+    # positional-encoding period 48: not a multiple of the 64-row wave block -> one table row per 16-row fragment on the
+    # LDS-DMA kernel (level 3 of the UNet: 96 tokens per frame)
+    kc.case_gemm_lnfold(cx, B=2, Fr=3, P=48, C=64, N=192, seed=7)
 
 
 def test_gemm_geglu(cx):

@@ -57,7 +57,10 @@ def _kv(shape: str):
     out = {}
     for tok in shape.split():
         k, _, v = tok.partition("=")
-        out[k] = int(v)
+        try:
+            out[k] = int(v)
+        except ValueError:  # a launch note this module does not price must not take the bench line down
+            out[k] = v
     return out
 
 
@@ -95,6 +98,8 @@ def price_launch(key: str):
         return 0.0, 2.0 * a["n"] * a["pixels"] * a["C"]
     if kern.startswith("hv_ln_stats"):
         return 0.0, 2.0 * a["M"] * a["C"]
+    if kern.startswith("hv_affine_apply") and "rows" in a:
+        return 0.0, 4.0 * a["rows"] * (a["C"] + a.get("C2", 0))  # bf16 in, bf16 out
     return 0.0, 0.0
 
 
@@ -115,6 +120,8 @@ def price_launch_rw(key: str):
         wr = 2.0 * a["heads"] * a["D"] * a["n"] * a["Lq"]
     elif kern.startswith("hv_temporal"):
         wr = 2.0 * 8 * int(kern.split("<")[1].split(">")[0]) * a["B"] * a["P"] * a["Fq"]
+    elif kern.startswith("hv_affine_apply") and "rows" in a:
+        wr = total / 2
     else:
         wr = 0.0
     return total - wr, wr

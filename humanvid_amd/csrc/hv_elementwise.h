@@ -254,7 +254,7 @@ static inline void hv_affine_apply_launch(const bf16_t* X, long ldx, int rows, i
     const long total = (long)rows * ((C + C2) / 8);
     long blocks = (total + 255) / 256;
     if (blocks > 256 * 16) blocks = 256 * 16;
-    hv_note("hv_affine_apply_kernel | rows=%d C=%d+%d act=%d", rows, C, C2, act);
+    hv_note("hv_affine_apply_kernel | rows=%d C=%d C2=%d act=%d", rows, C, C2, act);
     hv_launch(hv_affine_apply_kernel, dim3((unsigned)blocks), dim3(256), stream, X, ldx, rows, rows_per_image, C, X2, ldx2, C2, scale,
               shift, act, Y, ldy);
 }

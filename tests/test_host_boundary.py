@@ -174,3 +174,7 @@ def test_config5_windows_and_bench_pricing():
     fl, by = bench.price_launch("hv_conv3x3_kernel<16,0,1,128> | n=48 Hs=96 Ws=64 Ho=96 Wo=64 Cin=320 Cout=320 gn=1 res=1")
     assert fl == 2.0 * 9 * 320 * 320 * 48 * 6144
     assert bench.price_launch("hv_pack_kernel") == (0.0, 0.0)
+    fl, by = bench.price_launch("hv_affine_apply_kernel | rows=73728 C=640 C2=320 act=2")
+    assert fl == 0.0 and by == 4.0 * 73728 * 960 and bench.price_launch_rw("hv_affine_apply_kernel | rows=8 C=8 C2=0 act=0") == (128.0, 128.0)
+    # a launch note with a field this module cannot parse is priced as nothing, it does not take the bench line down
+    assert bench.price_launch("hv_some_future_kernel | rows=96+0 mode=x") == (0.0, 0.0)

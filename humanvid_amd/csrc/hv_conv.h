@@ -359,6 +359,18 @@ __global__ __launch_bounds__(2 * 64 * (NPIX / WPX), (WPX == 128 ? 2 : (NPIX == 2
     const int gn_parts = tiles_y * tiles_x * WM;
     float* const gn_dst = p.gn_part ? p.gn_part + ((long)img * gn_parts + ((y0 / TH) * tiles_x + x0 / TW) * WM + wm) * p.Cout * 2
                                     : nullptr;
+    // The stores go out in a second, ROW-major pass (pixel fragment outer, the four 32-byte channel segments of a pixel's
+    // 128-byte line back to back): issued column by column -- a line's four segments a whole column pass apart -- the
+    // partial lines reached HBM separately (WRITE_SIZE 2.3x the algorithmic bytes at 320 -> 320 channels,
+    // profiles/r03_pmc_traffic.json before this change).  The packed results replace the accumulators (32 registers).
+    u32x2 outp[4][NMF];
+    long opix[NMF];
+#pragma unroll
+    for (int mf = 0; mf < NMF; ++mf) {
+        const int opx = WPX * wm + 16 * mf + r16;  // recomputed: py / px need not stay live through the k-loop
+        const int oy = y0 + opx / TW, ox = x0 + opx % TW;
+        opix[mf] = (oy < p.Ho && ox < p.Wo) ? (long)(img * p.Ho + oy) * p.Wo + ox : -1;
+    }
 #pragma unroll
     for (int nf = 0; nf < 4; ++nf) {
         const int n = n0 + 64 * wn + 16 * nf + 4 * quad;
@@ -367,15 +379,13 @@ __global__ __launch_bounds__(2 * 64 * (NPIX / WPX), (WPX == 128 ? 2 : (NPIX == 2
         if (p.bias) add += *reinterpret_cast<const f32x4*>(p.bias + n);
         if (rv) add += *reinterpret_cast<const f32x4*>(rv + n);
         u32x2 res2[NMF];
-        long opix[NMF];
 #pragma unroll
         for (int mf = 0; mf < NMF; ++mf) {
-            const int opx = WPX * wm + 16 * mf + r16;  // recomputed: py / px need not stay live through the k-loop
-            const int oy = y0 + opx / TW, ox = x0 + opx % TW;
-            const bool valid = oy < p.Ho && ox < p.Wo;
-            opix[mf] = valid ? (long)(img * p.Ho + oy) * p.Wo + ox : -1;
             u32x2 r = {0u, 0u};
-            if (p.residual && valid) r = hv_ld8(p.residual + ((long)(rimg * p.Ho + oy) * p.Wo + ox) * p.Cout + n);
+            if (p.residual && opix[mf] >= 0) {
+                const long rpix = p.residual_images > 0 ? opix[mf] - (long)(img - rimg) * p.Ho * p.Wo : opix[mf];
+                r = hv_ld8(p.residual + rpix * p.Cout + n);
+            }
             res2[mf] = r;
         }
         f32x4 gs = {0.f, 0.f, 0.f, 0.f}, gq = {0.f, 0.f, 0.f, 0.f};
@@ -389,8 +399,7 @@ __global__ __launch_bounds__(2 * 64 * (NPIX / WPX), (WPX == 128 ? 2 : (NPIX == 2
             v[3] += hv_bf2f((bf16_t)(res2[mf][1] >> 16));
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[r] = hv_act(v[r], p.out_act);
-            u32x2 o = {hv_pack2(v[0], v[1]), hv_pack2(v[2], v[3])};
-            if (!(HV_CONV_ABL & 32) || o[0] == 0x12345u) hv_st8(p.Y + opix[mf] * p.Cout + n, o);
+            outp[nf][mf] = u32x2{hv_pack2(v[0], v[1]), hv_pack2(v[2], v[3])};
             gs += v;
             gq += v * v;
         }
@@ -405,6 +414,16 @@ __global__ __launch_bounds__(2 * 64 * (NPIX / WPX), (WPX == 128 ? 2 : (NPIX == 2
                 *reinterpret_cast<f32x4*>(gn_dst + 2 * n) = f32x4{a[0], b[0], a[1], b[1]};
                 *reinterpret_cast<f32x4*>(gn_dst + 2 * n + 4) = f32x4{a[2], b[2], a[3], b[3]};
             }
+        }
+    }
+#pragma unroll
+    for (int mf = 0; mf < NMF; ++mf) {
+        if (opix[mf] < 0) continue;
+#pragma unroll
+        for (int nf = 0; nf < 4; ++nf) {
+            const int n = n0 + 64 * wn + 16 * nf + 4 * quad;
+            if (n >= p.Cout) continue;
+            if (!(HV_CONV_ABL & 32) || outp[nf][mf][0] == 0x12345u) hv_st8(p.Y + opix[mf] * p.Cout + n, outp[nf][mf]);
         }
     }
 }

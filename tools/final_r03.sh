@@ -35,4 +35,12 @@ for pass in "${PASSES[@]}"; do
 done
 cd $REPO
 python tools/pmc_by_shape.py gpurun_out/r03_step_profile_final.tsv gpurun_out/r03_pmc_traffic.json /tmp/pmc_fetch /tmp/pmc_write /tmp/pmc_mfma 2>&1 | tail -22
+# the bench line once more, now with roofline.traffic from the passes just collected (bench.py reads profiles/r03_pmc_traffic.json
+# and refuses a file whose kernel-source digest is not this tree's)
+cp gpurun_out/r03_pmc_traffic.json profiles/r03_pmc_traffic.json
+HV_PROFILE_DUMP=gpurun_out/r03_step_profile_final.tsv timeout 400 python bench.py > gpurun_out/r03_bench_line_final.json 2> gpurun_out/r03_bench_final.err
+python -c "
+import json
+d=json.loads(open('gpurun_out/r03_bench_line_final.json').read().strip().splitlines()[-1])
+print('final line:', d['value'], 'steps/s', d['ms_per_step'], 'ms', {k: d['roofline'][k] for k in ('kernel', 'achieved', 'frac', 'traffic')})"
 if [ $MEASURE_ONLY == 0 ]; then python tools/pmc_lds.py /tmp/pmc_lds > gpurun_out/r03_lds_conflicts.txt 2>&1; head -12 gpurun_out/r03_lds_conflicts.txt | cut -c1-160; fi

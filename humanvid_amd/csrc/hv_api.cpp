@@ -129,7 +129,7 @@ int hv_set_tuning(int key, int value) {
     else if (key == HV_TUNE_GEMM_GLDS && (value >= 0 && value <= 3)) hvk_gemm_use_glds(value);
     else if (key == HV_TUNE_GEMM_PERM && (value == 0 || value == 1)) hvk_gemm_perm(value);
     else if (key == HV_TUNE_CONV_GLDS && (value == 0 || value == 1)) hvk_conv_use_glds(value);
-    else if (key == HV_TUNE_CONV_BIG && (value >= 0 && value <= 5)) hvk_conv_use_big(value);
+    else if (key == HV_TUNE_CONV_BIG && (value >= 0 && value <= 3)) hvk_conv_use_big(value);
     else return hv_fail(HV_EINVAL, "hv_set_tuning: unknown key/value");
     return HV_OK;
 }

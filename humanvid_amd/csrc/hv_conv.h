@@ -83,7 +83,7 @@ struct HvConvGeom {
 // the finding behind the GEMM's BK = 64), every tap step carries 32 MFMAs per wave behind its barrier instead of 16, and the
 // number of steps, barriers and DMA instructions halves.  74 KiB of LDS (one 26 KiB halo buffer, three 16 KiB weight slots).
 template <int TW, int MODE, bool GLDS, int NPIX, int WPX = 64, int CK = 32>
-__global__ __launch_bounds__(2 * 64 * (NPIX / WPX), (WPX == 128 ? 2 : (NPIX == 256 && MODE == HV_CONV_S1 ? 4 : 1))) void hv_conv3x3_kernel(hv_conv3x3_params p) {
+__global__ __launch_bounds__(2 * 64 * (NPIX / WPX), (WPX == 128 ? 2 : 1)) void hv_conv3x3_kernel(hv_conv3x3_params p) {
     using G = HvConvGeom<TW, MODE, NPIX, WPX, CK>;
     static_assert(CK == 32 || (CK == 64 && GLDS), "64-channel chunks stream their weights by LDS-DMA");
     constexpr int TH = G::TH;
@@ -451,11 +451,11 @@ static inline void hv_conv3x3_launch_t(const hv_conv3x3_params& p, hipStream_t s
 // gn_part is [n_images][tiles_y * tiles_x * WM][Cout][2]
 static inline void hv_conv3x3_tile_shape(const hv_conv3x3_params& p, int& TH, int& TW, int& WM) {
     const bool narrow = p.Wo <= 8;
-    const bool big = g_hv_conv_big && !narrow && p.Ho >= 16 && (p.mode == HV_CONV_UP2 || (p.mode == HV_CONV_S1 && g_hv_conv_big >= 4));
+    const bool big = g_hv_conv_big && !narrow && p.Ho >= 16 && p.mode == HV_CONV_UP2;
     TW = narrow ? 8 : 16;
     const int npix = big ? 256 : 128;
     TH = npix / TW;
-    WM = npix / (p.mode == HV_CONV_S1 && g_hv_conv_big == 5 && big ? 128 : 64);
+    WM = npix / 64;
 }
 static inline int hv_conv3x3_gn_parts_of(const hv_conv3x3_params& p) {
     if (p.Cout % 4 != 0 || p.Ho <= 0 || p.Wo <= 0) return 0;
@@ -476,20 +476,19 @@ static inline int hv_conv3x3_launch(const hv_conv3x3_params& p, hipStream_t stre
     // halo (33x33 pixels) would not fit two buffers in LDS
     const bool narrow = p.Wo <= 8;
     // (measured on MI355X: the 8-wave tile wins for the upsample-folded conv, 0.90 -> 1.03 PF/s, and
-    //  loses for stride 1, where the per-step barrier over 8 waves costs more than the traffic saved)
+    //  loses for stride 1, where the per-step barrier over 8 waves costs more than the traffic saved; re-measured in round 3
+    //  with the conflict-free LDS pitches, on 8 and on 4 waves: still no gain, profiles/r03_conv_tiles_ab.txt -- dispatch removed)
     const bool big = g_hv_conv_big && !narrow && p.Ho >= 16 && p.mode == HV_CONV_UP2;
     // 64-channel reduction chunks (whole 128-byte weight lines by LDS-DMA, 32 MFMAs per tap step): stride 1, both sources in
     // whole 64-channel chunks.  Hardware A/B (profiles/r03_hwcheck.txt, 48 images): 24x16 1280 -> 1280 0.746 -> 0.719 ms,
     // 12x8 0.258 -> 0.221 ms, but 96x64 320 -> 320 0.863 -> 0.928 and 48x32 640 -> 640 0.742 -> 0.770: the default takes
     // them for images of at most 384 output pixels (tuning value 3 forces them everywhere, 0 / 2 never).
     const bool ck64 = p.mode == HV_CONV_S1 && p.C1 % 64 == 0 && p.C2 % 64 == 0 &&
-                      (g_hv_conv_big == 3 || ((g_hv_conv_big == 1 || g_hv_conv_big >= 4) && p.Ho * p.Wo <= 384));
+                      (g_hv_conv_big == 3 || (g_hv_conv_big == 1 && p.Ho * p.Wo <= 384));
     switch (p.mode) {
         case HV_CONV_S1:
             if (ck64 && narrow) hv_conv3x3_launch_t<8, HV_CONV_S1, 128, 64, 64>(p, stream);
             else if (ck64) hv_conv3x3_launch_t<16, HV_CONV_S1, 128, 64, 64>(p, stream);
-            else if (g_hv_conv_big == 4 && !narrow && p.Ho >= 16) hv_conv3x3_launch_t<16, HV_CONV_S1, 256>(p, stream);
-            else if (g_hv_conv_big == 5 && !narrow && p.Ho >= 16) hv_conv3x3_launch_t<16, HV_CONV_S1, 256, 128>(p, stream);
             else if (narrow) hv_conv3x3_launch_t<8, HV_CONV_S1, 128>(p, stream);
             else hv_conv3x3_launch_t<16, HV_CONV_S1, 128>(p, stream);
             break;

@@ -1170,6 +1170,136 @@ __global__ __launch_bounds__(NW * 64, 2) void hv_gemm_glds_kernel(HvGemmParams p
     }
 }
 
+// ---- wide-tile LDS-DMA kernel for narrow outputs (round 3, written at the end of the round without GPU time to tune it:
+// OPT-IN, hv_set_tuning(HV_TUNE_GEMM_GLDS, 4)): 256 x 320 x 64 tiles for N = 320 / 640.  The 128 x 128 kernel spends three
+// column tiles on 320 columns (17 % of its MFMAs and W bytes on padding) and streams the X rows once per column tile through
+// the CU's L2 -> LDS fill path, which is what bounds it (profiles/r03_gemm_trace.txt): here a 256-row block of X is read
+// ONCE and multiplied with all 320 columns -- 72 KiB of fill per k-step for 256 x 320 x 64 MACs against 192 KiB.
+//   8 waves; wave w owns rows [32 w, +32) x all 320 columns = 5 column blocks of 64 (the epilogues' unit): 2 x 20 fragments,
+//   160 accumulator registers.  Ring: 2 slots x (X 32 KiB + W 40 KiB) = 144 KiB, one workgroup per CU.
+//   One raw barrier per k-step: wait for the own DMA of k-tile s, barrier (everyone's k-tile s landed; everyone is done with
+//   slot (s+1) % 2), issue k-tile s+1, multiply from slot s % 2.  The DMA goes out from inline asm (hv_glds16_s): hipcc
+//   does not see it and puts no vmcnt(0) in front of the fragment reads.
+//   Same swizzles, permuted channel assignment and epilogues (per 64-column block, NMF = 2) as hv_gemm_glds_kernel.
+template <int STATS>
+__global__ __launch_bounds__(512, 2) void hv_gemm_wide_kernel(HvGemmParams p, int form) {
+    constexpr int BM = 256, BN = 320, BK = 64, NS = 2, NW = 8, NB = BN / 64, NMF = 2;
+    constexpr int XT = BM * BK * 2, WT = BN * BK * 2, SLOT = XT + WT;
+    constexpr int RPI = 8, CPR = 8, RPB = 2;  // rows per 1 KiB wave-instruction, 16-byte chunks per row, rows per bank row
+    constexpr int XQ = BM / RPI / NW, WQ = BN / RPI / NW;  // 4 + 5 DMA instructions per wave and k-tile
+    __shared__ __attribute__((aligned(16))) unsigned char smem[NS * SLOT];
+    const int tid = threadIdx.x, lane = tid & 63;
+#ifndef HV_EMU
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#else
+    const int wave = tid >> 6;
+#endif
+    const int r16 = lane & 15, quad = lane >> 4;
+    const int tiles_n = p.N / BN, tiles_m = (p.M + BM - 1) / BM;
+    const int total = tiles_n * tiles_m;
+    const int wg_per_xcd = gridDim.x / 8;
+    const int xcd = blockIdx.x % 8, wg = blockIdx.x / 8;
+    const int per_xcd = (total + 7) / 8;
+    const int t_begin = xcd * per_xcd, t_end = min(total, t_begin + per_xcd);
+    const int first = t_begin + wg;
+    if (first >= t_end) return;
+    const int my_tiles = (t_end - first + wg_per_xcd - 1) / wg_per_xcd;
+    const int nk = p.K / BK, nsteps = my_tiles * nk;
+
+    // Issue state.  DMA instruction q of a wave covers tile rows 8 (wave + 8 q) + lane / 8: 64 rows further per q, and both
+    // swizzles only look at row bits 0..3 -- so ONE per-lane byte offset per operand serves all q and all k-tiles of a
+    // tile (M % 256 == 0, N % 320 == 0: no clamping), and everything that moves (q, k-tile, tile origin) is added to the
+    // scalar base.  (Nine per-lane offsets advanced per k-tile, the form of the other kernel, spilled here: the 256 x 320
+    // accumulator tile leaves 96 registers.)
+    const int sub = lane / CPR, slot = lane & (CPR - 1);
+    const int trow0 = RPI * wave + sub;
+    const unsigned xofs = ((unsigned)trow0 * (unsigned)p.ldx + (unsigned)((slot ^ ((trow0 / RPB) % CPR)) * 8)) * 2u;
+    const unsigned wofs = ((unsigned)trow0 * (unsigned)p.K + (unsigned)((slot ^ hv_wperm_swizzle(trow0)) * 8)) * 2u;
+    int i_tile = first, i_k = 0, i_slot = 0;
+    auto issue = [&]() __attribute__((always_inline)) {
+        unsigned char* sl = smem + i_slot * SLOT;
+        const int m0 = (i_tile / tiles_n) * BM, n0 = (i_tile % tiles_n) * BN;
+        const char* xb = reinterpret_cast<const char*>(p.X) + ((long)m0 * p.ldx + (long)i_k * BK) * 2;
+        const char* wb = reinterpret_cast<const char*>(p.W) + ((long)n0 * p.K + (long)i_k * BK) * 2;
+        hv_static_for<XQ>([&](auto Q) __attribute__((always_inline)) {
+            constexpr int q = decltype(Q)::value;
+            hv_glds16_s(xb + (long)(RPI * NW * q) * p.ldx * 2, xofs, sl + (wave + NW * q) * 1024);
+        });
+        hv_static_for<WQ>([&](auto Q) __attribute__((always_inline)) {
+            constexpr int q = decltype(Q)::value;
+            hv_glds16_s(wb + (long)(RPI * NW * q) * p.K * 2, wofs, sl + XT + (wave + NW * q) * 1024);
+        });
+        if (++i_slot == NS) i_slot = 0;
+        if (++i_k == nk) {
+            i_k = 0;
+            i_tile += wg_per_xcd;
+        }
+    };
+
+    f32x4 acc[NB][4][NMF];
+    auto clear_acc = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int b = 0; b < NB; ++b)
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int c = 0; c < NMF; ++c) acc[b][a][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    };
+    clear_acc();
+    issue();
+    int c_tile = first, c_k = 0, c_slot = 0, landed = 0;
+#ifdef HV_GEMM_TRACE
+    int hv_ti = 0;
+#endif
+    for (int s = 0; s < nsteps; ++s) {
+        // (after an epilogue everything issued has landed: it waits for every load before its first store)
+        if (landed > 0) --landed;
+        else hv_vm_wait<0>();
+        hv_barrier_raw();
+        const unsigned char* xs = smem + c_slot * SLOT;
+        const unsigned char* ws = xs + XT;
+        if (++c_slot == NS) c_slot = 0;
+        if (s + 1 < nsteps) issue();
+        // ten block steps (kk, b): the W fragments of step i+1 are read in front of the eight MFMAs of step i (two register
+        // sets, compile-time alternation), and a scheduling fence per step keeps hipcc from hoisting more reads (spills)
+        bf16x8 xf[2][NMF], wfa[4], wfb[4];
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int mf = 0; mf < NMF; ++mf) xf[kk][mf] = hv_as_bf16x8(hv_ld16(xs + hv_swz<BK>(32 * wave + 16 * mf + r16, kk * 4 + quad)));
+        auto ldw = [&](int i, bf16x8(&w)[4]) __attribute__((always_inline)) {
+            const int kk = i / NB, b = i % NB;
+#pragma unroll
+            for (int f = 0; f < 4; ++f) w[f] = hv_as_bf16x8(hv_ld16(ws + hv_swz_wperm(64 * b + hv_perm_row(f, r16), kk * 4 + quad)));
+        };
+        ldw(0, wfa);
+        hv_static_for<2 * NB>([&](auto I) __attribute__((always_inline)) {
+            constexpr int i = decltype(I)::value, kk = i / NB, b = i % NB;
+            bf16x8(&cur)[4] = (i % 2 == 0) ? wfa : wfb;
+            bf16x8(&nxt)[4] = (i % 2 == 0) ? wfb : wfa;
+            if constexpr (i + 1 < 2 * NB) ldw(i + 1, nxt);
+#pragma unroll
+            for (int nf = 0; nf < 4; ++nf)
+#pragma unroll
+                for (int mf = 0; mf < NMF; ++mf)
+                    acc[b][nf][mf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cur[nf], xf[kk][mf], acc[b][nf][mf], 0, 0, 0);
+#if !defined(HV_EMU)
+            __builtin_amdgcn_sched_barrier(0);
+#endif
+        });
+        if (++c_k == nk) {
+            c_k = 0;
+            const int m0 = (c_tile / tiles_n) * BM, n0 = (c_tile % tiles_n) * BN;
+#pragma unroll
+            for (int b = 0; b < NB; ++b)
+                hv_gemm_epilogue_form<NMF, true, STATS>(form, p, acc[b], m0 + 32 * wave, n0 + 64 * b, r16, quad HV_TRACE_ARG);
+            landed = 1;
+            c_tile += wg_per_xcd;
+            clear_acc();
+        }
+    }
+}
+
 static int g_hv_gemm_max_grid = 512;  // tuning knob (hv_set_tuning): persistent workgroups
 // tuning knob (hv_set_tuning key 3) -- kernel selection:
 //   1 (default): 256 x 256 x 64 (one 8-wave workgroup per CU) when N >= 960 and its tiles fill the last round over the 256
@@ -1177,6 +1307,7 @@ static int g_hv_gemm_max_grid = 512;  // tuning knob (hv_set_tuning): persistent
 //      (profiles/r03_step_ab.txt): 130.0 ms (round-2 default) -> 128.0 ms
 //   2: 256 x 256 x 64 wherever its tile shape is legal (A/Bs), 3: 128 x 128 x 64 everywhere (A/Bs)
 //   0: the register-staged kernel for everything (A/Bs; also what problems outside the fast epilogue forms run on)
+//   4: as 1, plus the 256 x 320 x 64 wide-tile kernel for N = 320 / 640 (opt-in, hv_gemm_wide_kernel)
 static int g_hv_gemm_glds = 1;
 static int g_hv_gemm_perm = 1;  // tuning knob (hv_set_tuning key 6): 16-byte epilogue through the permuted channel assignment (A/B)
 
@@ -1191,9 +1322,10 @@ static inline HvGemmChoice hv_gemm_choose(const HvGemmParams& p);
 // parts per image of the GroupNorm partial statistics (0 = this problem's kernel cannot emit them)
 static inline int hv_gemm_gn_parts_of(const HvGemmParams& p) {
     const HvGemmChoice c = hv_gemm_choose(p);
-    if (c.kernel != 2 || !c.perm || (c.form != HV_FORM_RES && c.form != HV_FORM_PLAIN)) return 0;
-    if (p.gn_rows_per_image <= 0 || p.gn_rows_per_image % 64 != 0 || p.M % p.gn_rows_per_image != 0) return 0;
-    return p.gn_rows_per_image / 64;
+    if ((c.kernel != 2 && c.kernel != 3) || !c.perm || (c.form != HV_FORM_RES && c.form != HV_FORM_PLAIN)) return 0;
+    const int rows = c.kernel == 3 ? 32 : 64;  // rows of a wave's sub-tile = rows per partial sum
+    if (p.gn_rows_per_image <= 0 || p.gn_rows_per_image % rows != 0 || p.M % p.gn_rows_per_image != 0) return 0;
+    return p.gn_rows_per_image / rows;
 }
 
 static inline HvGemmChoice hv_gemm_choose(const HvGemmParams& p) {
@@ -1211,6 +1343,16 @@ static inline HvGemmChoice hv_gemm_choose(const HvGemmParams& p) {
     if (form64 == HV_FORM_NONE && g_hv_gemm_perm && p.N % 8 == 0 && p.pe != nullptr && hv_gemm_fast_form(p, 16) == HV_FORM_LN)
         form64 = HV_FORM_LN;
     if (!(g_hv_gemm_glds && !prologue && p.M >= 256 && span_ok && form64 != HV_FORM_NONE)) return c;
+    // opt-in (tuning value 4): 256 x 320 x 64 tiles for N = 320 / 640 with a plain-output form on the permuted assignment
+    if (g_hv_gemm_glds == 4 && g_hv_gemm_perm && p.X2 == nullptr && p.N % 320 == 0 && p.N <= 640 && p.M % 256 == 0 && p.Yt == nullptr && !p.geglu) {
+        const int form32 = hv_gemm_fast_form(p, 32);
+        if (form32 == HV_FORM_RES || form32 == HV_FORM_PLAIN || form32 == HV_FORM_LN) {
+            c.kernel = 3;
+            c.form = form32;
+            c.perm = true;
+            return c;
+        }
+    }
     const int tm = (p.M + 255) / 256;
     const int n128 = ((p.N + 127) / 128) * 128, n256 = ((p.N + 255) / 256) * 256;
     c.gm = n128 / 128 > 8 ? 8 : 1;  // grouped raster for wide outputs (see the kernel)
@@ -1221,7 +1363,7 @@ static inline HvGemmChoice hv_gemm_choose(const HvGemmParams& p) {
     const int t256 = tm * (n256 / 256), rounds256 = (t256 + 255) / 256;
     const bool fills256 = t256 * 10 >= rounds256 * 256 * 9;
     const bool shape256 = ok128 && p.N >= 960 && (n256 - p.N) * 8 <= p.N;
-    const bool big = g_hv_gemm_glds != 3 && shape256 && (fills256 || g_hv_gemm_glds == 2);
+    const bool big = g_hv_gemm_glds != 3 && shape256 && (fills256 || g_hv_gemm_glds == 2);  // (value 4 selects like 1 here)
     c.kernel = big ? 1 : 2;
     c.form = big ? form128 : form64;
     // plain bf16 outputs (plain / residual / LayerNorm fold) and GEGLU with N % 8 == 0: permuted channel assignment, 16-byte epilogue
@@ -1233,7 +1375,7 @@ static inline HvGemmChoice hv_gemm_choose(const HvGemmParams& p) {
 // 64-column blocks per row of the LayerNorm partial statistics (0 = this problem's kernel cannot emit them)
 static inline int hv_gemm_ln_parts_of(const HvGemmParams& p) {
     const HvGemmChoice c = hv_gemm_choose(p);
-    if (c.kernel != 2 || !c.perm || (c.form != HV_FORM_RES && c.form != HV_FORM_PLAIN) || p.N % 64 != 0) return 0;
+    if ((c.kernel != 2 && c.kernel != 3) || !c.perm || (c.form != HV_FORM_RES && c.form != HV_FORM_PLAIN) || p.N % 64 != 0) return 0;
     return p.N / 64;
 }
 
@@ -1266,6 +1408,17 @@ static inline int hv_gemm_launch(const HvGemmParams& p, hipStream_t stream) {
             hv_note("hv_gemm_glds_kernel<256,8,256,1> | %s", shape);
             hv_launch(hv_gemm_glds_kernel<256, 8, 256, 1, false>, dim3(grid), dim3(512), stream, p, c.gm, c.form);
         }
+        return 0;
+    }
+    if (c.kernel == 3) {
+        const int tw = ((p.M + 255) / 256) * (p.N / 320);
+        int grid = ((tw + 7) / 8) * 8;
+        if (grid > 256) grid = 256;
+        if (grid > g_hv_gemm_max_grid) grid = g_hv_gemm_max_grid;
+        hv_note("hv_gemm_wide_kernel<%s> | %s", p.gn_part ? "gn" : (p.ln_part ? "ln" : "-"), shape);
+        if (p.gn_part != nullptr) hv_launch(hv_gemm_wide_kernel<1>, dim3(grid), dim3(512), stream, p, c.form);
+        else if (p.ln_part != nullptr) hv_launch(hv_gemm_wide_kernel<2>, dim3(grid), dim3(512), stream, p, c.form);
+        else hv_launch(hv_gemm_wide_kernel<0>, dim3(grid), dim3(512), stream, p, c.form);
         return 0;
     }
     if (c.kernel == 2) {

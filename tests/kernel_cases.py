@@ -405,7 +405,7 @@ def case_gn_parts_conv(cx: Ctx, n=3, H=16, W=16, Cin=64, Cout=320, C2=0, groups=
     return e1
 
 
-def case_gn_parts_gemm(cx: Ctx, n=4, rows=128, C=320, K=128, groups=32, seed=52, offset=0.3):
+def case_gn_parts_gemm(cx: Ctx, n=4, rows=128, C=320, K=128, groups=32, seed=52, offset=0.3, part_rows=64):
     """the same for the projection-out GEMM (bias + residual in place, 128x128x64 LDS-DMA kernel, permuted epilogue)"""
     g = torch.Generator().manual_seed(seed)
     M = n * rows
@@ -415,7 +415,7 @@ def case_gn_parts_gemm(cx: Ctx, n=4, rows=128, C=320, K=128, groups=32, seed=52,
     xd, wd = cx.bf(x), cx.bf(wt)
     kw = dict(bias=cx.dev(bias), residual=y)
     np_ = ops.gemm(cx.lib, cx.stream, xd, wd, y, gn_rows_per_image=rows, query_gn_parts=True, **kw)
-    assert np_ == rows // 64, np_
+    assert np_ == rows // part_rows, np_  # one partial sum per wave sub-tile: 64 rows (128 x 128 kernel), 32 (wide kernel)
     part = torch.zeros(n, np_, C, 2, device=cx.device)
     ops.gemm(cx.lib, cx.stream, xd, wd, y, gn_part=part, gn_rows_per_image=rows, **kw)
     gamma, beta = 1 + 0.2 * rnd(g, C), 0.1 * rnd(g, C)

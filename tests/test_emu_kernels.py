@@ -83,6 +83,25 @@ def test_gemm_fast_epilogue_forms(cx):
         cx.lib.call("hv_set_tuning", 2, 512)
 
 
+def test_gemm_wide_tile_kernel(cx):
+    """hv_gemm_wide_kernel (256 x 320 x 64 tiles, opt-in tuning value 4) for N = 320 / 640, M % 256 == 0: the three output
+    forms it takes, several tiles per persistent workgroup, one and several k-steps per tile, and the GroupNorm / LayerNorm
+    partial statistics (32-row partial sums); problems it does not take fall through to the default selection"""
+    cx.lib.call("hv_set_tuning", 2, 8)
+    cx.lib.call("hv_set_tuning", 3, 4)
+    try:
+        for form in ("ln", "res", "plain"):
+            kc.case_gemm_forms(cx, M=768, C=128, N=320, P=128, form=form, seed=71)     # 3 tiles
+        kc.case_gemm_forms(cx, M=512, C=64, N=640, P=256, form="res", seed=72)          # one k-step per tile, 4 tiles
+        kc.case_gemm_forms(cx, M=2560, C=192, N=320, P=32, form="ln", seed=73)          # 10 tiles over 8 workgroups; table row per 32-row block
+        kc.case_gn_parts_gemm(cx, n=4, rows=128, C=320, K=128, seed=74, part_rows=32)
+        kc.case_ln_parts_gemm(cx, M=768, C=320, K=128, seed=75)
+        kc.case_gemm_forms(cx, M=520, C=128, N=320, P=128, form="res", seed=76)         # M % 256 != 0: default kernels
+    finally:
+        cx.lib.call("hv_set_tuning", 3, 1)
+        cx.lib.call("hv_set_tuning", 2, 512)
+
+
 def test_affine_apply(cx):
     kc.case_affine_apply(cx, n_img=3, rows=50, C=64)
     kc.case_affine_apply(cx, n_img=2, rows=33, C=320, act=A.ACT_SILU, seed=41)

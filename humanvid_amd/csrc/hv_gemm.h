@@ -1171,7 +1171,7 @@ __global__ __launch_bounds__(NW * 64, 2) void hv_gemm_glds_kernel(HvGemmParams p
 }
 
 // ---- wide-tile LDS-DMA kernel for narrow outputs (round 3, written at the end of the round without GPU time to tune it:
-// OPT-IN, hv_set_tuning(HV_TUNE_GEMM_GLDS, 4)): 256 x 320 x 64 tiles for N = 320 / 640.  The 128 x 128 kernel spends three
+// OPT-IN, hv_set_tuning(HV_TUNE_GEMM_GLDS, 4)): 256 x 320 x 64 tiles for N = 320 (the kernel itself handles any N % 320 == 0).  The 128 x 128 kernel spends three
 // column tiles on 320 columns (17 % of its MFMAs and W bytes on padding) and streams the X rows once per column tile through
 // the CU's L2 -> LDS fill path, which is what bounds it (profiles/r03_gemm_trace.txt): here a 256-row block of X is read
 // ONCE and multiplied with all 320 columns -- 72 KiB of fill per k-step for 256 x 320 x 64 MACs against 192 KiB.
@@ -1307,7 +1307,7 @@ static int g_hv_gemm_max_grid = 512;  // tuning knob (hv_set_tuning): persistent
 //      (profiles/r03_step_ab.txt): 130.0 ms (round-2 default) -> 128.0 ms
 //   2: 256 x 256 x 64 wherever its tile shape is legal (A/Bs), 3: 128 x 128 x 64 everywhere (A/Bs)
 //   0: the register-staged kernel for everything (A/Bs; also what problems outside the fast epilogue forms run on)
-//   4: as 1, plus the 256 x 320 x 64 wide-tile kernel for N = 320 / 640 (opt-in, hv_gemm_wide_kernel)
+//   4: as 1, plus the 256 x 320 x 64 wide-tile kernel for N = 320, K >= 640 (opt-in, hv_gemm_wide_kernel)
 static int g_hv_gemm_glds = 1;
 static int g_hv_gemm_perm = 1;  // tuning knob (hv_set_tuning key 6): 16-byte epilogue through the permuted channel assignment (A/B)
 
@@ -1344,7 +1344,11 @@ static inline HvGemmChoice hv_gemm_choose(const HvGemmParams& p) {
         form64 = HV_FORM_LN;
     if (!(g_hv_gemm_glds && !prologue && p.M >= 256 && span_ok && form64 != HV_FORM_NONE)) return c;
     // opt-in (tuning value 4): 256 x 320 x 64 tiles for N = 320 / 640 with a plain-output form on the permuted assignment
-    if (g_hv_gemm_glds == 4 && g_hv_gemm_perm && p.X2 == nullptr && p.N % 320 == 0 && p.N <= 640 && p.M % 256 == 0 && p.Yt == nullptr && !p.geglu) {
+    // Same-box A/B (profiles/r03_gemm_wide_ab.txt): level-0 ff2 (N = 320, K = 1280) 0.384 -> 0.336 ms, N = 320 / K = 320 0.158 ->
+    // 0.155, but N = 640 at level 1 0.086 -> 0.097 and 0.298 -> 0.316 (576 tiles = 2.25 rounds over the 256 CUs): the value
+    // takes N = 320 with K >= 640 only (step -0.5 ms); it stays opt-in because the round's GPU budget could not re-run the
+    // whole -m gpu suite with it as the default.
+    if (g_hv_gemm_glds == 4 && g_hv_gemm_perm && p.X2 == nullptr && p.N == 320 && p.K >= 640 && p.M % 256 == 0 && p.Yt == nullptr && !p.geglu) {
         const int form32 = hv_gemm_fast_form(p, 32);
         if (form32 == HV_FORM_RES || form32 == HV_FORM_PLAIN || form32 == HV_FORM_LN) {
             c.kernel = 3;

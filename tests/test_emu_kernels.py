@@ -91,12 +91,12 @@ def test_gemm_wide_tile_kernel(cx):
     cx.lib.call("hv_set_tuning", 3, 4)
     try:
         for form in ("ln", "res", "plain"):
-            kc.case_gemm_forms(cx, M=768, C=128, N=320, P=128, form=form, seed=71)     # 3 tiles
-        kc.case_gemm_forms(cx, M=512, C=64, N=640, P=256, form="res", seed=72)          # one k-step per tile, 4 tiles
-        kc.case_gemm_forms(cx, M=2560, C=192, N=320, P=32, form="ln", seed=73)          # 10 tiles over 8 workgroups; table row per 32-row block
-        kc.case_gn_parts_gemm(cx, n=4, rows=128, C=320, K=128, seed=74, part_rows=32)
-        kc.case_ln_parts_gemm(cx, M=768, C=320, K=128, seed=75)
-        kc.case_gemm_forms(cx, M=520, C=128, N=320, P=128, form="res", seed=76)         # M % 256 != 0: default kernels
+            kc.case_gemm_forms(cx, M=768, C=640, N=320, P=128, form=form, seed=71)     # 3 tiles, 10 k-steps each
+        kc.case_gemm_forms(cx, M=2560, C=704, N=320, P=32, form="ln", seed=73)          # 10 tiles over 8 workgroups; table row per 32-row block
+        kc.case_gn_parts_gemm(cx, n=4, rows=128, C=320, K=640, seed=74, part_rows=32)
+        kc.case_ln_parts_gemm(cx, M=768, C=320, K=640, seed=75)
+        kc.case_gemm_forms(cx, M=520, C=640, N=320, P=128, form="res", seed=76)         # M % 256 != 0: default kernels
+        kc.case_gemm_forms(cx, M=512, C=64, N=320, P=256, form="res", seed=72)          # K < 640: default kernels
     finally:
         cx.lib.call("hv_set_tuning", 3, 1)
         cx.lib.call("hv_set_tuning", 2, 512)

@@ -37,6 +37,21 @@ def test_gemm_fused(cx):
     kc.case_geglu_pointwise(cx, M=512, C=64)    # the register-staged kernel's
 
 
+def test_gemm_wide_tile_kernel(cx):
+    """the opt-in 256 x 320 x 64 wide-tile kernel (hv_set_tuning(3, 4): N = 320, K >= 640, M % 256 == 0) at the level-0
+    feed-forward output shape of a frame shard (M = 36 864) and with several tiles per workgroup (M = 147 456): its three
+    output forms and the fused GroupNorm / LayerNorm partial statistics (one partial sum per 32-row wave block)"""
+    cx.lib.call("hv_set_tuning", 3, 4)
+    try:
+        for form in ("res", "ln", "plain"):
+            kc.case_gemm_forms(cx, M=36864, C=1280, N=320, P=768, form=form, seed=81)
+        kc.case_gemm_forms(cx, M=147456, C=640, N=320, P=6144, form="res", seed=82)
+        kc.case_gn_parts_gemm(cx, n=6, rows=6144, C=320, K=1280, seed=83, part_rows=32)
+        kc.case_ln_parts_gemm(cx, M=36864, C=320, K=640, seed=84)
+    finally:
+        cx.lib.call("hv_set_tuning", 3, 1)
+
+
 def test_gemm_epilogue_forms(cx):
     """the epilogue forms the engine launches (hv_gemm_epilogue_fast on the LDS-DMA kernel), every LDS-DMA tile shape"""
     for form in ("ln", "ln_yt", "ln_geglu", "res", "plain"):

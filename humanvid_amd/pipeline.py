@@ -203,17 +203,19 @@ class Pose2VideoPipeline:
         latents = 1 / 0.18215 * latents
         b = latents.shape[0]
         flat = latents.permute(0, 2, 1, 3, 4).reshape(b * video_length, *latents.shape[1:2], *latents.shape[3:])
-        world = 1 if self.shard is None else self.shard.world
+        # over every rank of the job: with window groups (FrameShard(window_groups=G)) the clip is finished and replicated on
+        # all of them, so the decode splits over all G x R ranks, not over the sub-group's R
+        world = 1 if self.shard is None else self.shard.all_world
         lo, n = 0, flat.shape[0]
         if world > 1 and flat.shape[0] % world == 0:
             n = flat.shape[0] // world
-            lo = self.shard.rank * n
+            lo = self.shard.all_rank * n
         step = max(1, int(frames_per_batch))
         frames = [self.vae.decode(flat[i:min(i + step, lo + n)].to(self.vae.dtype)).sample for i in range(lo, lo + n, step)]
         video = torch.cat(frames)
         if n != flat.shape[0]:
             full = torch.empty(flat.shape[0], *video.shape[1:], dtype=video.dtype, device=video.device)
-            self.shard.all_gather(full, video.contiguous())
+            self.shard.all_gather_everyone(full, video.contiguous())
             video = full
         video = video.view(b, video_length, *video.shape[1:]).permute(0, 2, 1, 3, 4)
         video = (video / 2 + 0.5).clamp(0, 1)

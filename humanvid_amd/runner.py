@@ -66,6 +66,10 @@ class FrameShard:
         self.group = group  # frame sharding + temporal exchange
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
+        # every rank of the job (== world / rank without window groups): what is not tied to a window -- the VAE decode of
+        # the finished clip -- is split over all of them
+        self.all_world = dist.get_world_size(self.all_group)
+        self.all_rank = dist.get_rank(self.all_group)
 
         # gloo (CPU tests, or several ranks sharing one GPU in the 1-GPU parity test) has no device
         # collectives: stage through host memory.  nccl (= RCCL over xGMI) runs on device buffers.
@@ -131,15 +135,20 @@ class FrameShard:
             return self.recorder.collective(fn)
         return fn()
 
-    def _all_gather(self, out: torch.Tensor, inp: torch.Tensor):
-        sent = inp.numel() * inp.element_size() * (self.world - 1)
+    def _all_gather(self, out: torch.Tensor, inp: torch.Tensor, everyone: bool = False):
+        group = self.all_group if everyone else self.group
+        sent = inp.numel() * inp.element_size() * ((self.all_world if everyone else self.world) - 1)
         if self.staged and inp.device.type != "cpu":
             def staged():
                 host_out = torch.empty(out.numel(), dtype=inp.dtype)
-                self.dist.all_gather_into_tensor(host_out, inp.cpu().reshape(-1), group=self.group)
+                self.dist.all_gather_into_tensor(host_out, inp.cpu().reshape(-1), group=group)
                 out.view(-1).copy_(host_out)
             return self._timed(sent, staged)
-        self._timed(sent, lambda: self.dist.all_gather_into_tensor(out, inp, group=self.group))
+        self._timed(sent, lambda: self.dist.all_gather_into_tensor(out, inp, group=group))
+
+    def all_gather_everyone(self, out: torch.Tensor, inp: torch.Tensor):
+        """all-gather over EVERY rank of the job (with window groups: across the groups), outside any recorded step"""
+        return self._all_gather(out, inp, everyone=True)
 
     def _all_reduce(self, t: torch.Tensor):
         # over ALL ranks of the job: with window groups the other groups hold the other windows' contributions

@@ -159,12 +159,13 @@ class _ToyVae(torch.nn.Module):
         return o
 
 
-def _decode_worker(rank, world, port, out_path):
+def _decode_worker(rank, world, port, out_path, window_groups=1):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from humanvid_amd.pipeline import Pose2VideoPipeline
 
-    pipe = Pose2VideoPipeline(_ToyVae(), None, None, None, None, None, None).enable_frame_sharding()
+    pipe = Pose2VideoPipeline(_ToyVae(), None, None, None, None, None, None).enable_frame_sharding(window_groups=window_groups)
+    assert pipe.shard.all_world == world and pipe.shard.world == world // window_groups
     lat = torch.randn(1, 4, 6, 8, 8, generator=torch.Generator().manual_seed(9))
     video = pipe.decode_latents(lat, frames_per_batch=2)
     if rank == 1:
@@ -192,4 +193,12 @@ def test_vae_decode_batched_and_frame_sharded_matches_per_frame_loop(tmp_path):
     s.close()
     out_path = str(tmp_path / "video.pt")
     mp.spawn(_decode_worker, args=(2, port, out_path), nprocs=2, join=True)
+    assert torch.allclose(torch.load(out_path), ref, atol=1e-6)
+    # window-parallel mode (two sub-groups of one rank): the decode still splits over BOTH ranks
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    out_path = str(tmp_path / "video_groups.pt")
+    mp.spawn(_decode_worker, args=(2, port, out_path, 2), nprocs=2, join=True)
     assert torch.allclose(torch.load(out_path), ref, atol=1e-6)

@@ -150,6 +150,36 @@ def case_affine_apply_cat(cx: Ctx, n_img=3, rows=50, C1=64, C2=32, seed=43):
     return e
 
 
+def case_fp8_amax_under_command_list_replay(cx: Ctx, n_img=2, Lk=72, H=8, D=40, seed=90):
+    """the fp8 pre-pass's per-head V amax is reset by a KERNEL (hv_attention_fp8_zero_kernel through hv_launch), so a
+    recorded command list (hv_cmdlist_*: the replay form of a frame-sharded denoising step) re-zeroes it on every replay.
+    With the round-2 hipMemsetAsync the reset was not recorded and the atomicMax kept the running maximum of every layer
+    and earlier step.  Record phase 1 once, shrink V in place, replay: the amax must follow."""
+    import ctypes
+
+    g = torch.Generator().manual_seed(seed)
+    Cc = H * D
+    k, vt = cx.bf(rnd(g, n_img * Lk, Cc)), cx.bf(rnd(g, Cc, n_img * Lk))
+    T = (Lk + 63) // 64
+    ks, va = torch.zeros(n_img, H, T, device=cx.device), torch.zeros(H, device=cx.device)
+    kw = dict(n_images=n_img, heads=H, D=D, L=Lk, ldk=Cc, ldvt=n_img * Lk, phase=1)
+    h = ctypes.c_void_p()
+    cx.lib.call("hv_cmdlist_begin")
+    try:
+        ops.attention_fp8_quantize(cx.lib, cx.stream, k, vt, ks, va, **kw)  # recorded (and executed)
+    finally:
+        cx.lib.call("hv_cmdlist_end", ctypes.byref(h))
+    cx.sync()
+    first = va.clone()
+    want = vt.float().view(H, D, n_img * Lk).abs().amax(dim=(1, 2))
+    assert nrmse(first, want) < 1e-6
+    vt.mul_(0.125)  # exact in bf16
+    cx.lib.call("hv_cmdlist_run", h, cx.stream)
+    cx.sync()
+    assert torch.equal(va, first * 0.125), (va, first)
+    cx.lib.call("hv_cmdlist_destroy", h)
+
+
 def case_layernorm_stats(cx: Ctx, M=77, C=320, seed=44, offset=3.0):
     """row statistics of hv_layernorm_stats (mean, 1/sqrt(var + eps)) against torch on the bf16-rounded rows; C = 320 / 640 /
     1280 take the several-rows-per-wave kernel, other widths the one-row-per-wave kernel; M not a multiple of the rows per

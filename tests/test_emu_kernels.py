@@ -102,6 +102,10 @@ def test_gemm_wide_tile_kernel(cx):
         cx.lib.call("hv_set_tuning", 2, 512)
 
 
+def test_fp8_amax_reset_is_recorded_by_command_lists(cx):
+    kc.case_fp8_amax_under_command_list_replay(cx)
+
+
 def test_affine_apply(cx):
     kc.case_affine_apply(cx, n_img=3, rows=50, C=64)
     kc.case_affine_apply(cx, n_img=2, rows=33, C=320, act=A.ACT_SILU, seed=41)

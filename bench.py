@@ -388,17 +388,24 @@ def main():
         if world > 1:
             # one more, eagerly launched step outside the timed region with every collective counted and bracketed by
             # events: collectives per step, bytes this rank sends, and the exchange time the step is exposed to
+            # (a diagnostic: whatever goes wrong in it must not take the bench line down -- every rank still reaches the
+            #  reductions below, with ok = 0)
             sh = pipe.shard
             sync_barrier()
             sh.reset_stats()
             sh.measure = True
             t0 = time.perf_counter()
-            one_step()
-            torch.cuda.synchronize()
-            wall = (time.perf_counter() - t0) * 1e3
-            sh.measure = False
-            prof["exchange"] = dict(collectives_per_step=sh.stats["collectives"], bytes_sent_per_rank=sh.stats["bytes_sent"],
-                                    exposed_exchange_ms=sh.exposed_ms(), eager_step_ms=wall)
+            try:
+                one_step()
+                torch.cuda.synchronize()
+                wall = (time.perf_counter() - t0) * 1e3
+                prof["exchange"] = dict(collectives_per_step=sh.stats["collectives"], bytes_sent_per_rank=sh.stats["bytes_sent"],
+                                        exposed_exchange_ms=sh.exposed_ms(), eager_step_ms=wall, ok=1.0)
+            except Exception as e:  # noqa: BLE001
+                prof["exchange"] = dict(collectives_per_step=0, bytes_sent_per_rank=0, exposed_exchange_ms=0.0, eager_step_ms=0.0,
+                                        ok=0.0, error=repr(e)[:200])
+            finally:
+                sh.measure = False
 
     if SETUP + Wm == 0:
         sync_barrier()
@@ -414,8 +421,9 @@ def main():
     exchange = None
     if world > 1 and "exchange" in prof:
         ex = prof["exchange"]
-        t = torch.tensor([ex["exposed_exchange_ms"], ex["eager_step_ms"]], device=dev)
+        t = torch.tensor([ex["exposed_exchange_ms"], ex["eager_step_ms"], -ex["ok"]], device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        ex = dict(ex, ok=bool(float(t[2]) <= -1.0))  # every rank measured
         exchange = dict(ex, exposed_exchange_ms=float(t[0]), eager_step_ms=float(t[1]),
                         note="one eagerly launched step after the timed region, max over ranks; exposed = event distance around "
                              "every collective on the compute stream (nothing overlaps the exchange yet)")

@@ -557,7 +557,8 @@ HV_DEV void hv_gemm_epilogue_fast_perm(const HvGemmParams& p, f32x4 (&acc)[4][NM
                 u32x2{__builtin_bit_cast(unsigned, a), __builtin_bit_cast(unsigned, b)};
         }
     }
-    if (STATS == 1 && p.gn_part != nullptr) {  // (wave-uniform) rows [m_base, + 16 NMF) lie in one image: hv_gemm_gn_parts
+    if (STATS == 1 && p.gn_part != nullptr && m_base < p.M) {  // (wave-uniform) rows [m_base, + 16 NMF) lie in one image: hv_gemm_gn_parts;
+        // a wave sub-tile that starts beyond the ragged M edge (M % 128 == 64 on the 128 x 128 kernel) has no part to write
         const int rows = 16 * NMF, parts = p.gn_rows_per_image / rows;
         const int img = m_base / p.gn_rows_per_image, part = (m_base - img * p.gn_rows_per_image) / rows;
         float* dst = p.gn_part + ((long)img * parts + part) * p.N * 2;

@@ -234,6 +234,7 @@ __global__ __launch_bounds__(256) void hv_gn_from_parts_kernel(HvGnPartsParams p
 
 static inline int hv_gn_from_parts_launch(const HvGnPartsParams& p, hipStream_t stream) {
     const int C = p.C1 + p.C2;
+    if (p.groups <= 0 || p.n_images <= 0) return -1;
     if (p.C1 <= 0 || p.C2 < 0 || C % p.groups != 0 || p.parts1 <= 0 || p.part1 == nullptr || p.pixels <= 0) return -1;
     if (p.C2 > 0 && (p.part2 == nullptr || p.parts2 <= 0)) return -1;
     hv_note("hv_gn_from_parts_kernel | n=%d C=%d parts=%d+%d", p.n_images, C, p.parts1, p.C2 > 0 ? p.parts2 : 0);

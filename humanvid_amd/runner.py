@@ -23,6 +23,9 @@ class Workspace:
     def __init__(self, device):
         self.device = device
         self.bufs: Dict[str, torch.Tensor] = {}
+        # tables keyed by an activation's ADDRESS (Runner.gn_parts / ln_parts: normalisation statistics left by the producer,
+        # with their "gnp_<address>" / "lnp_<address>" buffers here): purged when the activation buffer is reallocated
+        self.address_tables = []
 
     def get(self, name: str, shape, dtype=BF16) -> torch.Tensor:
         shape = tuple(int(s) for s in shape)
@@ -31,6 +34,12 @@ class Workspace:
             n *= s
         t = self.bufs.get(name)
         if t is None or t.dtype != dtype or t.numel() < n:
+            if t is not None:  # grown (e.g. a larger batch): what was keyed by the old address dies with it
+                old = t.data_ptr()
+                for pre in ("gnp_", "lnp_"):
+                    self.bufs.pop(f"{pre}{old}", None)
+                for table in self.address_tables:
+                    table.pop(old, None)
             t = torch.empty(max(n, 1), dtype=dtype, device=self.device)
             self.bufs[name] = t
         return t[:n].view(shape)
@@ -184,6 +193,7 @@ class Runner:
         self._pe_split: Dict[tuple, tuple] = {}
         self.gn_parts: Dict[int, torch.Tensor] = {}
         self.ln_parts: Dict[int, torch.Tensor] = {}  # the same for LayerNorm row statistics (gemm_ln / ln_stats)
+        self.ws.address_tables += [self.gn_parts, self.ln_parts]
         # HUMANVID_GN_FUSED=0: every GroupNorm reads its input again (hv_groupnorm_affine), for A/Bs
         self.gn_fused = os.environ.get("HUMANVID_GN_FUSED", "1") == "1"
         # GroupNorm apply + SiLU in front of a ResnetBlock3D convolution (resnet.py:215-222, 235-241) as its own pass

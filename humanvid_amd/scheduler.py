@@ -122,6 +122,13 @@ def fused_step_coefficients(sched, timestep: int, num_inference_steps: int):
     abar = getattr(sched, "alphas_cumprod", None)
     if abar is None:
         raise NotImplementedError("the scheduler has no alphas_cumprod: a DDIM-style scheduler is required")
+    # Only DDIM's update is fused.  Multistep / higher-order / ancestral samplers of diffusers (DPMSolver*, PNDM, UniPC,
+    # Euler*, Heun, LMS, KDPM2 ...) also carry alphas_cumprod and would pass the checks above while following a different
+    # update rule: recognised by what DDIM does not have (an order above 1, a sigma table, solver state) and refused.
+    if int(attr("order", 1) or 1) != 1 or hasattr(sched, "sigmas") or hasattr(sched, "model_outputs") or \
+            hasattr(sched, "ets") or attr("solver_order") is not None or attr("algorithm_type") is not None:
+        raise NotImplementedError(f"{type(sched).__name__} is not a DDIM-style scheduler: the fused CFG + DDIM step would sample "
+                                  "it with DDIM (eta = 0) coefficients")
     T = int(attr("num_train_timesteps", len(abar)))
     t = int(timestep)
     prev = t - T // int(num_inference_steps)

@@ -76,3 +76,36 @@ def rms_ncfhw(x: torch.Tensor) -> torch.Tensor:
 
 def rms_nhwc(x: torch.Tensor) -> torch.Tensor:
     return x.float().pow(2).mean(dim=(1, 2, 3)).sqrt()
+
+
+# ---- loop-body cases (oracle/gen_fullsize_steps_golden.py <-> tests/test_gpu_fullsize_steps.py) ----------------------
+# "steps3":   two consecutive denoising steps (i = 0: t = 999, zero terminal SNR, sqrt(abar) = 0; i = 1: t = 966) of the
+#             30-step schedule at config #3's size, one 24-frame window, PoseGuider + CameraPoseEncoder in the loop
+# "windows48": one step of a 48-frame clip (context 24, overlap 4 -> three overlapping windows, the geometry of config #5's
+#             step) at a reduced 32 x 32 latent: window accumulation + counter division + CFG + DDIM
+# "edge_t32": the LAST step of the 30-step schedule (t = 32 -> prev < 0 -> final_alpha_cumprod) at config #3's size
+STEP_CASES = {
+    "steps3": dict(F=24, h=96, w=64, steps=(0, 1), num_inference_steps=30),
+    "windows48": dict(F=48, h=32, w=32, steps=(0, 1), num_inference_steps=30),
+    "edge_t32": dict(F=24, h=96, w=64, steps=(29,), num_inference_steps=30),
+}
+GUIDANCE = 3.5
+
+
+def make_step_inputs(case: str, locations, channels_of):
+    """-> latents [1,4,F,h,w], pose images [1,3,F,8h,8w] in [0,1], Pluecker map [1,6,F,8h,8w], clip [1,1,768],
+    banks {loc: [2,N_l,C]} -- all from CPU generators with fixed seeds."""
+    c = STEP_CASES[case]
+    F, h, w = c["F"], c["h"], c["w"]
+    g = torch.Generator().manual_seed(1234)
+    lat = torch.randn(1, 4, F, h, w, generator=g)
+    pose = torch.rand(1, 3, F, 8 * h, 8 * w, generator=torch.Generator().manual_seed(11))
+    pl = torch.randn(1, 6, F, 8 * h, 8 * w, generator=torch.Generator().manual_seed(12))
+    clip = torch.randn(1, 1, 768, generator=torch.Generator().manual_seed(13))
+    gb = torch.Generator().manual_seed(15)
+    banks = {}
+    for loc in locations:
+        C = channels_of(loc)
+        lvl = level_of(loc, C)
+        banks[loc] = torch.randn(2, (h >> lvl) * (w >> lvl), C, generator=gb).half().float()
+    return lat, pose, pl, clip, banks

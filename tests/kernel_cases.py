@@ -446,8 +446,14 @@ def case_gn_parts_gemm(cx: Ctx, n=4, rows=128, C=320, K=128, groups=32, seed=52,
     kw = dict(bias=cx.dev(bias), residual=y)
     np_ = ops.gemm(cx.lib, cx.stream, xd, wd, y, gn_rows_per_image=rows, query_gn_parts=True, **kw)
     assert np_ == rows // part_rows, np_  # one partial sum per wave sub-tile: 64 rows (128 x 128 kernel), 32 (wide kernel)
-    part = torch.zeros(n, np_, C, 2, device=cx.device)
+    # the part table is followed by a sentinel tail: a wave sub-tile beyond the ragged M edge (M % 128 == 64 on the 128 x 128
+    # kernel: n * rows / 64 odd) must not write a part of an image that does not exist
+    store = torch.full((n * np_ * C * 2 + 2 * C * 2,), -777.0, device=cx.device)
+    part = store[:n * np_ * C * 2].view(n, np_, C, 2)
+    part.zero_()
     ops.gemm(cx.lib, cx.stream, xd, wd, y, gn_part=part, gn_rows_per_image=rows, **kw)
+    cx.sync()
+    assert bool((store[n * np_ * C * 2:] == -777.0).all()), "gn_part written beyond the last image"
     gamma, beta = 1 + 0.2 * rnd(g, C), 0.1 * rnd(g, C)
     sc, sh = torch.zeros(n, C, device=cx.device), torch.zeros(n, C, device=cx.device)
     ops.groupnorm_from_parts(cx.lib, cx.stream, part, cx.dev(gamma), cx.dev(beta), groups, 1e-5, rows, sc, sh)

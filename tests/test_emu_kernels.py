@@ -383,5 +383,6 @@ def test_groupnorm_statistics_from_the_producing_kernels(cx):
     kc.case_gn_parts_conv(cx, n=1, H=8, W=16, Cin=32, Cout=128, C2=64, seed=53)        # two sources: a group straddles the seam
     kc.case_gn_parts_conv(cx, n=1, H=8, W=8, Cin=32, Cout=64, mode=A.CONV_UP2, seed=54)  # upsample-folded: 16 x 16 output
     kc.case_gn_parts_gemm(cx, n=3, rows=128, C=320, K=64)
+    kc.case_gn_parts_gemm(cx, n=5, rows=64, C=320, K=64, seed=61)                       # M % 128 == 64: the last wave row block starts at M
     kc.case_ln_parts_gemm(cx, M=300, C=128, K=64)
     kc.case_ln_parts_gemm(cx, M=520, C=320, K=64, residual=False, seed=60)

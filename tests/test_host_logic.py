@@ -188,6 +188,15 @@ def test_fused_step_coefficients_cover_v_and_epsilon_prediction():
         fused_step_coefficients(bad, 999, 25)  # zero terminal SNR has no epsilon form
     with pytest.raises(NotImplementedError):
         fused_step_coefficients(types.SimpleNamespace(config=dict(prediction_type="sample"), alphas_cumprod=s.alphas_cumprod), 10, 25)
+    # diffusers-style schedulers that are NOT DDIM also carry alphas_cumprod: refused, not sampled with DDIM coefficients
+    for extra in (dict(order=2), dict(sigmas=torch.ones(26)), dict(model_outputs=[None, None]), dict(ets=[])):
+        other = types.SimpleNamespace(alphas_cumprod=s.alphas_cumprod, config=dict(prediction_type="epsilon"), **extra)
+        with pytest.raises(NotImplementedError):
+            fused_step_coefficients(other, 10, 25)
+    dpm = types.SimpleNamespace(alphas_cumprod=s.alphas_cumprod, config=dict(prediction_type="epsilon", solver_order=2,
+                                                                               algorithm_type="dpmsolver++"))
+    with pytest.raises(NotImplementedError):
+        fused_step_coefficients(dpm, 10, 25)
 
 
 def test_camera_front_end_matches_golden():

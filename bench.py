@@ -288,6 +288,10 @@ def main():
     ap.add_argument("--window-groups", type=int, default=1,
                     help="N > 1 GPUs: split the ranks into this many groups that take different context windows of a step "
                          "(window-parallel x frame-shard; clips with several windows per step, e.g. --config 5)")
+    ap.add_argument("--cfg-streams", default="auto", choices=["auto", "0", "1"],
+                    help="N > 1 GPUs: the two CFG halves of a step on two streams, replayed interleaved, so that one half's temporal "
+                         "exchange runs under the other half's kernels (DESIGN.md section 5).  auto: on, after a three-step probe "
+                         "run outside the timed region; if the probe raises, the serial path is timed and the line says so")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="skip the profiled extra step (roofline block)")
@@ -407,6 +411,26 @@ def main():
             finally:
                 sh.measure = False
 
+    cfg_streams = None
+    if world > 1:
+        sh = pipe.shard
+        sh.overlap_cfg = args.cfg_streams != "0" and not args.no_graph
+        cfg_streams = "on" if sh.overlap_cfg else "off"
+        if sh.overlap_cfg and args.cfg_streams == "auto":
+            # probe outside the timed region: eager step, recorded step, interleaved replay -- the path has only ever run on the
+            # host-staged transport of the one-GPU tests; a failure here must not take the bench line down
+            ok = torch.ones(1, device=dev)
+            try:
+                pipe.denoise(latents.clone(), pose, plucker, clip, n_inf, 3.5, max_steps=3)
+                torch.cuda.synchronize()
+            except Exception as e:  # noqa: BLE001
+                ok.zero_()
+                cfg_streams = "off (probe failed: " + repr(e)[:160] + ")"
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if float(ok) < 1.0:
+                sh.overlap_cfg = False
+                if cfg_streams == "on":
+                    cfg_streams = "off (probe failed on another rank)"
     if SETUP + Wm == 0:
         sync_barrier()
         times["t0"] = time.perf_counter()
@@ -425,8 +449,10 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         ex = dict(ex, ok=bool(float(t[2]) <= -1.0))  # every rank measured
         exchange = dict(ex, exposed_exchange_ms=float(t[0]), eager_step_ms=float(t[1]),
-                        note="one eagerly launched step after the timed region, max over ranks; exposed = event distance around "
-                             "every collective on the compute stream (nothing overlaps the exchange yet)")
+                        note="one EAGERLY launched step after the timed region, max over ranks; exposed = event distance around "
+                             "every collective on its stream: an upper bound -- the eager step runs the CFG halves one after "
+                             "the other, the timed steps replay them interleaved (cfg_streams) so that one half's exchange "
+                             "runs under the other half's kernels")
     if rank == 0:
         cfg = dict(DEFAULT_UNET3D_CONFIG)
         cfg.update(SD15_INFERENCE_V2)
@@ -444,7 +470,8 @@ def main():
             "dtype": "bf16 (fp8 e4m3 QK^T / PV in the spatial attention)" if fp8_attn else "bf16", "data": "synthetic",
             "config": {"workload": cfgsel["what"] + f"; CFG 3.5, SD-1.5 UNet3D + motion modules, {len(windows)} window(s) "
                                    "per step, DDIM v-pred",
-                       "parallelism": par, "hip_graph": not args.no_graph and world == 1},
+                       "parallelism": par, "hip_graph": not args.no_graph,
+                       **({} if cfg_streams is None else {"cfg_streams": cfg_streams})},
             "step_algorithmic_tflop": fl_total / 1e12,
             "step_tflops_per_gpu": fl_total / 1e12 / (ms_step / 1e3) / world,
             "step_frac_of_mfma_peak": fl_total / 1e12 / (ms_step / 1e3) / world / PEAK_BF16_TFLOPS,

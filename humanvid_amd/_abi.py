@@ -79,7 +79,7 @@ class AttentionParams(_S):
         ("K2", P), ("ldk2", L), ("Vt2", P), ("ldvt2", L), ("bank_sel", P),
         ("O", P), ("ldo", L),
         ("n_images", I), ("heads", I), ("D", I), ("Lq", I), ("L1", I), ("L2", I),
-        ("scale", F), ("v_row_major", I),
+        ("scale", F),
     ]
 
 

@@ -94,8 +94,7 @@ int hv_attention(const hv_attention_params* p, void* stream) {
     int rc = hvk_attention(*p, (hipStream_t)stream);
     if (rc == -2) return hv_fail(HV_ENOTSUP, "hv_attention: head dim must be 40, 80 or 160");
     if (rc != 0)
-        return hv_fail(HV_EINVAL, "hv_attention: need 16-byte aligned strides (transposed-V form: L1 % 8 == 0, L2 % 8 == 0; "
-                                  "row-major-V form: heads * D a multiple of 320)");
+        return hv_fail(HV_EINVAL, "hv_attention: need 16-byte aligned strides, L1 % 8 == 0, L2 % 8 == 0, tensors below 4 GiB");
     return hv_check_launch("hv_attention");
 }
 
@@ -122,14 +121,16 @@ int hv_attention_fp8(const hv_attention_params* p, const float* kscale, const fl
     return hv_check_launch("hv_attention_fp8");
 }
 
+static int g_hv_cmdlist_graphs = 1;  // hv_set_tuning(HV_TUNE_CMDLIST_GRAPHS): 0 = hv_cmdlist_run re-issues the closures on every run (A/B)
 int hv_set_tuning(int key, int value) {
-    if (key == HV_TUNE_ATTN_QT_D40 && (value == 2 || value == 4)) hvk_attention_tune(40, value);
+    if (key == HV_TUNE_ATTN_D40 && (value >= 0 && value <= 2)) hvk_attention_tune(40, value);
     else if (key == HV_TUNE_ATTN_QT_D160 && (value == 1 || value == 2)) hvk_attention_tune(160, value);
     else if (key == HV_TUNE_GEMM_MAX_GRID && value >= 8 && value % 8 == 0) hvk_gemm_tune(value);
-    else if (key == HV_TUNE_GEMM_GLDS && (value >= 0 && value <= 4)) hvk_gemm_use_glds(value);
+    else if (key == HV_TUNE_GEMM_GLDS && (value >= 0 && value <= 6)) hvk_gemm_use_glds(value);
     else if (key == HV_TUNE_GEMM_PERM && (value == 0 || value == 1)) hvk_gemm_perm(value);
     else if (key == HV_TUNE_CONV_GLDS && (value == 0 || value == 1)) hvk_conv_use_glds(value);
     else if (key == HV_TUNE_CONV_BIG && (value >= 0 && value <= 3)) hvk_conv_use_big(value);
+    else if (key == HV_TUNE_CMDLIST_GRAPHS && (value == 0 || value == 1)) g_hv_cmdlist_graphs = value;
     else return hv_fail(HV_EINVAL, "hv_set_tuning: unknown key/value");
     return HV_OK;
 }
@@ -226,9 +227,36 @@ int hv_cmdlist_end(void** list_out) {
     return HV_OK;
 }
 int hv_cmdlist_size(void* list) { return list ? (int)((HvCmdList*)list)->cmds.size() : 0; }
+#ifndef HV_EMU
+static hipStream_t g_hv_capture_stream = nullptr;
+#endif
 int hv_cmdlist_run(void* list, void* stream) {
     if (!list) return hv_fail(HV_EINVAL, "hv_cmdlist_run: null list");
-    for (auto& c : ((HvCmdList*)list)->cmds) c((hipStream_t)stream);
+    HvCmdList* cl = (HvCmdList*)list;
+#ifndef HV_EMU
+    if (g_hv_cmdlist_graphs && !cl->cmds.empty()) {
+        if (cl->exec == nullptr) {  // first run: capture the segment's launches into a graph instead of issuing them
+            if (!g_hv_capture_stream && hipStreamCreateWithFlags(&g_hv_capture_stream, hipStreamNonBlocking) != hipSuccess)
+                return hv_fail(HV_EHIP, "hv_cmdlist_run: capture stream");
+            hipError_t e = hipStreamBeginCapture(g_hv_capture_stream, hipStreamCaptureModeRelaxed);
+            if (e != hipSuccess) return hv_fail(HV_EHIP, hipGetErrorString(e));
+            for (auto& c : cl->cmds) c(g_hv_capture_stream);
+            hipGraph_t g = nullptr;
+            e = hipStreamEndCapture(g_hv_capture_stream, &g);
+            if (e != hipSuccess) return hv_fail(HV_EHIP, hipGetErrorString(e));
+            e = hipGraphInstantiate(&cl->exec, g, nullptr, nullptr, 0);
+            (void)hipGraphDestroy(g);
+            if (e != hipSuccess) {
+                cl->exec = nullptr;
+                return hv_fail(HV_EHIP, hipGetErrorString(e));
+            }
+        }
+        const hipError_t e = hipGraphLaunch(cl->exec, (hipStream_t)stream);
+        if (e != hipSuccess) return hv_fail(HV_EHIP, hipGetErrorString(e));
+        return HV_OK;
+    }
+#endif
+    for (auto& c : cl->cmds) c((hipStream_t)stream);
     return hv_check_launch("hv_cmdlist_run");
 }
 int hv_cmdlist_destroy(void* list) {

@@ -32,31 +32,13 @@
 #pragma once
 #include "hv_common.h"
 #include "humanvid_hip.h"
+#include "hv_attention40.h"
 
 // phase timestamps for tools/attn_trace.hip (which includes hv_gemm.h first with HV_GEMM_TRACE defined)
 #ifndef HV_TRACE
 #define HV_TRACE(id)
 #endif
 
-#ifndef HV_ATTN_STRIDE32
-#define HV_ATTN_STRIDE32 1  // 0: the round-2 LDS row strides (A/B builds)
-#endif
-#ifndef HV_ATTN_OCC40Q4
-#define HV_ATTN_OCC40Q4 2
-#endif
-#ifndef HV_ATTN_OCC40
-#define HV_ATTN_OCC40 4
-#endif
-#ifndef HV_ATTN_ABL
-#define HV_ATTN_ABL 0  // ablation builds (tools/attn_ablation.sh; timing only, results are wrong): 1 no exp, 2 no max test,
-                       // 4 no bf16 convert, 8 no fragment LDS reads, 16 no tile staging, 32 no barrier,
-                       // 64 fragment reads issued but not waited for
-#endif
-#ifndef HV_ATTN_ONES
-// Denominator through the MFMA: d = 40 pads V^T to 48 rows; the first spare row is a row of ones, so the P.V MFMA that is
-// issued anyway also accumulates sum(P) and the 16 VALU adds per query fragment and tile disappear.
-#define HV_ATTN_ONES 1
-#endif
 #ifndef HV_ATTN_THR
 #define HV_ATTN_THR 8.0f  // log2 units: probabilities stay below 2^THR before the reference maximum is raised
 #endif
@@ -69,14 +51,15 @@ struct HvAttnGeom {
     static constexpr int DT = (D + 15) / 16;          // 16-row fragments of V^T / O^T
     static constexpr int DK = 32 * NFULL;
     static constexpr int DV = 16 * DT;
-    static constexpr bool ONES = HV_ATTN_ONES && DV > D;              // spare V^T row available for the denominator
+    static constexpr bool ONES = DV > D;  // spare V^T row available: a row of ones, so that the P.V MFMA that is issued anyway also
+                                          // accumulates sum(P) (d = 40 pads V^T to 48 rows) and the 16 VALU adds per query fragment and tile disappear
     // LDS row strides (bytes): = 32 (mod 64).  A ds_read_b128 is served in the lane groups {0-3, 12-15, 20-27}, {4-11, 16-19,
     // 28-31}, ... (MI355X_MICROARCH.md, LDS table): a group mixes two quads of a fragment read, i.e. rows r16 at byte offset
     // 16 q and rows r16' at 16 (q + 1).  With the "odd multiple of 16 bytes" stride of rounds 1-2 (144) every fragment read
     // was a 2-way bank conflict under that grouping; strides of 96, 160, 224, ... are conflict-free (checked per group with
     // the documented bank rule, the same model that reproduces the conflict-free GEMM swizzle).
     // (d = 80 keeps 208 / 144: with 224 / 160 only two workgroups fit a CU instead of three, measured +17 %)
-    static constexpr bool S32 = HV_ATTN_STRIDE32 && D != 80;
+    static constexpr bool S32 = D != 80;
     static constexpr int KRS = S32 ? ((DK * 2 + 31) / 64) * 64 + 32 : DK * 2 + 16;  // K rows: DK * 2 data bytes
     static constexpr int VRS = S32 ? 160 : 64 * 2 + 16;                                // V^T rows: 64 keys
     static constexpr int KBYTES = 64 * KRS;
@@ -99,7 +82,7 @@ struct HvAttnGeom {
 // d = 40 / 80 / 160): more resident waves let one wave's softmax VALU overlap another's MFMA
 template <int D, int QT>
 struct HvAttnOcc {
-    static constexpr int value = (D == 40 && QT == 2) ? HV_ATTN_OCC40 : ((D == 80 && QT == 2) ? 2 : ((D == 40 && QT == 4) ? HV_ATTN_OCC40Q4 : 1));
+    static constexpr int value = (D == 40 && QT == 2) ? 4 : ((D == 80 && QT == 2) ? 2 : 1);
 };
 
 template <int D, int QT, bool MASK>
@@ -309,11 +292,11 @@ __global__ __launch_bounds__(256, (HvAttnOcc<D, QT>::value)) void hv_attention_k
     for (int ti = 0; ti < ntiles; ++ti) {
         const int buf = ti & 1;
         HV_TRACE(1);
-        if (!(HV_ATTN_ABL & 16)) store_tile(buf);
+        store_tile(buf);
         HV_TRACE(2);
-        if (!(HV_ATTN_ABL & 32)) __syncthreads();
+        __syncthreads();
         HV_TRACE(3);
-        if (!(HV_ATTN_ABL & 16) && ti + 1 < ntiles) load_tile(ti + 1);
+        if (ti + 1 < ntiles) load_tile(ti + 1);
         HV_TRACE(4);
         const unsigned char* kb = Ks + buf * G::KBYTES + r16 * G::KRS;
         const unsigned char* vb = Vs + buf * G::VBYTES + r16 * G::VRS + quad * 16;
@@ -332,11 +315,7 @@ __global__ __launch_bounds__(256, (HvAttnOcc<D, QT>::value)) void hv_attention_k
             for (int s = 0; s < NFULL; ++s) {
                 // (issuing all fragment reads of the tile ahead of their MFMAs -- 24-32 more registers, three waves per SIMD -- was
                 //  measured 3 % slower at d = 40: the waits it removes are worth less than the fourth wave)
-                bf16x8 kf = (HV_ATTN_ABL & 8) ? qf[0][s] : hv_as_bf16x8(hv_ld16(kb + (16 * kvf) * G::KRS + s * 64 + quad * 16));
-#if (HV_ATTN_ABL & 64) && !defined(HV_EMU)
-                asm volatile("" ::"v"(kf));  // the read is issued, nothing waits for it
-                kf = qf[0][s];
-#endif
+                const bf16x8 kf = hv_as_bf16x8(hv_ld16(kb + (16 * kvf) * G::KRS + s * 64 + quad * 16));
 #pragma unroll
                 for (int qt = 0; qt < QT; ++qt)
                     sacc[qt][kvf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[qt][s], sacc[qt][kvf], 0, 0, 0);
@@ -376,7 +355,7 @@ __global__ __launch_bounds__(256, (HvAttnOcc<D, QT>::value)) void hv_attention_k
 #pragma unroll
             for (int kvf = 0; kvf < 4; ++kvf)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) pv[kvf][r] = (HV_ATTN_ABL & 1) ? sacc[qt][kvf][r] : __builtin_amdgcn_exp2f(sacc[qt][kvf][r]);
+                for (int r = 0; r < 4; ++r) pv[kvf][r] = __builtin_amdgcn_exp2f(sacc[qt][kvf][r]);
             float pm = fmaxf(fmaxf(pv[0][0], pv[0][1]), pv[0][2]);
             pm = fmaxf(fmaxf(pm, pv[0][3]), pv[1][0]);
             pm = fmaxf(fmaxf(pm, pv[1][1]), pv[1][2]);
@@ -386,7 +365,7 @@ __global__ __launch_bounds__(256, (HvAttnOcc<D, QT>::value)) void hv_attention_k
             pm = fmaxf(fmaxf(pm, pv[3][1]), pv[3][2]);
             pm = fmaxf(pm, pv[3][3]);
             const bool first = ti == 0;  // the first tile fixes the reference maximum (it starts at 0, not at a score)
-            if ((HV_ATTN_ABL & 2) ? first : (first || __any(pm > HV_ATTN_PTHR))) {
+            if (first || __any(pm > HV_ATTN_PTHR)) {
                 // rare: raise the reference maximum by the query's tile maximum (reduced over the four quads), redo the
                 // exponentials against it and scale everything that is still at the old reference exactly once.  The
                 // scores are recomputed from the K tile in LDS (keeping them live beside the probabilities on the common
@@ -437,13 +416,6 @@ __global__ __launch_bounds__(256, (HvAttnOcc<D, QT>::value)) void hv_attention_k
                 u32x4 w = {hv_pack2(pv[2 * ks][0], pv[2 * ks][1]), hv_pack2(pv[2 * ks][2], pv[2 * ks][3]),
                            hv_pack2(pv[2 * ks + 1][0], pv[2 * ks + 1][1]),
                            hv_pack2(pv[2 * ks + 1][2], pv[2 * ks + 1][3])};
-                if (HV_ATTN_ABL & 4) {
-#ifndef HV_EMU
-                    asm volatile("" ::"v"(pv[2 * ks][0]), "v"(pv[2 * ks][1]), "v"(pv[2 * ks][2]), "v"(pv[2 * ks][3]), "v"(pv[2 * ks + 1][0]),
-                                 "v"(pv[2 * ks + 1][1]), "v"(pv[2 * ks + 1][2]), "v"(pv[2 * ks + 1][3]));
-#endif
-                    pf[qt][ks] = qf[qt][0];
-                } else
                 pf[qt][ks] = hv_as_bf16x8(w);
             }
         }
@@ -456,11 +428,7 @@ __global__ __launch_bounds__(256, (HvAttnOcc<D, QT>::value)) void hv_attention_k
         for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
-                bf16x8 vf = (HV_ATTN_ABL & 8) ? qf[0][0] : hv_as_bf16x8(hv_ld16(vb + (16 * dt) * G::VRS + ks * 64));
-#if (HV_ATTN_ABL & 64) && !defined(HV_EMU)
-                asm volatile("" ::"v"(vf));
-                vf = qf[0][0];
-#endif
+                const bf16x8 vf = hv_as_bf16x8(hv_ld16(vb + (16 * dt) * G::VRS + ks * 64));
 #pragma unroll
                 for (int qt = 0; qt < QT; ++qt)
                     oacc[qt][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[qt][ks], oacc[qt][dt], 0, 0, 0);
@@ -513,8 +481,8 @@ static inline void hv_attention_launch_t(const hv_attention_params& p, hipStream
         hv_launch(hv_attention_kernel<D, QT, false>, dim3(grid), dim3(256), stream, p);
 }
 
-// tuning knobs (hv_set_tuning): query fragments per wave, per head dim
-static int g_hv_attn_qt40 = 2, g_hv_attn_qt160 = 2;
+// tuning knob (hv_set_tuning): query fragments per wave at head dim 160
+static int g_hv_attn_qt160 = 2;
 
 static inline int hv_attention_launch(const hv_attention_params& p, hipStream_t stream) {
     if (p.L1 <= 0 || p.L1 % 8 != 0 || p.L2 % 8 != 0 || p.Lq <= 0) return -1;
@@ -533,7 +501,7 @@ static inline int hv_attention_launch(const hv_attention_params& p, hipStream_t 
     }
     switch (p.D) {
         case 40:
-            if (g_hv_attn_qt40 == 4) hv_attention_launch_t<40, 4>(p, stream);
+            if (g_hv_attn40) hv_attention40_launch(p, stream);  // the dedicated level-0 kernel (hv_attention40.h)
             else hv_attention_launch_t<40, 2>(p, stream);
             break;
         case 80: hv_attention_launch_t<80, 2>(p, stream); break;

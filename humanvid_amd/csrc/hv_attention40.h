@@ -1,0 +1,357 @@
+// hv_attention40.h -- spatial self-attention with reference-bank keys for head dim 40 (SD-1.5 level 0: 320 channels over
+// 8 heads), the shape that carries 19 % of a denoising step at 24f x 768x512 (five launches of 48 images x 6144 queries
+// against 6144 own + 6144 bank keys).  Same semantics and parameter block as hv_attention (hv_attention.h; reference:
+// /root/reference/src/models/mutual_self_attention.py:147-186 over diffusers' AttnProcessor2_0), other structure.
+//
+// What the round-3 measurements said about the generic kernel at this shape (profiles/r03_attn_ablation.txt, 4.2 ms per
+// launch): the MFMAs alone take 1.47 ms -- 40 % of them padding (QK^T 40 -> 64 deep, PV 40 -> 48 rows) --, the 14 fragment
+// reads per tile and wave cost 1.5 ms, staging the K / V^T tiles through registers into LDS 1.55 ms, softmax VALU 1.1 ms.
+// This kernel (round 4) changes the four things those numbers point at:
+//  * S^T = K.Q^T on v_mfma_f32_32x32x16_bf16: 16-deep steps pad the head dim to 48 instead of 64 (-25 % QK^T MFMA time),
+//    one K fragment read feeds a 32-cycle MFMA over 32 queries (six K reads per 64-key tile and wave instead of eight), and
+//    no accumulation chain mixes MFMA shapes (the gfx950 hazard of profiles/r02_mfma_chain_hazard.md): S^T chains are
+//    32x32x16 only, O^T chains 16x16x32 only;
+//  * the probabilities go from the 32 x 32 S^T layout (lane = query l & 31, half l >> 5 holds 16 of the block's 32 keys)
+//    to the B operand of O^T += V^T.P^T (16x16x32: lane = query l & 15, quad l >> 4 holds 8 keys) with four
+//    v_permlane16_swap per 32-key block -- the K rows are staged in the order that makes the swapped dwords line up with
+//    the natural key order of V^T (below), so nothing else moves;
+//  * 256 queries per workgroup (8 waves x 32): a staged K / V^T tile serves twice the queries of the generic kernel's 128
+//    -- half the staging loads, LDS stores and barriers per query; 30 KB of LDS, two workgroups per CU;
+//  * softmax VALU work per score: the query's reference maximum rides in the MFMA (K is augmented by a column of ones at
+//    head-dim index 40, Q by -m there: the MFMA delivers s - m with C = 0 -- no accumulator initialisation moves, no
+//    subtraction), the "some probability exceeds 2^THR" test runs on the PACKED bf16 pairs (v_pk_max_u16: positive bf16
+//    order like unsigned integers -- 15 instead of 31 maxima), exponentials in the exp2 domain as before.
+// The reference maximum therefore lives in bf16 (it is an element of the Q operand); the rescale factors are computed from
+// the rounded values, so every tile of a query is exponentiated against exactly the maximum its O^T / denominator carry
+// (the softmax is invariant to the choice of reference as long as it is used consistently).
+//
+// Key order.  S^T block (32 keys x 32 queries), C/D layout of the 32x32 MFMA: lane l, register i <-> row (i & 3) + 8 (i >> 2)
+// + 4 (l >> 5).  K tile rows are staged so that LDS row 8 a + 4 b + c of a 32-key block holds key 16 b + 4 a + c: register i
+// of half b then IS key 16 b + i, the packed pair j (registers 2 j, 2 j + 1) keys 16 b + 2 j (+1), and after
+// v_permlane16_swap(pair d, pair d + 4) quad q of the result holds keys 8 q + 2 d (+1) for the queries r16 (first result:
+// queries 0-15 of the wave's 32, second: 16-31) -- dword d of the PV B operand with V^T in natural key order.
+#pragma once
+#include "hv_common.h"
+#include "humanvid_hip.h"
+
+#ifndef HV_ATTN_THR
+#define HV_ATTN_THR 8.0f
+#endif
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned short hv_u16x2 __attribute__((ext_vector_type(2)));
+
+// v_permlane16_swap: odd 16-lane rows of `a` are exchanged with even rows of `b`
+HV_DEV void hv_swap16_pair(unsigned& a, unsigned& b) {
+#ifndef HV_EMU
+    const auto r = __builtin_amdgcn_permlane16_swap(a, b, false, false);
+    a = r[0];
+    b = r[1];
+#else
+    const int lane = threadIdx.x & 63;
+    const bool odd = (lane >> 4) & 1;
+    const unsigned xa = __shfl(b, lane ^ 16), xb = __shfl(a, lane ^ 16);
+    a = odd ? xa : a;
+    b = odd ? b : xb;
+#endif
+}
+HV_DEV unsigned hv_pk_max_u16(unsigned a, unsigned b) {
+    return __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(hv_u16x2, a), __builtin_bit_cast(hv_u16x2, b)));
+}
+
+struct HvAttn40Geom {
+    static constexpr int D = 40, NW = 8, BQ = 32 * NW;
+    static constexpr int KRS = 112;  // K row pitch: 80 data bytes + the augmented column (bf16 1.0 at byte 80) + padding; 28 dwords:
+                                     // the 16 rows of a ds_read_b128 lane group (equal column offset in the 32x32 A-operand read)
+                                     // fall on 16 different 4-dword bank windows (28 r mod 64 is a permutation of the multiples of 4)
+    static constexpr int VRS = 160;  // V^T row pitch (64 keys = 128 data bytes): conflict-free for the 16x16x32 A-operand read
+    static constexpr int DV = 48;    // V^T rows: 40 channels, the row of ones (denominator), 7 zero rows
+    static constexpr int KBYTES = 64 * KRS, VBYTES = DV * VRS;
+    static constexpr int KCH = 64 * 5, VCH = 40 * 8;  // 16-byte chunks of a K / V^T tile: 320 each
+    static constexpr int VT0 = 512 - VCH;              // first thread of the V^T loaders (threads 192 .. 511; K: threads 0 .. 319)
+};
+
+template <bool MASK>
+__global__ __launch_bounds__(512, 4) void hv_attention40_kernel(hv_attention_params p, int head_major) {
+    using G = HvAttn40Geom;
+    constexpr int D = G::D;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * (G::KBYTES + G::VBYTES)];
+    unsigned char* Ks = smem;
+    unsigned char* Vs = smem + 2 * G::KBYTES;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+#ifndef HV_EMU
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#else
+    const int wave = tid >> 6;
+#endif
+    const int r16 = lane & 15, quad = lane >> 4, l32 = lane & 31, half = lane >> 5;
+
+    const int nqb = (p.Lq + G::BQ - 1) / G::BQ;
+    const int total = nqb * p.heads * p.n_images;
+    const int cpx = gridDim.x / 8;
+    int t = (blockIdx.x % 8) * cpx + blockIdx.x / 8;  // XCD x walks the contiguous range [x cpx, (x + 1) cpx)
+    if (t >= total) return;
+    int qb, head;
+    if (head_major) {  // the 8 heads of a query block run next to each other: their 80-byte output pieces fill whole lines in L2
+        head = t % p.heads;
+        t /= p.heads;
+        qb = t % nqb;
+        t /= nqb;
+    } else {  // the query blocks of an (image, head) run next to each other: its K / V^T stream through L2 once
+        qb = t % nqb;
+        t /= nqb;
+        head = t % p.heads;
+        t /= p.heads;
+    }
+    int img = t;
+    // alternate between the CFG halves (the conditional images attend to twice the keys): every XCD gets the same mix
+    if ((p.n_images & 1) == 0) img = (img & 1) * (p.n_images >> 1) + (img >> 1);
+    const int sel = (p.bank_sel != nullptr && p.L2 > 0) ? p.bank_sel[img] : -1;
+    const int T1 = (p.L1 + 63) / 64;
+    const int T2 = sel >= 0 ? (p.L2 + 63) / 64 : 0;
+    const int ntiles = T1 + T2;
+
+    // LDS: zero everything once (the padding is never overwritten by the tile stores), then the augmented K column (bf16 1.0
+    // at head-dim index 40 of every key row) and the V^T row of ones (row 40: the P.V MFMA accumulates the denominator)
+    for (int i = tid; i < 2 * (G::KBYTES + G::VBYTES) / 16; i += 512) hv_st16(smem + i * 16, u32x4{0u, 0u, 0u, 0u});
+    __syncthreads();
+    if (tid < 128) *reinterpret_cast<unsigned*>(Ks + (tid >> 6) * G::KBYTES + (tid & 63) * G::KRS + 2 * D) = 0x00003F80u;
+    if (tid >= 128 && tid < 144)
+        hv_st16(Vs + ((tid - 128) >> 3) * G::VBYTES + D * G::VRS + ((tid - 128) & 7) * 16,
+                u32x4{0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u});
+
+    // ---- query fragments: B operand of S^T = K.Q^T (32x32x16): lane = query l32, elements = head-dim 16 s + 8 half + 0..7;
+    //      pre-multiplied by scale * log2(e) (scores come out of the MFMA in the exp2 domain); step 2 of the upper half is the
+    //      augmented part: element 0 carries -m (the query's reference maximum, negated), the rest is zero
+    bf16x8 qf[3];
+    const int q_wave = qb * G::BQ + wave * 32;
+    {
+        const int q = q_wave + l32;
+        const bf16_t* qrow = p.Q + ((long)img * p.Lq + q) * p.ldq + head * D;
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {
+            u32x4 v = {0u, 0u, 0u, 0u};
+            if (q < p.Lq && 16 * s + 8 * half + 8 <= D) v = hv_ld16(qrow + 16 * s + 8 * half);
+            float f[8];
+            hv_unpack8(v, f);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) f[e] *= p.scale * 1.44269504089f;
+            qf[s] = hv_as_bf16x8(hv_pack8(f));
+        }
+    }
+    float mneg = 0.f;  // -m of this lane's query: always exactly representable in bf16 (it is what qf[2][0] of the upper half holds)
+
+    // ---- tile staging: one 16-byte chunk of the K tile (threads 0 .. 319: waves 0-4) and / or one of the V^T tile (threads
+    //      192 .. 511: waves 3-7) per thread, through registers (the loads of tile t + 1 fly during the arithmetic of tile t)
+    const bool k_loader = wave < 5, v_loader = wave >= 3;  // (wave-uniform)
+    const int krow = tid / 5, kcol = (tid - 5 * krow) * 16;  // key row within the tile, byte within its 80-byte head slice
+    const int vid = tid - G::VT0, vrow = vid >> 3, vcol = (vid & 7) * 16;  // V^T channel row, byte within its 128 bytes (8 keys per chunk)
+    // key 16 b + 4 a + c of a 32-key block is staged at row 8 a + 4 b + c (see the header)
+    const int klds = ((krow & 32) | (((krow >> 2) & 3) << 3) | (((krow >> 4) & 1) << 2) | (krow & 3)) * G::KRS + kcol;
+    const int vlds = vrow * G::VRS + vcol;
+    u32x4 kreg = {0u, 0u, 0u, 0u}, vreg = {0u, 0u, 0u, 0u};
+    const char* kbase = nullptr;
+    const char* vbase = nullptr;
+    unsigned kstep = 0, koff = 0, voff = 0;
+    int src_kv0 = 0, src_L = 0;
+    auto set_source = [&](bool bank) {
+        const unsigned rowbase = bank ? (unsigned)sel * (unsigned)p.L2 : (unsigned)img * (unsigned)p.L1;
+        const unsigned ldk2 = (unsigned)(bank ? p.ldk2 : p.ldk) * 2u, ldv2 = (unsigned)(bank ? p.ldvt2 : p.ldvt) * 2u;  // bytes
+        kbase = reinterpret_cast<const char*>(bank ? p.K2 : p.K) + ((size_t)rowbase * ldk2 + (size_t)(head * D) * 2u);
+        vbase = reinterpret_cast<const char*>(bank ? p.Vt2 : p.Vt) + ((size_t)(head * D) * ldv2 + (size_t)rowbase * 2u);
+        kstep = 64u * ldk2;
+        src_kv0 = 0;
+        src_L = bank ? p.L2 : p.L1;
+        koff = hv_umul24((unsigned)krow, ldk2) + (unsigned)kcol;
+        voff = hv_umul24((unsigned)(vrow & 63), ldv2) + (unsigned)vcol;  // (& 63: non-loader threads stay inside the 24-bit multiply)
+    };
+    auto load_tile = [&](int ti) {
+        if (ti == T1) set_source(true);  // (rare, wave-uniform) the bank follows the own keys
+        if (k_loader) {
+            kreg = u32x4{0u, 0u, 0u, 0u};
+            if (!MASK || src_kv0 + krow < src_L) kreg = hv_ld16(kbase + koff);
+        }
+        if (v_loader) {
+            vreg = u32x4{0u, 0u, 0u, 0u};
+            if (!MASK || src_kv0 + (vcol >> 1) < src_L) vreg = hv_ld16(vbase + voff);  // (L % 8 == 0: a chunk never straddles the end)
+        }
+        kbase += kstep;
+        vbase += 128;
+        src_kv0 += 64;
+    };
+    auto store_tile = [&](int buf) {
+        if (k_loader) hv_st16(Ks + buf * G::KBYTES + klds, kreg);
+        if (v_loader) hv_st16(Vs + buf * G::VBYTES + vlds, vreg);
+    };
+
+    f32x4 oacc[2][3];  // O^T accumulators [16-query tile][16-row channel fragment]: lane = query r16, channels 16 dt + 4 quad + 0..3
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+        for (int dt = 0; dt < 3; ++dt) oacc[qt][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    set_source(false);
+    load_tile(0);
+    __syncthreads();  // LDS initialisation complete before the first tile store
+    for (int ti = 0; ti < ntiles; ++ti) {
+        const int buf = ti & 1;
+        store_tile(buf);
+        __syncthreads();
+        if (ti + 1 < ntiles) load_tile(ti + 1);
+        const unsigned char* kb = Ks + buf * G::KBYTES + l32 * G::KRS + half * 16;
+        const unsigned char* vb = Vs + buf * G::VBYTES + r16 * G::VRS + quad * 16;
+        const int tile_kv0 = MASK ? ((ti >= T1 ? ti - T1 : ti) * 64) : 0;
+        const int tile_L = MASK ? (ti >= T1 ? p.L2 : p.L1) : 0;
+        auto mask_tail = [&](f32x16 (&sc)[2]) __attribute__((always_inline)) {
+            if (!MASK) return;
+            if (tile_kv0 + 64 > tile_L) {
+#pragma unroll
+                for (int kbk = 0; kbk < 2; ++kbk)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i)
+                        if (tile_kv0 + 32 * kbk + 16 * half + i >= tile_L) sc[kbk][i] = -INFINITY;  // register i of half b = key 16 b + i
+            }
+        };
+        auto scores = [&](f32x16 (&sc)[2]) __attribute__((always_inline)) {
+#pragma unroll
+            for (int kbk = 0; kbk < 2; ++kbk) {
+                f32x16 a;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) a[i] = 0.f;
+#pragma unroll
+                for (int s = 0; s < 3; ++s) {
+                    const bf16x8 kf = hv_as_bf16x8(hv_ld16(kb + (32 * kbk) * G::KRS + s * 32));
+                    a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], a, 0, 0, 0);
+                }
+                sc[kbk] = a;
+            }
+        };
+        // ---- S^T (two 32-key blocks x this wave's 32 queries), relative to the reference maximum
+        f32x16 sacc[2];
+#ifndef HV_EMU
+        __builtin_amdgcn_s_setprio(1);
+#endif
+        scores(sacc);
+#ifndef HV_EMU
+        __builtin_amdgcn_s_setprio(0);
+#endif
+        mask_tail(sacc);
+        // ---- probabilities (exp2 domain), packed to bf16 pairs: w[kbk][j] = keys 16 half + 2 j, + 1 of block kbk
+        unsigned w[2][8];
+#pragma unroll
+        for (int kbk = 0; kbk < 2; ++kbk)
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                w[kbk][j] = hv_pack2(__builtin_amdgcn_exp2f(sacc[kbk][2 * j]), __builtin_amdgcn_exp2f(sacc[kbk][2 * j + 1]));
+        // some probability of the wave above 2^THR (bf16 256.0 = 0x4380; +inf = 0x7F80 is above as well)?  Positive bf16
+        // order like 16-bit unsigned integers: the maximum runs on the packed pairs.
+        unsigned pm = hv_pk_max_u16(w[0][0], w[0][1]);
+#pragma unroll
+        for (int j = 2; j < 8; ++j) pm = hv_pk_max_u16(pm, w[0][j]);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) pm = hv_pk_max_u16(pm, w[1][j]);
+        const bool over = (pm & 0xffffu) > 0x4380u || (pm >> 16) > 0x4380u;
+        const bool first = ti == 0;  // the first tile fixes the reference maximum (it starts at 0, not at a score)
+        if (first || __any(over)) {
+            // rare: raise the reference maximum by the query's tile maximum, redo the exponentials against it and scale what
+            // is still at the old reference (O^T with its denominator row) exactly once.  The scores are recomputed from LDS.
+#ifndef HV_EMU
+            asm volatile("" ::: "memory");  // keeps the LDS reads (and with them the MFMAs) below inside the branch
+#endif
+            f32x16 s2[2];
+            scores(s2);
+            mask_tail(s2);
+            float mx = s2[0][0];
+#pragma unroll
+            for (int kbk = 0; kbk < 2; ++kbk)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) mx = fmaxf(mx, s2[kbk][i]);
+            mx = fmaxf(mx, hv_swap32(mx));  // the other half of the keys of the same query sits in lane ^ 32
+            const float inc = first ? mx : fmaxf(mx, 0.f);
+            const float mneg_new = hv_bf2f(hv_f2bf(mneg - inc));  // the new reference as the Q operand will carry it
+            const float inc_eff = mneg - mneg_new;
+#pragma unroll
+            for (int kbk = 0; kbk < 2; ++kbk)
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    w[kbk][j] = hv_pack2(__builtin_amdgcn_exp2f(s2[kbk][2 * j] - inc_eff), __builtin_amdgcn_exp2f(s2[kbk][2 * j + 1] - inc_eff));
+            if (!first) {
+                const float alpha = __builtin_amdgcn_exp2f(-inc_eff);
+                const float a0 = __shfl(alpha, r16), a1 = __shfl(alpha, 16 + r16);  // lanes 0-31 hold queries 0-31 of the wave
+#pragma unroll
+                for (int dt = 0; dt < 3; ++dt) {
+                    oacc[0][dt] *= a0;
+                    oacc[1][dt] *= a1;
+                }
+            }
+            mneg = mneg_new;
+            if (half) qf[2][0] = (short)hv_f2bf(mneg_new);
+        }
+        // ---- P^T in the B-operand layout of the 16x16x32 MFMA: pf[qt][kbk], four lane-row swaps per 32-key block
+        bf16x8 pf[2][2];
+#pragma unroll
+        for (int kbk = 0; kbk < 2; ++kbk) {
+            u32x4 b0, b1;
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                unsigned a = w[kbk][d], b = w[kbk][d + 4];
+                hv_swap16_pair(a, b);
+                b0[d] = a;
+                b1[d] = b;
+            }
+            pf[0][kbk] = hv_as_bf16x8(b0);
+            pf[1][kbk] = hv_as_bf16x8(b1);
+        }
+        // ---- O^T += V^T . P^T   (row 40 of V^T is all ones: accumulates the denominator)
+#ifndef HV_EMU
+        __builtin_amdgcn_s_setprio(1);
+#endif
+#pragma unroll
+        for (int dt = 0; dt < 3; ++dt)
+#pragma unroll
+            for (int kbk = 0; kbk < 2; ++kbk) {
+                const bf16x8 vf = hv_as_bf16x8(hv_ld16(vb + (16 * dt) * G::VRS + kbk * 64));
+#pragma unroll
+                for (int qt = 0; qt < 2; ++qt)
+                    oacc[qt][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[qt][kbk], oacc[qt][dt], 0, 0, 0);
+            }
+#ifndef HV_EMU
+        __builtin_amdgcn_s_setprio(0);
+#endif
+    }
+
+    // ---- normalise and store: lane owns query 16 qt + r16, channels 16 dt + 4 quad + 0..3; the denominator is O^T row 40
+    //      (fragment 2, rows 8 .. 11 of it = quad 2, register 0)
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+        const float l = __shfl(oacc[qt][2][0], 32 + r16);
+        const float inv = 1.0f / l;
+        const int q = q_wave + 16 * qt + r16;
+        if (q >= p.Lq) continue;
+        bf16_t* dst = p.O + ((long)img * p.Lq + q) * p.ldo + head * D;
+#pragma unroll
+        for (int dt = 0; dt < 3; ++dt) {
+            const int d = 16 * dt + 4 * quad;
+            if (d < D) {
+                const u32x2 o = {hv_pack2(oacc[qt][dt][0] * inv, oacc[qt][dt][1] * inv),
+                                 hv_pack2(oacc[qt][dt][2] * inv, oacc[qt][dt][3] * inv)};
+                hv_st8(dst + d, o);
+            }
+        }
+    }
+}
+
+// tuning knobs (hv_set_tuning): 1 = this kernel for head dim 40 (default), 0 = the generic kernel; workgroup raster
+static int g_hv_attn40 = 1, g_hv_attn40_head_major = 0;
+
+static inline void hv_attention40_launch(const hv_attention_params& p, hipStream_t stream) {
+    using G = HvAttn40Geom;
+    const int total = ((p.Lq + G::BQ - 1) / G::BQ) * p.heads * p.n_images;
+    const int grid = ((total + 7) / 8) * 8;
+    const bool ragged = (p.L1 % 64) != 0 || (p.L2 % 64) != 0;
+    hv_note("hv_attention40_kernel<%s> | n=%d heads=%d D=%d Lq=%d L1=%d L2=%d bank=%d", g_hv_attn40_head_major ? "hm" : "qm",
+            p.n_images, p.heads, p.D, p.Lq, p.L1, p.L2, p.bank_sel != nullptr && p.L2 > 0);
+    if (ragged) hv_launch(hv_attention40_kernel<true>, dim3(grid), dim3(512), stream, p, g_hv_attn40_head_major);
+    else hv_launch(hv_attention40_kernel<false>, dim3(grid), dim3(512), stream, p, g_hv_attn40_head_major);
+}

@@ -477,7 +477,6 @@ static inline void hv_attention_fp8_launch_t(const hv_attention_params& p, const
 
 static inline int hv_attention_fp8_launch(const hv_attention_params& p, const float* ks, const float* va, const float* ks2,
                                           const float* va2, hipStream_t stream) {
-    if (p.v_row_major) return -1;
     if (p.L1 <= 0 || p.L1 % 8 != 0 || p.L2 % 8 != 0 || p.Lq <= 0) return -1;
     if (p.ldq % 8 || p.ldk % 8 || p.ldvt % 8 || p.ldo % 4) return -1;
     const bool bank = p.L2 > 0 && p.bank_sel != nullptr;

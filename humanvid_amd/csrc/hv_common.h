@@ -173,16 +173,6 @@ HV_DEV void hv_glds16_s(const void* base_uniform, unsigned byte_ofs, void* lds_w
                  : "v"(byte_ofs), "s"(base_uniform), "s"(lds_addr_uniform)
                  : "memory");
 }
-// L2 prefetch: one dword per lane by LDS-DMA into a throw-away LDS area (no VGPR destination, so nothing can be clobbered when
-// the data lands late); brings the 128-byte lines the lanes point at into L2 ahead of the real LDS-DMA of a later k-step.
-HV_DEV void hv_l2_prefetch_dword(const void* base_uniform, unsigned byte_ofs, void* lds_dummy_wave_base) {
-    const unsigned lds_addr_uniform = (unsigned)(unsigned long)(__attribute__((address_space(3))) void*)lds_dummy_wave_base;
-    unsigned keep;
-    asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep)
-                 : "v"(byte_ofs), "s"(base_uniform), "s"(lds_addr_uniform)
-                 : "memory");
-}
 template <int N>
 HV_DEV void hv_vm_wait() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
@@ -198,7 +188,6 @@ HV_DEV void hv_glds16(const void* gsrc, void* lds_wave_base) {
 HV_DEV void hv_glds16_s(const void* base_uniform, unsigned byte_ofs, void* lds_wave_base) {
     memcpy((char*)lds_wave_base + (threadIdx.x & 63) * 16, (const char*)base_uniform + byte_ofs, 16);
 }
-HV_DEV void hv_l2_prefetch_dword(const void*, unsigned, void*) {}
 template <int N>
 HV_DEV void hv_vm_wait() {}
 HV_DEV void hv_barrier_raw() { __syncthreads(); }
@@ -260,6 +249,16 @@ HV_DEV void hv_static_for(F&& f) {
 // interleaved with RCCL collectives (frame-sharded runs).
 struct HvCmdList {
     std::vector<std::function<void(hipStream_t)>> cmds;
+#ifndef HV_EMU
+    // hv_cmdlist_run: the closures are captured once into a HIP graph (on a capture stream of their own, so that the caller's
+    // stream may be the null stream) and every run is one hipGraphLaunch on the caller's stream -- a frame-sharded step is
+    // ~700 launches cut into ~90 segments by its collectives: ~90 graph launches instead of ~700 std::function calls + kernel
+    // launches from the host per step and rank
+    hipGraphExec_t exec = nullptr;
+    ~HvCmdList() {
+        if (exec) (void)hipGraphExecDestroy(exec);
+    }
+#endif
 };
 extern thread_local HvCmdList* g_hv_recording;  // defined in hv_api.cpp
 

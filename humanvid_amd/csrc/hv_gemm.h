@@ -1171,6 +1171,133 @@ __global__ __launch_bounds__(NW * 64, 2) void hv_gemm_glds_kernel(HvGemmParams p
     }
 }
 
+// ---- epilogue of the wide-tile kernel (below): one wave's 32 rows x 320 columns = five 64-column blocks under the permuted
+// channel assignment (hv_perm_row: the fragment pair (2 j, 2 j + 1) of a lane is the 8 consecutive channels 64 b + 32 j + 8 quad).
+// Round 3 called hv_gemm_epilogue_fast_perm once per block: the five copies of the run-time form switch and of the pointer
+// tests became branches around every block with accumulators spilled across them (19-30 registers), and every block's
+// residual request waited for its own HBM round trip.  Here the forms are compile-time, there is no pointer test inside
+// (the bias is mandatory for this kernel; a problem without a per-row table passes the bias row again with weight 0), the
+// residual rows of block b + 1 are requested BEFORE block b is converted (two register sets alternating at compile time)
+// and a block's results are stored as soon as they are packed (160 accumulator registers leave no room to hold them back).
+// STATS = 1: GroupNorm partial sums per 32-row wave block (p.gn_part); STATS = 2: LayerNorm partial sums per 64-column block
+// (p.ln_part) -- both over the fp32 values in front of the bf16 rounding, exactly as the square-tile kernels take them (the
+// kernel selection must never change a result: the two CFG halves of a step may run on different tile shapes).
+template <bool LN, bool RES, int STATS>
+HV_DEV void hv_gemm_epilogue_wide(const HvGemmParams& p, f32x4 (&acc)[5][4][2], int m_base, int n0, int r16, int quad,
+                                  const float* tab_row, float tab_scale) {
+    constexpr int NB = 5, NMF = 2;
+    static_assert(!(LN && RES) && !(LN && STATS != 0), "forms of hv_gemm_fast_form");
+    auto ld4 = [&](const float* base, unsigned byte_ofs) __attribute__((always_inline)) {
+        return *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(base) + byte_ofs);
+    };
+#ifndef HV_EMU
+    // the LDS-DMA of the next k-tile (inline asm: invisible to hipcc's wait counts) has landed before anything below is
+    // issued: the caller skips its own wait after an epilogue
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+#endif
+    float mean[NMF], rstd[NMF];
+    unsigned rrow[NMF], yrow[NMF];  // byte offsets of the lane's residual / output rows
+#pragma unroll
+    for (int mf = 0; mf < NMF; ++mf) {
+        const unsigned m = (unsigned)(m_base + 16 * mf + r16);  // M % 256 == 0: no ragged rows
+        mean[mf] = rstd[mf] = 0.f;
+        if (LN) {
+            mean[mf] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(p.row_mean) + 4u * m);
+            rstd[mf] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(p.row_rstd) + 4u * m);
+        }
+        rrow[mf] = m * (unsigned)p.ldr * 2u;
+        yrow[mf] = m * (unsigned)p.ldy * 2u;
+    }
+    u32x4 resA[NMF][2], resB[NMF][2];
+    auto load_res = [&](int b, u32x4(&r)[NMF][2]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int mf = 0; mf < NMF; ++mf)
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+                r[mf][h] = hv_ld16(reinterpret_cast<const char*>(p.residual) + (rrow[mf] + 2u * (unsigned)(n0 + 64 * b + 32 * h + 8 * quad)));
+    };
+    char* const yb = reinterpret_cast<char*>(p.Y);
+    if (RES) load_res(0, resA);
+    hv_static_for<NB>([&](auto B) __attribute__((always_inline)) {
+        constexpr int b = decltype(B)::value;
+        u32x4(&cur)[NMF][2] = (b % 2 == 0) ? resA : resB;
+        u32x4(&nxt)[NMF][2] = (b % 2 == 0) ? resB : resA;
+        if constexpr (RES && b + 1 < NB) load_res(b + 1, nxt);
+#if !defined(HV_EMU)
+        __builtin_amdgcn_sched_barrier(0);  // the next block's residual requests stay ahead of this block's arithmetic
+#endif
+        float rs[NMF] = {0.f, 0.f}, rq[NMF] = {0.f, 0.f};
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            u32x4 o[NMF];
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                // per-column vectors: channels 64 b + 32 h + 8 quad + 4 k .. + 3 (L1 / L2 hits)
+                const unsigned co = 4u * (unsigned)(n0 + 64 * b + 32 * h + 8 * quad + 4 * k);
+                const f32x4 add = ld4(p.bias, co) + tab_scale * ld4(tab_row, co);
+                const f32x4 cs = LN ? ld4(p.colsum, co) : f32x4{0.f, 0.f, 0.f, 0.f};
+                f32x4 gs = {0.f, 0.f, 0.f, 0.f}, gq = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int mf = 0; mf < NMF; ++mf) {
+                    f32x4 v = acc[b][2 * h + k][mf];
+                    if (LN) v = rstd[mf] * (v - mean[mf] * cs);
+                    v += add;
+                    if (RES) {
+                        const unsigned r0 = cur[mf][h][2 * k], r1 = cur[mf][h][2 * k + 1];
+                        v += f32x4{hv_bf2f((bf16_t)(r0 & 0xffff)), hv_bf2f((bf16_t)(r0 >> 16)), hv_bf2f((bf16_t)(r1 & 0xffff)),
+                                   hv_bf2f((bf16_t)(r1 >> 16))};
+                    }
+                    const unsigned o0 = hv_pack2(v[0], v[1]), o1 = hv_pack2(v[2], v[3]);
+                    o[mf][2 * k] = o0;
+                    o[mf][2 * k + 1] = o1;
+                    if (STATS == 1) {
+                        gs += v;
+                        gq += v * v;
+                    }
+                    if (STATS == 2) {
+                        rs[mf] += (v[0] + v[1]) + (v[2] + v[3]);
+                        rq[mf] += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+                    }
+                }
+                if (STATS == 1) {  // rows [m_base, + 32) lie in one image (hv_gemm_gn_parts_of)
+                    const int parts = p.gn_rows_per_image / 32;
+                    const int img = m_base / p.gn_rows_per_image, part = (m_base - img * p.gn_rows_per_image) / 32;
+                    float* dst = p.gn_part + ((long)img * parts + part) * p.N * 2;
+                    f32x4 a, c;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        a[e] = hv_row16_sum(gs[e]);
+                        c[e] = hv_row16_sum(gq[e]);
+                    }
+                    if (r16 == 0) {
+                        *reinterpret_cast<f32x4*>(reinterpret_cast<char*>(dst) + 2u * co) = f32x4{a[0], c[0], a[1], c[1]};
+                        *reinterpret_cast<f32x4*>(reinterpret_cast<char*>(dst) + (2u * co + 16u)) = f32x4{a[2], c[2], a[3], c[3]};
+                    }
+                }
+            }
+#pragma unroll
+            for (int mf = 0; mf < NMF; ++mf) hv_st16(yb + (yrow[mf] + 2u * (unsigned)(n0 + 64 * b + 32 * h + 8 * quad)), o[mf]);
+        }
+        if (STATS == 2) {
+            const int parts = p.N / 64, blk = (n0 + 64 * b) / 64;
+#pragma unroll
+            for (int mf = 0; mf < NMF; ++mf) {
+                float a = rs[mf], c = rq[mf];
+                a += __shfl_xor(a, 16);
+                c += __shfl_xor(c, 16);
+                a += __shfl_xor(a, 32);
+                c += __shfl_xor(c, 32);
+                const int m = m_base + 16 * mf + r16;
+                if (quad == 0) *reinterpret_cast<u32x2*>(p.ln_part + ((long)m * parts + blk) * 2) =
+                    u32x2{__builtin_bit_cast(unsigned, a), __builtin_bit_cast(unsigned, c)};
+            }
+        }
+#if !defined(HV_EMU)
+        __builtin_amdgcn_sched_barrier(0);
+#endif
+    });
+}
+
 // ---- wide-tile LDS-DMA kernel for narrow outputs (round 3, written at the end of the round without GPU time to tune it:
 // OPT-IN, hv_set_tuning(HV_TUNE_GEMM_GLDS, 4)): 256 x 320 x 64 tiles for N = 320 (the kernel itself handles any N % 320 == 0).  The 128 x 128 kernel spends three
 // column tiles on 320 columns (17 % of its MFMAs and W bytes on padding) and streams the X rows once per column tile through
@@ -1291,9 +1418,16 @@ __global__ __launch_bounds__(512, 2) void hv_gemm_wide_kernel(HvGemmParams p, in
         if (++c_k == nk) {
             c_k = 0;
             const int m0 = (c_tile / tiles_n) * BM, n0 = (c_tile % tiles_n) * BN;
-#pragma unroll
-            for (int b = 0; b < NB; ++b)
-                hv_gemm_epilogue_form<NMF, true, STATS>(form, p, acc[b], m0 + 32 * wave, n0 + 64 * b, r16, quad HV_TRACE_ARG);
+            {
+                const int mw = m0 + 32 * wave;
+                const float* tab = p.bias;  // one table row per 32-row wave block (hv_gemm_fast_form(p, 32)); none: the bias, weight 0
+                float tscale = 0.f;
+                if (p.pe != nullptr) tab = p.pe + (long)((mw / p.pe_period) % p.pe_frames) * p.N, tscale = 1.f;
+                else if (p.rowvec != nullptr) tab = p.rowvec + (long)(mw / p.rowvec_period) * p.N, tscale = 1.f;
+                if (form == HV_FORM_LN) hv_gemm_epilogue_wide<true, false, 0>(p, acc, mw, n0, r16, quad, tab, tscale);
+                else if (form == HV_FORM_RES) hv_gemm_epilogue_wide<false, true, STATS>(p, acc, mw, n0, r16, quad, tab, tscale);
+                else hv_gemm_epilogue_wide<false, false, STATS>(p, acc, mw, n0, r16, quad, tab, tscale);
+            }
             landed = 1;
             c_tile += wg_per_xcd;
             clear_acc();
@@ -1303,12 +1437,12 @@ __global__ __launch_bounds__(512, 2) void hv_gemm_wide_kernel(HvGemmParams p, in
 
 static int g_hv_gemm_max_grid = 512;  // tuning knob (hv_set_tuning): persistent workgroups
 // tuning knob (hv_set_tuning key 3) -- kernel selection:
-//   1 (default): 256 x 256 x 64 (one 8-wave workgroup per CU) when N >= 960 and its tiles fill the last round over the 256
-//      CUs to >= 90 %, otherwise 128 x 128 x 64 (two 4-wave workgroups per CU); round-3 same-box step A/B
-//      (profiles/r03_step_ab.txt): 130.0 ms (round-2 default) -> 128.0 ms
+//   1 (default): 256 x 320 x 64 wide tiles for N = 320, K >= 640 (M % 256 == 0, plain-output forms); otherwise 256 x 256 x 64
+//      (one 8-wave workgroup per CU) when N >= 960 and its tiles fill the last round over the 256 CUs to >= 90 %, otherwise
+//      128 x 128 x 64 (two 4-wave workgroups per CU)
 //   2: 256 x 256 x 64 wherever its tile shape is legal (A/Bs), 3: 128 x 128 x 64 everywhere (A/Bs)
 //   0: the register-staged kernel for everything (A/Bs; also what problems outside the fast epilogue forms run on)
-//   4: as 1, plus the 256 x 320 x 64 wide-tile kernel for N = 320, K >= 640 (opt-in, hv_gemm_wide_kernel)
+//   4: as 1 with the wide tiles for every N = 320 problem, 5: also for N = 640, 6: as 1 without the wide tiles (round-3 default)
 static int g_hv_gemm_glds = 1;
 static int g_hv_gemm_perm = 1;  // tuning knob (hv_set_tuning key 6): 16-byte epilogue through the permuted channel assignment (A/B)
 
@@ -1344,12 +1478,13 @@ static inline HvGemmChoice hv_gemm_choose(const HvGemmParams& p) {
     if (form64 == HV_FORM_NONE && g_hv_gemm_perm && p.N % 8 == 0 && p.pe != nullptr && hv_gemm_fast_form(p, 16) == HV_FORM_LN)
         form64 = HV_FORM_LN;
     if (!(g_hv_gemm_glds && !prologue && p.M >= 256 && span_ok && form64 != HV_FORM_NONE)) return c;
-    // opt-in (tuning value 4): 256 x 320 x 64 tiles for N = 320 / 640 with a plain-output form on the permuted assignment
-    // Same-box A/B (profiles/r03_gemm_wide_ab.txt): level-0 ff2 (N = 320, K = 1280) 0.384 -> 0.336 ms, N = 320 / K = 320 0.158 ->
-    // 0.155, but N = 640 at level 1 0.086 -> 0.097 and 0.298 -> 0.316 (576 tiles = 2.25 rounds over the 256 CUs): the value
-    // takes N = 320 with K >= 640 only (step -0.5 ms); it stays opt-in because the round's GPU budget could not re-run the
-    // whole -m gpu suite with it as the default.
-    if (g_hv_gemm_glds == 4 && g_hv_gemm_perm && p.X2 == nullptr && p.N == 320 && p.K >= 640 && p.M % 256 == 0 && p.Yt == nullptr && !p.geglu) {
+    // 256 x 320 x 64 wide tiles (hv_gemm_wide_kernel) for N = 320 with a plain-output form on the permuted assignment: the
+    // default takes N = 320 with K >= 640 (level-0 ff2: same-box A/B 0.384 -> 0.336 ms with the round-3 epilogue,
+    // profiles/r03_gemm_wide_ab.txt); tuning value 4 every N = 320 problem, 5 also N = 640 (576 tiles at level 1 = 2.25 rounds
+    // over the 256 CUs: measured slower in round 3), 6 none (the round-3 default) -- A/Bs.
+    const bool wide_n = p.N == 320 ? (p.K >= 640 || g_hv_gemm_glds == 4 || g_hv_gemm_glds == 5) : (p.N == 640 && g_hv_gemm_glds == 5);
+    if (g_hv_gemm_glds != 6 && g_hv_gemm_glds != 2 && g_hv_gemm_glds != 3 && wide_n && g_hv_gemm_perm && p.X2 == nullptr &&
+        p.M % 256 == 0 && p.Yt == nullptr && !p.geglu && p.bias != nullptr) {
         const int form32 = hv_gemm_fast_form(p, 32);
         if (form32 == HV_FORM_RES || form32 == HV_FORM_PLAIN || form32 == HV_FORM_LN) {
             c.kernel = 3;
@@ -1368,7 +1503,7 @@ static inline HvGemmChoice hv_gemm_choose(const HvGemmParams& p) {
     const int t256 = tm * (n256 / 256), rounds256 = (t256 + 255) / 256;
     const bool fills256 = t256 * 10 >= rounds256 * 256 * 9;
     const bool shape256 = ok128 && p.N >= 960 && (n256 - p.N) * 8 <= p.N;
-    const bool big = g_hv_gemm_glds != 3 && shape256 && (fills256 || g_hv_gemm_glds == 2);  // (value 4 selects like 1 here)
+    const bool big = g_hv_gemm_glds != 3 && shape256 && (fills256 || g_hv_gemm_glds == 2);  // (values 4 - 6 select like 1 here)
     c.kernel = big ? 1 : 2;
     c.form = big ? form128 : form64;
     // plain bf16 outputs (plain / residual / LayerNorm fold) and GEGLU with N % 8 == 0: permuted channel assignment, 16-byte epilogue

@@ -4,12 +4,11 @@
 #include "hv_kernels.h"
 
 int hvk_attention(const hv_attention_params& p, hipStream_t s) {
-    if (p.v_row_major) return -1;  // (the row-major-V kernel of round 2 never won an A/B and is gone: values arrive transposed)
     return hv_attention_launch(p, s);
 }
-void hvk_attention_tune(int head_dim, int qt) {
-    if (head_dim == 40) g_hv_attn_qt40 = qt;
-    if (head_dim == 160) g_hv_attn_qt160 = qt;
+void hvk_attention_tune(int head_dim, int v) {
+    if (head_dim == 40) g_hv_attn40 = v != 2, g_hv_attn40_head_major = v == 1;  // 0 / 1: hv_attention40 (query- / head-major raster), 2: generic kernel
+    if (head_dim == 160) g_hv_attn_qt160 = v;
 }
 int hvk_attention_fp8_quantize(const bf16_t* K, long ldk, const bf16_t* Vt, long ldvt, int n, int heads, int D, int L, float* kscale,
                                float* vamax, const float* vfloor, unsigned char* K8, long ldk8, unsigned char* Vt8, long ldvt8,

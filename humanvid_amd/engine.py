@@ -68,6 +68,10 @@ class UNet3DEngine:
         # module, named by the reference's module path (e.g. 'down_blocks.0.attentions.1').  Buffers are reused and updated in place: the observer
         # must copy what it wants to keep.  Used by the parity tests; None in production (and under graph capture).
         self.tap = None
+        # CFG half this executor instance evaluates when it is given one batch entry (B = 1) of a guided step: None = whole
+        # batch ([unconditional | conditional] in one forward), 0 / 1 = that half only (clone_for_half: the two halves of a
+        # frame-sharded step run on two streams so that one half's temporal exchange hides under the other's kernels)
+        self.cfg_half = None
         self._pack()
         mmk = self.cfg.get("motion_module_kwargs") or {}
         self.run = Runner(self.device, self.w, self.ws, self.groups, shard,
@@ -77,6 +81,21 @@ class UNet3DEngine:
     @property
     def stream(self) -> int:
         return hvlib.current_stream()
+
+    def clone_for_half(self, half: int) -> "UNet3DEngine":
+        """An executor for ONE CFG half (batch entry `half` of [unconditional, conditional]) with its own workspace and
+        statistics tables, sharing the packed weights, the projected reference banks and the folded cross-attention
+        constants of this one (read-only during a step).  Make the clones after the banks / embeddings are set."""
+        import copy
+
+        e = copy.copy(self)
+        e.ws = Workspace(self.device)
+        mmk = self.cfg.get("motion_module_kwargs") or {}
+        e.run = Runner(self.device, self.w, e.ws, self.groups, self.shard, temporal_heads=mmk.get("num_attention_heads", 8))
+        e._sel_cache = {}
+        e.cfg_half = int(half)
+        e.tap = None
+        return e
 
     def _dev(self, t: torch.Tensor, dtype=None) -> torch.Tensor:
         return t.detach().to(device=self.device, dtype=dtype or t.dtype).contiguous()
@@ -403,10 +422,13 @@ class UNet3DEngine:
                 k2, vt2, bb, Nb = bank
                 if self.do_cfg:
                     cond = 1 if bb > 1 else 0  # a one-entry bank (ReferenceNet run on the conditional embedding only)
-                    sel = [-1] * F + [cond] * (n - F) if B == 2 else [-1] * n
+                    if B == 2:
+                        sel = [-1] * F + [cond] * (n - F)
+                    else:  # one batch entry: the unconditional half, unless this executor evaluates the conditional one
+                        sel = [cond] * n if self.cfg_half == 1 else [-1] * n
                 else:
                     sel = [i // F if bb > 1 else 0 for i in range(n)]
-                skey = (n, F, int(self.do_cfg), bb)
+                skey = (n, F, int(self.do_cfg), bb, self.cfg_half)
                 sel_t = self._sel_cache.get(skey)
                 if sel_t is None:  # uploaded once (keeps the step free of host copies / graph-capturable)
                     sel_t = torch.tensor(sel, dtype=torch.int32).to(self.device)
@@ -435,8 +457,11 @@ class UNet3DEngine:
             else:
                 ops.attention(L, st, qk, qk[:, C:], vt, o, n_images=n, heads=self.heads, D=C // self.heads, Lq=N, L1=N,
                               ldq=ldqk, ldk=ldqk, ldvt=ldvt, ldo=C, **kw)
+            cc = self.cross_const[prefix]  # [batch entries][C]: the folded 1-key cross-attention, one row per CFG half
+            if self.cfg_half is not None and B == 1:
+                cc = cc[self.cfg_half:self.cfg_half + 1]
             self.run.gemm_ln(o, w[t + ".attn1.to_out.0.w"], hid, bias=w[t + ".attn1.to_out.0.bias"],
-                             rowvec=self.cross_const[prefix], rowvec_period=F * N, residual=hid)
+                             rowvec=cc, rowvec_period=F * N, residual=hid)
             feed_forward(t + ".ff1", t + ".ff.net.2", hid)
             self.run.gemm_with_stats(hid, w[prefix + ".proj_out.w"], x, N, bias=w[prefix + ".proj_out.bias"], residual=x2d)
             return x

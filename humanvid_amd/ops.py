@@ -136,7 +136,7 @@ def attention(lib, stream, q, k, vt, o, *, n_images, heads, D, Lq, L1, ldq, ldk,
     p = A.AttentionParams(
         Q=_p(q), ldq=ldq, K=_p(k), ldk=ldk, Vt=_p(vt), ldvt=ldvt, K2=_p(k2), ldk2=ldk2, Vt2=_p(vt2), ldvt2=ldvt2,
         bank_sel=_p(bank_sel), O=_p(o), ldo=ldo, n_images=n_images, heads=heads, D=D, Lq=Lq, L1=L1, L2=L2,
-        scale=1.0 / math.sqrt(D), v_row_major=0,
+        scale=1.0 / math.sqrt(D),
     )
     lib.call("hv_attention", C.byref(p), stream)
 
@@ -156,7 +156,7 @@ def attention_fp8(lib, stream, q, k, vt, o, kscale, vamax, *, n_images, heads, D
     p = A.AttentionParams(
         Q=_p(q), ldq=ldq, K=_p(k), ldk=ldk, Vt=_p(vt), ldvt=ldvt, K2=_p(k2), ldk2=ldk2, Vt2=_p(vt2), ldvt2=ldvt2,
         bank_sel=_p(bank_sel), O=_p(o), ldo=ldo, n_images=n_images, heads=heads, D=D, Lq=Lq, L1=L1, L2=L2,
-        scale=1.0 / math.sqrt(D), v_row_major=0,
+        scale=1.0 / math.sqrt(D),
     )
     lib.call("hv_attention_fp8", C.byref(p), _p(kscale), _p(vamax), _p(kscale2), _p(vamax2), stream)
 

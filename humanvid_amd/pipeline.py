@@ -100,6 +100,23 @@ class StepRecorder:
             else:
                 x()
 
+    @staticmethod
+    def replay_interleaved(recorders, streams):
+        """Replay several recordings of the SAME program (the two CFG halves of a step) item by item, recording r on
+        stream r: segment k of every half is issued before collective k of any, so the collectives reach the communicator's
+        queue in the order A1, B1, A2, B2, ... on every rank, and while half A waits for its exchange the GPU runs half B's
+        segment (and the other way round one item later)."""
+        n = len(recorders[0].items)
+        assert all(len(r.items) == n and [k for k, _ in r.items] == [k for k, _ in recorders[0].items] for r in recorders)
+        for i in range(n):
+            for r, s in zip(recorders, streams):
+                kind, x = r.items[i]
+                with torch.cuda.stream(s):
+                    if kind == "k":
+                        r.lib.call("hv_cmdlist_run", x, s.cuda_stream)
+                    else:
+                        x()
+
     def destroy(self):
         for kind, x in self.items:
             if kind == "k":
@@ -252,13 +269,19 @@ class Pose2VideoPipeline:
                 context_schedule="uniform", context_frames=24, context_stride=1, context_overlap=4,
                 use_graph: bool = True, callback: Optional[Callable] = None, callback_steps: int = 1,
                 max_steps: Optional[int] = None, step_hook: Optional[Callable] = None,
-                after_loop: Optional[Callable] = None) -> torch.Tensor:
+                after_loop: Optional[Callable] = None, first_step: int = 0) -> torch.Tensor:
         """Denoising loop body of the reference (pipeline_pose2vid_long.py:454-571).
 
         latents [1,4,F,h,w] fp32 (cuda); pose_cond_tensor [1,3,F,H,W] in [0,1]; camera_embedding
         [1,6,F,H,W]; clip_image_embeds [1,768] or [1,1,768].  The reference banks must already be on
         the denoising UNet (ReferenceAttentionControl.update, or engine.set_reference_banks).
-        step_hook(i) runs after step i; after_loop(one_step) receives the step closure once the loop is done."""
+        step_hook(i) runs after step i; after_loop(one_step) receives the step closure once the loop is done.
+        first_step > 0 enters the schedule at that step with `latents` as they are (partial trajectories: the parity test of
+        the schedule's last step, tests/test_gpu_fullsize_steps.py; the reference always starts at 0).
+        callback: called as the reference calls it (pipeline_pose2vid_long.py:507, 565-571) -- its inner
+        `for i in range(num_context_batches)` rebinds the step index before the callback test, so the callback receives
+        (num_context_batches - 1, t, latents) with t the scheduler's 0-d timestep tensor, whenever
+        (num_context_batches - 1) % callback_steps == 0 (context_batch_size = 1: one batch per context window)."""
         dev = hvlib.require_gpu()
         L = hvlib.load()
         unet = self.denoising_unet
@@ -328,7 +351,44 @@ class Pose2VideoPipeline:
         for x in x_in:
             x.zero_()
 
+        # ---- exchange / compute overlap for frame-sharded guided steps (FrameShard.overlap_cfg): the two CFG halves never
+        # interact before hv_cfg_ddim_step, so each runs as its own B = 1 forward on its own stream (own workspace), recorded
+        # once as command-list segments cut at its collectives and replayed INTERLEAVED with the other half
+        overlap = (self.shard is not None and world > 1 and do_cfg and use_graph and getattr(self.shard, "overlap_cfg", False))
+        if overlap:
+            halves = [eng.clone_for_half(hf) for hf in (0, 1)]
+            streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+            x_half = [[e.ws.get(f"pipe_x_in_{i}", (fl, h, w, 32)) for i, (_, fl, _) in enumerate(plans)] for e in halves]
+            for xs in x_half:
+                for x in xs:
+                    x.zero_()
+            counter_spare = torch.zeros_like(counter)  # the window counter is accumulated once (by half 0)
+
+            def half_step(hf):
+                st = hvlib.current_stream()
+                for (frames, fl, _), cond, xi in zip(plans, conds, x_half[hf]):
+                    ops.pack_ncfhw(L, st, latents, xi, rep=1, frames=frames)
+                    y = halves[hf].forward_nhwc(xi, t_dev[hf:hf + 1], cond, B=1, F=fl)
+                    ops.accumulate_window(L, st, y, 1, C, frames, acc[hf:hf + 1], counter if hf == 0 else counter_spare)
+
+            def fork():
+                for s_ in streams:
+                    s_.wait_stream(torch.cuda.current_stream())
+
+            def join_and_finish():
+                for s_ in streams:
+                    torch.cuda.current_stream().wait_stream(s_)
+                self.shard.all_reduce(acc_cnt)
+                ops.cfg_ddim_step(L, hvlib.current_stream(), latents, acc, counter, rep, coeffs)
+
         def one_step():
+            if overlap:  # (eager form: the halves one after the other on their streams -- steps 0 and the recorded one)
+                fork()
+                for hf in (0, 1):
+                    with torch.cuda.stream(streams[hf]):
+                        half_step(hf)
+                join_and_finish()
+                return
             st = hvlib.current_stream()
             for (frames, fl, _), cond, xi in zip(plans, conds, x_in):
                 ops.pack_ncfhw(L, st, latents, xi, rep=rep, frames=frames)
@@ -340,18 +400,38 @@ class Pose2VideoPipeline:
 
         graph = None
         recorder = None
-        n_steps = len(timesteps) if max_steps is None else min(max_steps, len(timesteps))
-        for i in range(n_steps):
+        n_steps = len(timesteps) if max_steps is None else min(first_step + max_steps, len(timesteps))
+        n_batches = len(list(get_context_scheduler(context_schedule)(0, num_inference_steps, F_, context_frames,
+                                                                      context_stride, context_overlap)))
+        for i in range(first_step, n_steps):
             t_dev.copy_(t_table[i].expand(rep))
             coeffs.copy_(c_table[i])
             multi = self.shard is not None and (world > 1 or self.shard.window_groups > 1)
-            if use_graph and not multi and i >= 1:
+            if use_graph and not multi and i >= first_step + 1:
                 if graph is None:
                     # step 0 ran eagerly (allocates every workspace buffer); capture step 1 and replay it
                     graph = self._capture(one_step)
                 else:
                     L.call("hv_graph_launch", graph, hvlib.current_stream())
-            elif use_graph and multi and i >= 1:
+            elif overlap and i >= first_step + 1:
+                if recorder is None:
+                    recorder = [StepRecorder(L), StepRecorder(L)]
+                    fork()
+                    for hf in (0, 1):  # record each half on its own stream (executes it as well)
+                        with torch.cuda.stream(streams[hf]):
+                            self.shard.recorder = recorder[hf]
+                            recorder[hf].begin()
+                            try:
+                                half_step(hf)
+                            finally:
+                                recorder[hf].end()
+                                self.shard.recorder = None
+                    join_and_finish()
+                else:
+                    fork()
+                    StepRecorder.replay_interleaved(recorder, streams)
+                    join_and_finish()
+            elif use_graph and multi and i >= first_step + 1:
                 if recorder is None:
                     # frame-sharded: record step 1 as command-list segments cut at every collective
                     recorder = StepRecorder(L)
@@ -368,16 +448,17 @@ class Pose2VideoPipeline:
                 one_step()
             if step_hook is not None:
                 step_hook(i)
-            if callback is not None and i % callback_steps == 0:
-                callback(i, timesteps[i], latents)
+            if callback is not None and (n_batches - 1) % callback_steps == 0:
+                callback(n_batches - 1, sched.timesteps[i], latents)
         if after_loop is not None:
             after_loop(one_step)  # e.g. bench.py: one more, eagerly launched step inside a launch profile
         if graph is not None:
             torch.cuda.current_stream().synchronize()
             L.call("hv_graph_destroy", graph)
         if recorder is not None:
-            torch.cuda.current_stream().synchronize()
-            recorder.destroy()
+            torch.cuda.synchronize()
+            for r in (recorder if isinstance(recorder, list) else [recorder]):
+                r.destroy()
         return latents
 
     def interpolate_latents(self, latents: torch.Tensor, interpolation_factor: int, device):

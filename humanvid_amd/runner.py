@@ -88,6 +88,13 @@ class FrameShard:
         # 7/8 of its own q|k|v and gets its output back: 1.5 GB per rank and step at config #4), "allgather" replicates
         # K/V of all frames on every rank (6.0 GB); SURVEY.md section 8(e)
         self.exchange = os.environ.get("HUMANVID_TEMPORAL_EXCHANGE", "alltoall")
+        # exchange / compute overlap of a guided (CFG) step: the two halves on two streams, replayed interleaved
+        # (Pose2VideoPipeline.denoise, StepRecorder.replay_interleaved).  Default ON with RCCL (device collectives), where an
+        # exchange is asynchronous to the other half's kernels; the host-staged transport of the CPU / one-GPU tests
+        # synchronises in every collective and gains nothing, so it stays off there unless HUMANVID_CFG_STREAMS=1 asks for it
+        # (the tests do: same result, bit for bit).
+        env = os.environ.get("HUMANVID_CFG_STREAMS")
+        self.overlap_cfg = (not self.staged) if env is None else env == "1"
         # diagnostics for the scaling runs (bench.py --gpus N): with `measure` on, every collective is counted with the bytes
         # this rank sends and bracketed by two events on the compute stream -- the kernels behind a collective wait for
         # it, so the event distance is the exchange time the step is EXPOSED to (nothing overlaps it yet)

@@ -84,12 +84,20 @@ def test_gemm_fast_epilogue_forms(cx):
 
 
 def test_gemm_wide_tile_kernel(cx):
-    """hv_gemm_wide_kernel (256 x 320 x 64 tiles, opt-in tuning value 4) for N = 320 / 640, M % 256 == 0: the three output
-    forms it takes, several tiles per persistent workgroup, one and several k-steps per tile, and the GroupNorm / LayerNorm
-    partial statistics (32-row partial sums); problems it does not take fall through to the default selection"""
+    """hv_gemm_wide_kernel (256 x 320 x 64 tiles; default for N = 320, K >= 640, M % 256 == 0; tuning value 4: every N = 320
+    problem, 5: N = 640 as well): the three output forms it takes, several tiles per persistent workgroup, one and several
+    k-steps per tile, and the GroupNorm / LayerNorm partial statistics (32-row partial sums); problems it does not take fall
+    through to the square tiles"""
     cx.lib.call("hv_set_tuning", 2, 8)
-    cx.lib.call("hv_set_tuning", 3, 4)
     try:
+        for v in (4, 5):
+            cx.lib.call("hv_set_tuning", 3, v)
+            kc.case_gemm_forms(cx, M=512, C=64, N=320, P=256, form="res", seed=77)      # one k-step per tile
+            kc.case_gn_parts_gemm(cx, n=4, rows=128, C=320, K=64, seed=78, part_rows=32)
+            kc.case_ln_parts_gemm(cx, M=768, C=320, K=128, seed=79)
+        kc.case_gemm_forms(cx, M=768, C=128, N=640, P=128, form="res", seed=80)         # (value 5) two column tiles per row block
+        kc.case_ln_parts_gemm(cx, M=512, C=640, K=64, seed=70)
+        cx.lib.call("hv_set_tuning", 3, 1)
         for form in ("ln", "res", "plain"):
             kc.case_gemm_forms(cx, M=768, C=640, N=320, P=128, form=form, seed=71)     # 3 tiles, 10 k-steps each
         kc.case_gemm_forms(cx, M=2560, C=704, N=320, P=32, form="ln", seed=73)          # 10 tiles over 8 workgroups; table row per 32-row block
@@ -97,6 +105,9 @@ def test_gemm_wide_tile_kernel(cx):
         kc.case_ln_parts_gemm(cx, M=768, C=320, K=640, seed=75)
         kc.case_gemm_forms(cx, M=520, C=640, N=320, P=128, form="res", seed=76)         # M % 256 != 0: default kernels
         kc.case_gemm_forms(cx, M=512, C=64, N=320, P=256, form="res", seed=72)          # K < 640: default kernels
+        assert kc.case_gn_parts_gemm(cx, n=4, rows=128, C=320, K=64, seed=74) is not None  # K < 640: 64-row partial sums
+        cx.lib.call("hv_set_tuning", 3, 6)                                                # no wide tiles: 64-row partial sums
+        kc.case_gn_parts_gemm(cx, n=4, rows=128, C=320, K=640, seed=74, part_rows=64)
     finally:
         cx.lib.call("hv_set_tuning", 3, 1)
         cx.lib.call("hv_set_tuning", 2, 512)
@@ -300,6 +311,19 @@ def test_attention_fp8(cx, D):
     e2 = kc.case_attention(cx, D=D, n_img=2, Lq=128, Lb=64, fp8=True, seed=17)
     e3 = kc.case_attention(cx, D=D, n_img=2, Lq=200, Lb=72, fp8=True, spike=True, seed=71)
     print(f"fp8 attention D={D}: nrmse {e1:.2e} {e2:.2e} {e3:.2e}")
+
+
+def test_attention40_variants(cx):
+    """head dim 40 runs on the dedicated kernel (hv_attention40.h): both workgroup rasters, the generic kernel behind tuning
+    value 2, several query blocks of 256 (ragged last one), several key tiles, a bank shorter than a tile"""
+    try:
+        for v in (2, 1, 0):
+            cx.lib.call("hv_set_tuning", 0, v)
+            kc.case_attention(cx, D=40, n_img=2, Lq=72, Lb=40)
+            kc.case_attention(cx, D=40, n_img=4, Lq=296, Lb=136, seed=19)
+    finally:
+        cx.lib.call("hv_set_tuning", 0, 0)
+    kc.case_attention(cx, D=40, n_img=2, Lq=520, Lb=8, seed=20)
 
 
 def test_attention_unmasked_instances(cx):

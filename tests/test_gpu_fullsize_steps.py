@@ -1,0 +1,98 @@
+"""Parity of the LOOP BODY at the benchmarked size against the reference's own modules ("parity beyond one
+forward").
+
+tests/golden/steps_<case>.npz were produced in the build container by oracle/gen_fullsize_steps_golden.py: the reference's
+UNet3DConditionModel (read mode, CFG, seeded fp16 banks), PoseGuider and CameraPoseEncoder, imported verbatim from
+/root/reference and driven by the statements of pipeline_pose2vid_long.py:455-563 (context windows from the reference's own
+src/pipelines/context.py, noise_pred / counter accumulation, guidance, DDIM step), fp32 on the host cores:
+
+  steps3     two CONSECUTIVE steps of the 30-step schedule at config #3's size (24 frames, 96 x 64 latent, SD-1.5 widths):
+             i = 0 is t = 999 -- zero terminal SNR, sqrt(abar_t) = 0, the step the single-forward fixture (t = 499) never saw --
+             and i = 1 (t = 966) starts from the native path's OWN step-0 latents: the error of step 0 rides along
+  edge_t32   the LAST step (i = 29, t = 32: prev_timestep < 0 -> final_alpha_cumprod) at the same size
+  windows48  two steps of a 48-frame clip (context 24, overlap 4: three overlapping windows per step, the geometry of
+             config #5) at a 32 x 32 latent: hv_accumulate_window + per-frame counter division with the level-0 kernels
+
+Compared per step: the latents after the scheduler step and the guided noise prediction (recovered from the latent update,
+which is linear in it).  Stated tolerances (bf16 storage, fp32 accumulation; measured values are printed):
+noise prediction NRMSE <= 2e-2 per step, latents <= 2e-2 (they carry sqrt(1 - abar_prev) of the prediction error, less at the
+early steps), every frame's noise prediction within 1.5 x that bound."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "oracle"))
+sys.path.insert(0, os.path.dirname(__file__))
+import fullsize_case as FC  # noqa: E402
+import oracle_torch as O  # noqa: E402  (test infrastructure: weight generators only)
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+TOL = 2e-2
+
+
+def nrmse(a, b):
+    return float((a.float() - b.float()).norm() / b.float().norm())
+
+
+@pytest.fixture(scope="module")
+def pipe_and_chan():
+    from humanvid_amd.conditioning import CameraPoseEncoder, PoseGuider
+    from humanvid_amd.pipeline import Pose2VideoPipeline
+    from humanvid_amd.scheduler import DDIMScheduler
+    from humanvid_amd.unet3d import UNet3DConditionModel
+
+    cfg = dict(O.SD15_UNET3D_CFG)
+    sd = O.make_unet3d_weights(cfg, seed=FC.WEIGHT_SEED)
+    net = UNet3DConditionModel(**dict(cfg, use_inflated_groupnorm=True, unet_use_cross_frame_attention=False,
+                                      unet_use_temporal_attention=False, motion_module_type="Vanilla"))
+    net.load_state_dict(sd, strict=True)
+    chan = {p: sd[p + ".norm.weight"].numel() for p in O.transformer_locations(cfg)}
+    del sd
+    net = net.to("cuda")
+    pg = PoseGuider(**O.POSE_GUIDER_CFG)
+    pg.load_state_dict(O.make_pose_guider_weights(), strict=True)
+    ck = dict(O.CAMERA_ENCODER_CFG, channels=[320], attention_block_types=["Temporal_Self"], use_conv=False, compression_factor=1)
+    cam = CameraPoseEncoder(**ck)
+    cam.load_state_dict(O.make_camera_encoder_weights(), strict=True)
+    sched = DDIMScheduler(beta_start=0.00085, beta_end=0.012, beta_schedule="linear", clip_sample=False, steps_offset=1,
+                          prediction_type="v_prediction", rescale_betas_zero_snr=True, timestep_spacing="trailing")
+    return Pose2VideoPipeline(None, None, None, net, pg.to("cuda"), cam.to("cuda"), sched), chan
+
+
+@pytest.mark.parametrize("case", ["windows48", "steps3", "edge_t32"])
+def test_native_loop_steps_match_the_reference_at_full_size(pipe_and_chan, case):
+    from humanvid_amd.scheduler import fused_step_coefficients
+
+    pipe, chan = pipe_and_chan
+    z = np.load(os.path.join(GOLD, f"steps_{case}.npz"))
+    steps = [int(s) for s in z["steps"]]
+    n_inf = int(z["num_inference_steps"])
+    lat, pose, pl, clip, banks = FC.make_step_inputs(case, list(chan), lambda p: chan[p])
+    eng = pipe.denoising_unet.engine()
+    eng.set_reference_banks({k: v.cuda() for k, v in banks.items()}, do_cfg=True)
+    eng._banks_from_modules = lambda: None
+    got = []
+    x_in = lat.clone()
+    pipe.denoise(lat.clone().cuda(), pose.cuda(), pl.cuda(), clip.cuda(), n_inf, FC.GUIDANCE, first_step=steps[0],
+                 max_steps=len(steps), callback=lambda i, t, x: got.append((int(t), x.detach().float().cpu().clone())))
+    torch.cuda.synchronize()
+    assert len(got) == len(steps)
+    pipe.scheduler.set_timesteps(n_inf)
+    for i, (t, x_out) in zip(steps, got):
+        assert t == int(z[f"t{i}"]), (t, int(z[f"t{i}"]))  # the callback receives the scheduler's timestep, as in the reference
+        assert torch.isfinite(x_out).all()
+        want_lat = torch.from_numpy(z[f"latents{i}"])
+        want_noise = torch.from_numpy(z[f"noise_pred{i}"].astype(np.float32))
+        # x' = c3 (c1 x - c2 m) + c4 (c1 m + c2 x)  ->  the guided prediction m from the update the native path made
+        c1, c2, c3, c4 = fused_step_coefficients(pipe.scheduler, t, n_inf)
+        noise = (x_out - (c3 * c1 + c4 * c2) * x_in) / (c4 * c1 - c3 * c2)
+        e_lat, e_noise = nrmse(x_out, want_lat), nrmse(noise, want_noise)
+        per_frame = (noise - want_noise).pow(2).sum(dim=(0, 1, 3, 4)).sqrt() / want_noise.pow(2).sum(dim=(0, 1, 3, 4)).sqrt()
+        print(f"[{case}] step {i} t={t}: latents nrmse {e_lat:.4e}  guided noise prediction nrmse {e_noise:.4e}  "
+              f"worst frame {float(per_frame.max()):.4e}")
+        assert e_noise < TOL and e_lat < TOL and float(per_frame.max()) < 1.5 * TOL, (case, i, e_lat, e_noise)
+        x_in = x_out  # the next step starts from the native path's own latents, as in a real run

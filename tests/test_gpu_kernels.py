@@ -38,11 +38,15 @@ def test_gemm_fused(cx):
 
 
 def test_gemm_wide_tile_kernel(cx):
-    """the opt-in 256 x 320 x 64 wide-tile kernel (hv_set_tuning(3, 4): N = 320, K >= 640, M % 256 == 0) at the level-0
-    feed-forward output shape of a frame shard (M = 36 864) and with several tiles per workgroup (M = 147 456): its three
-    output forms and the fused GroupNorm / LayerNorm partial statistics (one partial sum per 32-row wave block)"""
+    """the 256 x 320 x 64 wide-tile kernel (default for N = 320, K >= 640, M % 256 == 0; tuning value 4: every N = 320
+    problem) at the level-0 feed-forward output shape of a frame shard (M = 36 864) and with several tiles per workgroup
+    (M = 147 456): its three output forms and the fused GroupNorm / LayerNorm partial statistics (one partial sum per 32-row
+    wave block)"""
     cx.lib.call("hv_set_tuning", 3, 4)
     try:
+        kc.case_gemm_forms(cx, M=147456, C=320, N=320, P=6144, form="res", seed=85)
+        kc.case_gn_parts_gemm(cx, n=6, rows=6144, C=320, K=320, seed=86, part_rows=32)
+        kc.case_ln_parts_gemm(cx, M=36864, C=320, K=320, seed=87)
         for form in ("res", "ln", "plain"):
             kc.case_gemm_forms(cx, M=36864, C=1280, N=320, P=768, form=form, seed=81)
         kc.case_gemm_forms(cx, M=147456, C=640, N=320, P=6144, form="res", seed=82)
@@ -144,9 +148,15 @@ def test_config5_shape_attention(cx, D, L, fp8):
 
 
 def test_attention_variants(cx):
-    cx.lib.call("hv_set_tuning", 0, 2)
-    kc.case_attention(cx, D=40, n_img=4, Lq=520, Lb=264)
-    cx.lib.call("hv_set_tuning", 0, 4)
+    """head dim 40: the generic kernel (tuning value 2) and the dedicated kernel's head-major raster (1) compute the same
+    function as the default (0); head dim 160: one query fragment per wave"""
+    try:
+        for v in (2, 1, 0):
+            cx.lib.call("hv_set_tuning", 0, v)
+            kc.case_attention(cx, D=40, n_img=4, Lq=520, Lb=264)
+            kc.case_attention(cx, D=40, n_img=4, Lq=1536, Lb=1536, spike=True, seed=73, check=(0, 3), q_stride=4)
+    finally:
+        cx.lib.call("hv_set_tuning", 0, 0)
     cx.lib.call("hv_set_tuning", 1, 1)
     kc.case_attention(cx, D=160, n_img=4, Lq=96, Lb=96)
     cx.lib.call("hv_set_tuning", 1, 2)

@@ -38,7 +38,8 @@ def _inputs(F=4):
     return O, cfg, sd, lat, pose, pl, clip, banks
 
 
-def _worker(rank, world, port, out_path, backend="gloo", frames=4, window_groups=1, context_frames=24, context_overlap=4):
+def _worker(rank, world, port, out_path, backend="gloo", frames=4, window_groups=1, context_frames=24, context_overlap=4,
+            check_stats=True):
     import torch.distributed as dist
 
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
@@ -84,7 +85,7 @@ def _worker(rank, world, port, out_path, backend="gloo", frames=4, window_groups
         sh.measure = False
         windows = -(-frames // max(1, context_frames - context_overlap)) if frames > context_frames else 1
         assert sh.stats["collectives"] >= 1 and sh.stats["bytes_sent"] > 0 and sh.exposed_ms() > 0.0, sh.stats
-        if window_groups == 1:  # 2 exchanges per temporal attention block (all-to-all) or 1 (all-gather) + ONE all-reduce
+        if window_groups == 1 and check_stats:  # 2 exchanges per temporal attention block (all-to-all) or 1 (all-gather) + ONE all-reduce
             per_attn = 2 if sh.exchange == "alltoall" else 1
             n_attn = sum(1 for k in eng.w if k.endswith(".qkv.w") and "motion_modules" in k)
             assert sh.stats["collectives"] == windows * per_attn * n_attn + 1, (sh.stats["collectives"], n_attn)
@@ -157,3 +158,34 @@ def test_window_parallel_groups_match_oracle(tmp_path):
     errs = [float((a - b).norm() / b.norm()) for a, b in zip(got, trace)]
     print("window-parallel (2 groups x 1 rank) latent nrmse per step", errs)
     assert len(errs) == 3 and max(errs) < 2e-2, errs
+
+
+def _run_two_ranks(tmp_path, name, **kw):
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    out_path = str(tmp_path / name)
+    mp.spawn(_worker, args=(2, port, out_path, kw.get("backend", "gloo"), 4, 1, 24, 4, kw.get("check_stats", True)), nprocs=2,
+             join=True)
+    return torch.load(out_path)
+
+
+def test_cfg_halves_on_two_streams_are_bit_identical(tmp_path, monkeypatch):
+    """Exchange / compute overlap: with FrameShard.overlap_cfg the unconditional and the conditional half
+    of a guided step run as two B = 1 forwards on two streams -- step 0 eagerly, step 1 recorded per half, step 2 replayed
+    INTERLEAVED (segment k of both halves, then collective k of both) -- instead of one B = 2 forward.  Every image goes
+    through the same kernels with the same reduction order, so the latents of all three steps must equal the serial path's
+    bit for bit (2 ranks on one GPU, host-staged transport: only the transport differs from RCCL).  Also checked with the
+    command lists re-issued launch by launch instead of as captured graphs (HUMANVID_TUNING=7=0)."""
+    monkeypatch.setenv("HUMANVID_CFG_STREAMS", "0")
+    serial = _run_two_ranks(tmp_path, "serial.pt")
+    monkeypatch.setenv("HUMANVID_CFG_STREAMS", "1")
+    overlapped = _run_two_ranks(tmp_path, "overlap.pt", check_stats=False)
+    assert len(serial) == len(overlapped) == 3
+    for i, (a, b) in enumerate(zip(serial, overlapped)):
+        assert torch.isfinite(b).all() and torch.equal(a, b), (i, float((a - b).abs().max()))
+    monkeypatch.setenv("HUMANVID_TUNING", "7=0")
+    closures = _run_two_ranks(tmp_path, "overlap_closures.pt", check_stats=False)
+    for i, (a, b) in enumerate(zip(serial, closures)):
+        assert torch.equal(a, b), (i, float((a - b).abs().max()))

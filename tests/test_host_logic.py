@@ -303,3 +303,31 @@ def test_library_override_env_is_honoured(monkeypatch, tmp_path):
     with pytest.raises(OSError):
         hvlib.load()
     monkeypatch.setattr(hvlib, "_LIB", None)
+
+
+def test_loop_body_goldens_counters_and_callback_contract():
+    """tests/golden/steps_*.npz (the reference's own loop body, oracle/gen_fullsize_steps_golden.py): the per-frame window
+    counters the reference accumulated equal the coverage of this package's window table, and the golden timesteps are the
+    ones this package's scheduler walks (t = 999 first, t = 32 last of 30)."""
+    import sys
+
+    sys.path.insert(0, os.path.dirname(__file__))
+    import fullsize_case as FC
+    from humanvid_amd.scheduler import DDIMScheduler, get_context_scheduler
+
+    s = DDIMScheduler(beta_start=0.00085, beta_end=0.012, beta_schedule="linear", clip_sample=False, steps_offset=1,
+                      prediction_type="v_prediction", rescale_betas_zero_snr=True, timestep_spacing="trailing")
+    for case, geo in FC.STEP_CASES.items():
+        path = os.path.join(GOLD, f"steps_{case}.npz")
+        z = np.load(path)
+        s.set_timesteps(int(z["num_inference_steps"]))
+        ts = [int(t) for t in s.timesteps.tolist()]
+        windows = list(get_context_scheduler("uniform")(0, int(z["num_inference_steps"]), geo["F"], 24, 1, 4))
+        cover = np.zeros(geo["F"])
+        for c in windows:
+            cover[list(c)] += 1
+        for i in geo["steps"]:
+            assert int(z[f"t{i}"]) == ts[i]
+            assert np.array_equal(z[f"counter{i}"], cover), (case, z[f"counter{i}"], cover)
+    assert ts[0] == 999 and ts[-1] == 32
+    assert len(windows) == 1  # (the last case is a single 24-frame window)

@@ -211,10 +211,11 @@ def roofline_from_profile(kernels, traffic_file):
     return roof, table
 
 
-def cpu_baseline(budget_hw=(24, 16), frames=24):
-    """Time the fp32 oracle (a port of the reference's forward) on the host cores on a bounded sample:
-    one CFG UNet forward + DDIM update at F=24, full SD-1.5 widths, latent 24x16 (1/16 of the
-    config-#3 pixels); scaled to config #3 by the as-written FLOP ratio."""
+def cpu_baseline(budget_hw=(48, 32), frames=24):
+    """Time the fp32 oracle (a port of the reference's forward) on THIS host's cores on a bounded sample: one CFG UNet forward +
+    DDIM update at F=24, full SD-1.5 widths, latent 48x32 = a QUARTER of the config-#3 pixels (round 3 sampled 1/16 and
+    scaled by 22.5), scaled to config #3 by the as-written FLOP ratio (~4.6: the spatial attention is
+    quadratic in the pixels).  --cpu-baseline full times the whole 96x64 step instead (several minutes on 128 cores)."""
     sys.path.insert(0, os.path.join(REPO, "oracle"))
     import oracle_torch as O  # test infrastructure: timed here as the reported CPU baseline only
 
@@ -242,16 +243,21 @@ def cpu_baseline(budget_hw=(24, 16), frames=24):
     full = dict(DEFAULT_UNET3D_CONFIG)
     full.update(SD15_INFERENCE_V2)
     ratio = unet3d_flops(full, 2, 24, 96, 64, True)["total"] / unet3d_flops(full, 2, frames, h, w, True)["total"]
+    import platform
+
     return dict(value=1.0 / (dt * ratio), unit="steps/s", cores=torch.get_num_threads(), kind="port",
-                sample=f"fp32 oracle (port of the reference forward), 1 CFG step at F={frames}, latent {h}x{w}, SD-1.5 "
-                       f"widths: {dt:.1f} s; scaled by as-written FLOP ratio {ratio:.1f} to 24f x 768x512")
+                host=f"the bench host ({platform.node()}, {os.cpu_count()} logical cores)",
+                sample=f"fp32 oracle (port of the reference forward), 1 CFG step at F={frames}, latent {h}x{w} "
+                       f"({100.0 * h * w / (96 * 64):.0f} % of the config-3 pixels), SD-1.5 widths: {dt:.1f} s"
+                       + (f"; scaled by as-written FLOP ratio {ratio:.2f} to 24f x 768x512" if ratio > 1.001 else " (no scaling)"))
 
 
 CONFIGS = {
     # BASELINE.json configs[] index -> frames, height, width, description
     2: dict(F=16, H=512, W=512, what="Pose2Video 16f x 512x512, static camera (BASELINE.json configs[1])"),
     3: dict(F=24, H=768, W=512, what="Pose2Video 24f x 768x512, CameraCtrl Pluecker embedding (BASELINE.json configs[2])"),
-    5: dict(F=48, H=1024, W=576, what="Pose2Video 48f x 1024x576, 3 context windows of 24 per step (BASELINE.json configs[4])"),
+    5: dict(F=48, H=1024, W=576, what="Pose2Video 48f x 1024x576, 3 context windows of 24 per step (BASELINE.json configs[4]; "
+                                      "spatial attention bf16 by default, fp8 e4m3 with --fp8-attention 1: a footprint option)"),
 }
 
 
@@ -294,6 +300,9 @@ def main():
                          "run outside the timed region; if the probe raises, the serial path is timed and the line says so")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline", default="quarter", choices=["quarter", "full"],
+                    help="sample of the CPU baseline (fp32 oracle port on this host's cores): a quarter of the config-3 pixels "
+                         "(default, ~2 min on 128 cores) or the whole step (several minutes)")
     ap.add_argument("--no-profile", action="store_true", help="skip the profiled extra step (roofline block)")
     args = ap.parse_args()
 
@@ -471,6 +480,10 @@ def main():
             "config": {"workload": cfgsel["what"] + f"; CFG 3.5, SD-1.5 UNet3D + motion modules, {len(windows)} window(s) "
                                    "per step, DDIM v-pred",
                        "parallelism": par, "hip_graph": not args.no_graph,
+                       # BASELINE.json configs[4] names fp8 MFMA attention; it is a footprint option here, not the fast path
+                       # (QK^T reduces over d = 40 / 80 / 160, the 2x-rate MX fp8 MFMA over K = 128), so
+                       # the line says which arithmetic the spatial attention of THIS run used
+                       "attention_dtype": "fp8 e4m3 (hv_attention_fp8)" if fp8_attn else "bf16",
                        **({} if cfg_streams is None else {"cfg_streams": cfg_streams})},
             "step_algorithmic_tflop": fl_total / 1e12,
             "step_tflops_per_gpu": fl_total / 1e12 / (ms_step / 1e3) / world,
@@ -483,11 +496,12 @@ def main():
             out["roofline"] = roof
             out["kernels"] = table
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline()
+            out["cpu_baseline"] = cpu_baseline((96, 64) if args.cpu_baseline == "full" else (48, 32))
             ref = os.path.join(REPO, "tests", "golden", f"cpu_reference_config{args.config}.json")
             if os.path.exists(ref):  # the reference SOURCE timed in the build container (oracle/gen_fullsize_golden.py)
                 r = json.load(open(ref))
                 out["cpu_reference"] = {"value": r["steps_per_s"], "unit": "steps/s", "cores": r["cores"], "kind": "reference",
+                                        "host": "the build container (NOT the bench host)",
                                         "sample": "one steady-state denoising step of /root/reference's own code (fp32, "
                                                   f"{r['cores']} vCPU build container), committed measurement: "
                                                   f"tests/golden/cpu_reference_config{args.config}.json"}

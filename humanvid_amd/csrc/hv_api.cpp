@@ -126,8 +126,9 @@ int hv_set_tuning(int key, int value) {
     if (key == HV_TUNE_ATTN_D40 && (value >= 0 && value <= 2)) hvk_attention_tune(40, value);
     else if (key == HV_TUNE_ATTN_QT_D160 && (value == 1 || value == 2)) hvk_attention_tune(160, value);
     else if (key == HV_TUNE_GEMM_MAX_GRID && value >= 8 && value % 8 == 0) hvk_gemm_tune(value);
-    else if (key == HV_TUNE_GEMM_GLDS && (value >= 0 && value <= 6)) hvk_gemm_use_glds(value);
+    else if (key == HV_TUNE_GEMM_GLDS && ((value >= 0 && value <= 3) || value == 6)) hvk_gemm_use_glds(value);
     else if (key == HV_TUNE_GEMM_PERM && (value == 0 || value == 1)) hvk_gemm_perm(value);
+    else if (key == HV_TUNE_GEMM_STAGGER && (value == 0 || value == 2 || value == 4 || value == 8)) hvk_gemm_stagger(value);
     else if (key == HV_TUNE_CONV_GLDS && (value == 0 || value == 1)) hvk_conv_use_glds(value);
     else if (key == HV_TUNE_CONV_BIG && (value >= 0 && value <= 3)) hvk_conv_use_big(value);
     else if (key == HV_TUNE_CMDLIST_GRAPHS && (value == 0 || value == 1)) g_hv_cmdlist_graphs = value;

@@ -733,6 +733,24 @@ struct HvInt {
     static constexpr int value = N;
 };
 
+// Phase stagger of the persistent workgroups (hv_set_tuning key HV_TUNE_GEMM_STAGGER; round 4).  All workgroups of a launch
+// start together and walk tiles of identical cost, so every CU reaches its epilogue at the same moment: the phase timeline
+// (profiles/r03_gemm_trace.txt) shows 5500-7400 of a K = 320 tile's ~32 000 cycles as "store issue" -- eight store
+// instructions per wave that wait because 256 CUs x 64 KB hit the memory system at once (16 MB: ~3 us at the HBM write rate),
+// while the k-loops in between leave it idle.  Delaying the workgroups of an XCD by (index mod phases) x a fraction of a tile
+// once, at the start, spreads the bursts; the order of tiles and every result are unchanged.
+// stagger = phases << 8 | s_sleep(127) units (8128 cycles each) per phase step; 0 = off.
+HV_DEV void hv_gemm_stagger(int stagger) {
+#ifndef HV_EMU
+    if (stagger == 0) return;
+    const int phases = stagger >> 8, unit = stagger & 255;
+    const int n = ((int)(blockIdx.x >> 3) % phases) * unit;
+    for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(127);
+#else
+    (void)stagger;
+#endif
+}
+
 // Persistent workgroups: each walks a strided list of output tiles of its XCD's contiguous tile
 // range; the (tile, k-step) sequence is flattened so that the register prefetch (two k-tiles in
 // flight per workgroup) runs across tile boundaries and the epilogue of tile i overlaps the loads
@@ -903,7 +921,7 @@ __global__ __launch_bounds__(256, 2) void hv_gemm_kernel(HvGemmParams p) {
 //   STATS (with PERM): the plain / residual epilogue also leaves GroupNorm (1, p.gn_part) or LayerNorm (2, p.ln_part) partial
 //   statistics of its tile.
 template <int BN, int NW, int BM, int PH, bool PERM = false, int STATS = 0>
-__global__ __launch_bounds__(NW * 64, 2) void hv_gemm_glds_kernel(HvGemmParams p, int gm, int form) {
+__global__ __launch_bounds__(NW * 64, 2) void hv_gemm_glds_kernel(HvGemmParams p, int gm, int form, int stagger) {
     constexpr int BK = 64, NS = 2;
     constexpr int WAVES_N = BN / 64, WAVES_M = NW / WAVES_N;
     constexpr int WTM = BM / WAVES_M, NMF = WTM / 16;
@@ -954,6 +972,7 @@ __global__ __launch_bounds__(NW * 64, 2) void hv_gemm_glds_kernel(HvGemmParams p
     const int first = t_begin + wg;
     const int tstep = wg_per_xcd;
     if (first >= t_end) return;
+    hv_gemm_stagger(stagger);
     const int my_tiles = (t_end - first + wg_per_xcd - 1) / wg_per_xcd;
     const int nk = p.K / BK;
     const int nsteps = my_tiles * nk;
@@ -1179,14 +1198,13 @@ __global__ __launch_bounds__(NW * 64, 2) void hv_gemm_glds_kernel(HvGemmParams p
 // (the bias is mandatory for this kernel; a problem without a per-row table passes the bias row again with weight 0), the
 // residual rows of block b + 1 are requested BEFORE block b is converted (two register sets alternating at compile time)
 // and a block's results are stored as soon as they are packed (160 accumulator registers leave no room to hold them back).
-// STATS = 1: GroupNorm partial sums per 32-row wave block (p.gn_part); STATS = 2: LayerNorm partial sums per 64-column block
-// (p.ln_part) -- both over the fp32 values in front of the bf16 rounding, exactly as the square-tile kernels take them (the
-// kernel selection must never change a result: the two CFG halves of a step may run on different tile shapes).
-template <bool LN, bool RES, int STATS>
+// No statistics variants: no N = 320 / K >= 640 output of the denoising path feeds a norm (the parts queries answer 0 for this
+// kernel, so a caller that wants statistics gets the statistics pass).
+template <bool LN, bool RES>
 HV_DEV void hv_gemm_epilogue_wide(const HvGemmParams& p, f32x4 (&acc)[5][4][2], int m_base, int n0, int r16, int quad,
                                   const float* tab_row, float tab_scale) {
     constexpr int NB = 5, NMF = 2;
-    static_assert(!(LN && RES) && !(LN && STATS != 0), "forms of hv_gemm_fast_form");
+    static_assert(!(LN && RES), "forms of hv_gemm_fast_form");
     auto ld4 = [&](const float* base, unsigned byte_ofs) __attribute__((always_inline)) {
         return *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(base) + byte_ofs);
     };
@@ -1226,7 +1244,6 @@ HV_DEV void hv_gemm_epilogue_wide(const HvGemmParams& p, f32x4 (&acc)[5][4][2], 
 #if !defined(HV_EMU)
         __builtin_amdgcn_sched_barrier(0);  // the next block's residual requests stay ahead of this block's arithmetic
 #endif
-        float rs[NMF] = {0.f, 0.f}, rq[NMF] = {0.f, 0.f};
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             u32x4 o[NMF];
@@ -1236,7 +1253,6 @@ HV_DEV void hv_gemm_epilogue_wide(const HvGemmParams& p, f32x4 (&acc)[5][4][2], 
                 const unsigned co = 4u * (unsigned)(n0 + 64 * b + 32 * h + 8 * quad + 4 * k);
                 const f32x4 add = ld4(p.bias, co) + tab_scale * ld4(tab_row, co);
                 const f32x4 cs = LN ? ld4(p.colsum, co) : f32x4{0.f, 0.f, 0.f, 0.f};
-                f32x4 gs = {0.f, 0.f, 0.f, 0.f}, gq = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int mf = 0; mf < NMF; ++mf) {
                     f32x4 v = acc[b][2 * h + k][mf];
@@ -1250,47 +1266,10 @@ HV_DEV void hv_gemm_epilogue_wide(const HvGemmParams& p, f32x4 (&acc)[5][4][2], 
                     const unsigned o0 = hv_pack2(v[0], v[1]), o1 = hv_pack2(v[2], v[3]);
                     o[mf][2 * k] = o0;
                     o[mf][2 * k + 1] = o1;
-                    if (STATS == 1) {
-                        gs += v;
-                        gq += v * v;
-                    }
-                    if (STATS == 2) {
-                        rs[mf] += (v[0] + v[1]) + (v[2] + v[3]);
-                        rq[mf] += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
-                    }
-                }
-                if (STATS == 1) {  // rows [m_base, + 32) lie in one image (hv_gemm_gn_parts_of)
-                    const int parts = p.gn_rows_per_image / 32;
-                    const int img = m_base / p.gn_rows_per_image, part = (m_base - img * p.gn_rows_per_image) / 32;
-                    float* dst = p.gn_part + ((long)img * parts + part) * p.N * 2;
-                    f32x4 a, c;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        a[e] = hv_row16_sum(gs[e]);
-                        c[e] = hv_row16_sum(gq[e]);
-                    }
-                    if (r16 == 0) {
-                        *reinterpret_cast<f32x4*>(reinterpret_cast<char*>(dst) + 2u * co) = f32x4{a[0], c[0], a[1], c[1]};
-                        *reinterpret_cast<f32x4*>(reinterpret_cast<char*>(dst) + (2u * co + 16u)) = f32x4{a[2], c[2], a[3], c[3]};
-                    }
                 }
             }
 #pragma unroll
             for (int mf = 0; mf < NMF; ++mf) hv_st16(yb + (yrow[mf] + 2u * (unsigned)(n0 + 64 * b + 32 * h + 8 * quad)), o[mf]);
-        }
-        if (STATS == 2) {
-            const int parts = p.N / 64, blk = (n0 + 64 * b) / 64;
-#pragma unroll
-            for (int mf = 0; mf < NMF; ++mf) {
-                float a = rs[mf], c = rq[mf];
-                a += __shfl_xor(a, 16);
-                c += __shfl_xor(c, 16);
-                a += __shfl_xor(a, 32);
-                c += __shfl_xor(c, 32);
-                const int m = m_base + 16 * mf + r16;
-                if (quad == 0) *reinterpret_cast<u32x2*>(p.ln_part + ((long)m * parts + blk) * 2) =
-                    u32x2{__builtin_bit_cast(unsigned, a), __builtin_bit_cast(unsigned, c)};
-            }
         }
 #if !defined(HV_EMU)
         __builtin_amdgcn_sched_barrier(0);
@@ -1309,8 +1288,7 @@ HV_DEV void hv_gemm_epilogue_wide(const HvGemmParams& p, f32x4 (&acc)[5][4][2], 
 //   slot (s+1) % 2), issue k-tile s+1, multiply from slot s % 2.  The DMA goes out from inline asm (hv_glds16_s): hipcc
 //   does not see it and puts no vmcnt(0) in front of the fragment reads.
 //   Same swizzles, permuted channel assignment and epilogues (per 64-column block, NMF = 2) as hv_gemm_glds_kernel.
-template <int STATS>
-__global__ __launch_bounds__(512, 2) void hv_gemm_wide_kernel(HvGemmParams p, int form) {
+__global__ __launch_bounds__(512, 2) void hv_gemm_wide_kernel(HvGemmParams p, int form, int stagger) {
     constexpr int BM = 256, BN = 320, BK = 64, NS = 2, NW = 8, NB = BN / 64, NMF = 2;
     constexpr int XT = BM * BK * 2, WT = BN * BK * 2, SLOT = XT + WT;
     constexpr int RPI = 8, CPR = 8, RPB = 2;  // rows per 1 KiB wave-instruction, 16-byte chunks per row, rows per bank row
@@ -1331,6 +1309,7 @@ __global__ __launch_bounds__(512, 2) void hv_gemm_wide_kernel(HvGemmParams p, in
     const int t_begin = xcd * per_xcd, t_end = min(total, t_begin + per_xcd);
     const int first = t_begin + wg;
     if (first >= t_end) return;
+    hv_gemm_stagger(stagger);
     const int my_tiles = (t_end - first + wg_per_xcd - 1) / wg_per_xcd;
     const int nk = p.K / BK, nsteps = my_tiles * nk;
 
@@ -1424,9 +1403,9 @@ __global__ __launch_bounds__(512, 2) void hv_gemm_wide_kernel(HvGemmParams p, in
                 float tscale = 0.f;
                 if (p.pe != nullptr) tab = p.pe + (long)((mw / p.pe_period) % p.pe_frames) * p.N, tscale = 1.f;
                 else if (p.rowvec != nullptr) tab = p.rowvec + (long)(mw / p.rowvec_period) * p.N, tscale = 1.f;
-                if (form == HV_FORM_LN) hv_gemm_epilogue_wide<true, false, 0>(p, acc, mw, n0, r16, quad, tab, tscale);
-                else if (form == HV_FORM_RES) hv_gemm_epilogue_wide<false, true, STATS>(p, acc, mw, n0, r16, quad, tab, tscale);
-                else hv_gemm_epilogue_wide<false, false, STATS>(p, acc, mw, n0, r16, quad, tab, tscale);
+                if (form == HV_FORM_LN) hv_gemm_epilogue_wide<true, false>(p, acc, mw, n0, r16, quad, tab, tscale);
+                else if (form == HV_FORM_RES) hv_gemm_epilogue_wide<false, true>(p, acc, mw, n0, r16, quad, tab, tscale);
+                else hv_gemm_epilogue_wide<false, false>(p, acc, mw, n0, r16, quad, tab, tscale);
             }
             landed = 1;
             c_tile += wg_per_xcd;
@@ -1442,8 +1421,9 @@ static int g_hv_gemm_max_grid = 512;  // tuning knob (hv_set_tuning): persistent
 //      128 x 128 x 64 (two 4-wave workgroups per CU)
 //   2: 256 x 256 x 64 wherever its tile shape is legal (A/Bs), 3: 128 x 128 x 64 everywhere (A/Bs)
 //   0: the register-staged kernel for everything (A/Bs; also what problems outside the fast epilogue forms run on)
-//   4: as 1 with the wide tiles for every N = 320 problem, 5: also for N = 640, 6: as 1 without the wide tiles (round-3 default)
+//   6: as 1 without the wide tiles (the round-3 default; A/B)
 static int g_hv_gemm_glds = 1;
+static int g_hv_gemm_stagger = 0;  // tuning knob (hv_set_tuning key 8): phase groups of the persistent workgroups (0 = off, 2, 4, 8)
 static int g_hv_gemm_perm = 1;  // tuning knob (hv_set_tuning key 6): 16-byte epilogue through the permuted channel assignment (A/B)
 
 // Which kernel hv_gemm_launch takes for a problem: 0 register-staged, 1 = 256x256x64, 2 = 128x128x64 (LDS-DMA); perm = the
@@ -1452,18 +1432,18 @@ struct HvGemmChoice {
     int kernel, form, gm;
     bool perm;
 };
-static inline HvGemmChoice hv_gemm_choose(const HvGemmParams& p);
+static inline HvGemmChoice hv_gemm_choose(const HvGemmParams& p, bool want_stats);
 
 // parts per image of the GroupNorm partial statistics (0 = this problem's kernel cannot emit them)
 static inline int hv_gemm_gn_parts_of(const HvGemmParams& p) {
-    const HvGemmChoice c = hv_gemm_choose(p);
-    if ((c.kernel != 2 && c.kernel != 3) || !c.perm || (c.form != HV_FORM_RES && c.form != HV_FORM_PLAIN)) return 0;
-    const int rows = c.kernel == 3 ? 32 : 64;  // rows of a wave's sub-tile = rows per partial sum
+    const HvGemmChoice c = hv_gemm_choose(p, true);
+    if (c.kernel != 2 || !c.perm || (c.form != HV_FORM_RES && c.form != HV_FORM_PLAIN)) return 0;
+    const int rows = 64;  // rows of a wave's sub-tile = rows per partial sum
     if (p.gn_rows_per_image <= 0 || p.gn_rows_per_image % rows != 0 || p.M % p.gn_rows_per_image != 0) return 0;
     return p.gn_rows_per_image / rows;
 }
 
-static inline HvGemmChoice hv_gemm_choose(const HvGemmParams& p) {
+static inline HvGemmChoice hv_gemm_choose(const HvGemmParams& p, bool want_stats) {
     HvGemmChoice c{0, HV_FORM_NONE, 1, false};
     const bool prologue = p.pro_scale != nullptr || p.pro_act != HV_ACT_NONE;
     // the LDS-DMA kernel addresses its operands with 32-bit byte offsets and only knows the hot epilogue forms
@@ -1478,13 +1458,13 @@ static inline HvGemmChoice hv_gemm_choose(const HvGemmParams& p) {
     if (form64 == HV_FORM_NONE && g_hv_gemm_perm && p.N % 8 == 0 && p.pe != nullptr && hv_gemm_fast_form(p, 16) == HV_FORM_LN)
         form64 = HV_FORM_LN;
     if (!(g_hv_gemm_glds && !prologue && p.M >= 256 && span_ok && form64 != HV_FORM_NONE)) return c;
-    // 256 x 320 x 64 wide tiles (hv_gemm_wide_kernel) for N = 320 with a plain-output form on the permuted assignment: the
-    // default takes N = 320 with K >= 640 (level-0 ff2: same-box A/B 0.384 -> 0.336 ms with the round-3 epilogue,
-    // profiles/r03_gemm_wide_ab.txt); tuning value 4 every N = 320 problem, 5 also N = 640 (576 tiles at level 1 = 2.25 rounds
-    // over the 256 CUs: measured slower in round 3), 6 none (the round-3 default) -- A/Bs.
-    const bool wide_n = p.N == 320 ? (p.K >= 640 || g_hv_gemm_glds == 4 || g_hv_gemm_glds == 5) : (p.N == 640 && g_hv_gemm_glds == 5);
-    if (g_hv_gemm_glds != 6 && g_hv_gemm_glds != 2 && g_hv_gemm_glds != 3 && wide_n && g_hv_gemm_perm && p.X2 == nullptr &&
-        p.M % 256 == 0 && p.Yt == nullptr && !p.geglu && p.bias != nullptr) {
+    // 256 x 320 x 64 wide tiles (hv_gemm_wide_kernel) for N = 320, K >= 640 with a plain-output form on the permuted assignment
+    // (level-0 ff2: same-box 0.385 -> 0.327 ms, profiles/r04_s1.txt).  Measured and not taken: K = 320 (0.158 -> 0.159 ms: five
+    // k-steps do not amortise the 320-column epilogue), N = 640 (576 tiles at level 1 = 2.25 rounds over the 256 CUs: projection
+    // 0.086 -> 0.097 ms, ff2 0.303 -> 0.296).  Tuning value 6 = never (A/B).  The kernel leaves no normalisation statistics: a
+    // problem that asks for them stays on the square tiles.
+    if (g_hv_gemm_glds != 6 && g_hv_gemm_glds != 2 && g_hv_gemm_glds != 3 && p.N == 320 && p.K >= 640 && g_hv_gemm_perm &&
+        p.X2 == nullptr && p.M % 256 == 0 && p.Yt == nullptr && !p.geglu && p.bias != nullptr && !want_stats) {
         const int form32 = hv_gemm_fast_form(p, 32);
         if (form32 == HV_FORM_RES || form32 == HV_FORM_PLAIN || form32 == HV_FORM_LN) {
             c.kernel = 3;
@@ -1503,7 +1483,7 @@ static inline HvGemmChoice hv_gemm_choose(const HvGemmParams& p) {
     const int t256 = tm * (n256 / 256), rounds256 = (t256 + 255) / 256;
     const bool fills256 = t256 * 10 >= rounds256 * 256 * 9;
     const bool shape256 = ok128 && p.N >= 960 && (n256 - p.N) * 8 <= p.N;
-    const bool big = g_hv_gemm_glds != 3 && shape256 && (fills256 || g_hv_gemm_glds == 2);  // (values 4 - 6 select like 1 here)
+    const bool big = g_hv_gemm_glds != 3 && shape256 && (fills256 || g_hv_gemm_glds == 2);  // (value 6 selects like 1 here)
     c.kernel = big ? 1 : 2;
     c.form = big ? form128 : form64;
     // plain bf16 outputs (plain / residual / LayerNorm fold) and GEGLU with N % 8 == 0: permuted channel assignment, 16-byte epilogue
@@ -1514,9 +1494,19 @@ static inline HvGemmChoice hv_gemm_choose(const HvGemmParams& p) {
 
 // 64-column blocks per row of the LayerNorm partial statistics (0 = this problem's kernel cannot emit them)
 static inline int hv_gemm_ln_parts_of(const HvGemmParams& p) {
-    const HvGemmChoice c = hv_gemm_choose(p);
-    if ((c.kernel != 2 && c.kernel != 3) || !c.perm || (c.form != HV_FORM_RES && c.form != HV_FORM_PLAIN) || p.N % 64 != 0) return 0;
+    const HvGemmChoice c = hv_gemm_choose(p, true);
+    if (c.kernel != 2 || !c.perm || (c.form != HV_FORM_RES && c.form != HV_FORM_PLAIN) || p.N % 64 != 0) return 0;
     return p.N / 64;
+}
+
+// stagger argument of a launch: `tile_cycles` = rough duration of one tile (k-steps x cycles per k-step + epilogue), `tiles_per_wg`
+// how many tiles a workgroup walks (short walks are not staggered: the delay would not be amortised)
+static inline int hv_gemm_stagger_arg(int tile_cycles, int tiles_per_wg) {
+    if (g_hv_gemm_stagger <= 1 || tiles_per_wg < 4) return 0;
+    int unit = (tile_cycles / g_hv_gemm_stagger + 4064) / 8128;
+    if (unit < 1) unit = 1;
+    if (unit > 255) unit = 255;
+    return (g_hv_gemm_stagger << 8) | unit;
 }
 
 static inline int hv_gemm_launch(const HvGemmParams& p, hipStream_t stream) {
@@ -1535,18 +1525,19 @@ static inline int hv_gemm_launch(const HvGemmParams& p, hipStream_t stream) {
     if (g_hv_prof)
         snprintf(shape, sizeof(shape), "M=%d N=%d K=%d geglu=%d res=%d yt=%d f32=%d x2=%d", p.M, p.N, p.K, p.geglu,
                  p.residual != nullptr, p.Yt != nullptr ? p.N - p.n_split : 0, p.out_f32, p.X2 != nullptr);
-    const HvGemmChoice c = hv_gemm_choose(p);
+    const HvGemmChoice c = hv_gemm_choose(p, p.gn_part != nullptr || p.ln_part != nullptr);
     if (c.kernel == 1) {
         const int t256 = ((p.M + 255) / 256) * ((p.N + 255) / 256);
         int grid = ((t256 + 7) / 8) * 8;
         if (grid > 256) grid = 256;
         if (grid > g_hv_gemm_max_grid) grid = g_hv_gemm_max_grid;
+        const int stg = hv_gemm_stagger_arg((p.K / 64) * 4500 + 9000, t256 / grid);
         if (c.perm) {
             hv_note("hv_gemm_glds_kernel<256,8,256,1,perm> | %s", shape);
-            hv_launch(hv_gemm_glds_kernel<256, 8, 256, 1, true>, dim3(grid), dim3(512), stream, p, c.gm, c.form);
+            hv_launch(hv_gemm_glds_kernel<256, 8, 256, 1, true>, dim3(grid), dim3(512), stream, p, c.gm, c.form, stg);
         } else {
             hv_note("hv_gemm_glds_kernel<256,8,256,1> | %s", shape);
-            hv_launch(hv_gemm_glds_kernel<256, 8, 256, 1, false>, dim3(grid), dim3(512), stream, p, c.gm, c.form);
+            hv_launch(hv_gemm_glds_kernel<256, 8, 256, 1, false>, dim3(grid), dim3(512), stream, p, c.gm, c.form, stg);
         }
         return 0;
     }
@@ -1555,10 +1546,9 @@ static inline int hv_gemm_launch(const HvGemmParams& p, hipStream_t stream) {
         int grid = ((tw + 7) / 8) * 8;
         if (grid > 256) grid = 256;
         if (grid > g_hv_gemm_max_grid) grid = g_hv_gemm_max_grid;
-        hv_note("hv_gemm_wide_kernel<%s> | %s", p.gn_part ? "gn" : (p.ln_part ? "ln" : "-"), shape);
-        if (p.gn_part != nullptr) hv_launch(hv_gemm_wide_kernel<1>, dim3(grid), dim3(512), stream, p, c.form);
-        else if (p.ln_part != nullptr) hv_launch(hv_gemm_wide_kernel<2>, dim3(grid), dim3(512), stream, p, c.form);
-        else hv_launch(hv_gemm_wide_kernel<0>, dim3(grid), dim3(512), stream, p, c.form);
+        hv_note("hv_gemm_wide_kernel | %s", shape);
+        const int stg = hv_gemm_stagger_arg((p.K / 64) * 3000 + 8000, tw / grid);
+        hv_launch(hv_gemm_wide_kernel, dim3(grid), dim3(512), stream, p, c.form, stg);
         return 0;
     }
     if (c.kernel == 2) {
@@ -1566,18 +1556,19 @@ static inline int hv_gemm_launch(const HvGemmParams& p, hipStream_t stream) {
         int grid6 = ((tiles6 + 7) / 8) * 8;
         if (grid6 > 512) grid6 = 512;
         if (grid6 > g_hv_gemm_max_grid) grid6 = g_hv_gemm_max_grid;
+        const int stg = hv_gemm_stagger_arg((p.K / 64) * 2800 + 7700, tiles6 / grid6);
         if (c.perm && p.gn_part != nullptr) {
             hv_note("hv_gemm_glds_kernel<128,4,128,2,perm,gn> | %s", shape);
-            hv_launch(hv_gemm_glds_kernel<128, 4, 128, 2, true, 1>, dim3(grid6), dim3(256), stream, p, c.gm, c.form);
+            hv_launch(hv_gemm_glds_kernel<128, 4, 128, 2, true, 1>, dim3(grid6), dim3(256), stream, p, c.gm, c.form, stg);
         } else if (c.perm && p.ln_part != nullptr) {
             hv_note("hv_gemm_glds_kernel<128,4,128,2,perm,ln> | %s", shape);
-            hv_launch(hv_gemm_glds_kernel<128, 4, 128, 2, true, 2>, dim3(grid6), dim3(256), stream, p, c.gm, c.form);
+            hv_launch(hv_gemm_glds_kernel<128, 4, 128, 2, true, 2>, dim3(grid6), dim3(256), stream, p, c.gm, c.form, stg);
         } else if (c.perm) {
             hv_note("hv_gemm_glds_kernel<128,4,128,2,perm> | %s", shape);
-            hv_launch(hv_gemm_glds_kernel<128, 4, 128, 2, true>, dim3(grid6), dim3(256), stream, p, c.gm, c.form);
+            hv_launch(hv_gemm_glds_kernel<128, 4, 128, 2, true>, dim3(grid6), dim3(256), stream, p, c.gm, c.form, stg);
         } else {
             hv_note("hv_gemm_glds_kernel<128,4,128,2> | %s", shape);
-            hv_launch(hv_gemm_glds_kernel<128, 4, 128, 2, false>, dim3(grid6), dim3(256), stream, p, c.gm, c.form);
+            hv_launch(hv_gemm_glds_kernel<128, 4, 128, 2, false>, dim3(grid6), dim3(256), stream, p, c.gm, c.form, stg);
         }
         return 0;
     }

@@ -20,13 +20,13 @@ sys.path.insert(0, os.path.join(REPO, "oracle"))
 pytestmark = pytest.mark.gpu
 
 
-def _inputs(F=4):
+def _inputs(F=4, hw=8):
     import oracle_torch as O
 
     cfg = O.tiny_unet3d_cfg()
     sd = O.make_unet3d_weights(cfg, seed=0)
     g = torch.Generator().manual_seed(42)
-    H, W, h, w = 64, 64, 8, 8
+    H, W, h, w = 8 * hw, 8 * hw, hw, hw
     lat = torch.randn(1, 4, F, h, w, generator=g)
     pose = torch.rand(1, 3, F, H, W, generator=g)
     pl = torch.randn(1, 6, F, H, W, generator=g)
@@ -39,7 +39,7 @@ def _inputs(F=4):
 
 
 def _worker(rank, world, port, out_path, backend="gloo", frames=4, window_groups=1, context_frames=24, context_overlap=4,
-            check_stats=True):
+            check_stats=True, hw=8):
     import torch.distributed as dist
 
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
@@ -50,7 +50,7 @@ def _worker(rank, world, port, out_path, backend="gloo", frames=4, window_groups
     else:
         dist.init_process_group("gloo", rank=rank, world_size=world)
         torch.cuda.set_device(0)
-    O, cfg, sd, lat, pose, pl, clip, banks = _inputs(frames)
+    O, cfg, sd, lat, pose, pl, clip, banks = _inputs(frames, hw)
     from humanvid_amd.conditioning import CameraPoseEncoder, PoseGuider
     from humanvid_amd.engine import UNet3DEngine
     from humanvid_amd.pipeline import Pose2VideoPipeline
@@ -166,8 +166,8 @@ def _run_two_ranks(tmp_path, name, **kw):
     port = s.getsockname()[1]
     s.close()
     out_path = str(tmp_path / name)
-    mp.spawn(_worker, args=(2, port, out_path, kw.get("backend", "gloo"), 4, 1, 24, 4, kw.get("check_stats", True)), nprocs=2,
-             join=True)
+    mp.spawn(_worker, args=(2, port, out_path, kw.get("backend", "gloo"), 4, 1, 24, 4, kw.get("check_stats", True),
+                            kw.get("hw", 8)), nprocs=2, join=True)
     return torch.load(out_path)
 
 
@@ -177,15 +177,18 @@ def test_cfg_halves_on_two_streams_are_bit_identical(tmp_path, monkeypatch):
     INTERLEAVED (segment k of both halves, then collective k of both) -- instead of one B = 2 forward.  Every image goes
     through the same kernels with the same reduction order, so the latents of all three steps must equal the serial path's
     bit for bit (2 ranks on one GPU, host-staged transport: only the transport differs from RCCL).  Also checked with the
-    command lists re-issued launch by launch instead of as captured graphs (HUMANVID_TUNING=7=0)."""
+    command lists re-issued launch by launch instead of as captured graphs (HUMANVID_TUNING=7=0).
+    Latent 32 x 32 (level 1: 16 x 16 = 256 rows per image): a half of a rank's batch (2 images) still has >= 256 rows at
+    every level, so that both forms run on the LDS-DMA kernels that leave the normalisation statistics (below 256 rows the
+    register-staged kernel + the statistics pass take over, which rounds differently: not the regime of any real shard)."""
     monkeypatch.setenv("HUMANVID_CFG_STREAMS", "0")
-    serial = _run_two_ranks(tmp_path, "serial.pt")
+    serial = _run_two_ranks(tmp_path, "serial.pt", hw=32)
     monkeypatch.setenv("HUMANVID_CFG_STREAMS", "1")
-    overlapped = _run_two_ranks(tmp_path, "overlap.pt", check_stats=False)
+    overlapped = _run_two_ranks(tmp_path, "overlap.pt", check_stats=False, hw=32)
     assert len(serial) == len(overlapped) == 3
     for i, (a, b) in enumerate(zip(serial, overlapped)):
         assert torch.isfinite(b).all() and torch.equal(a, b), (i, float((a - b).abs().max()))
     monkeypatch.setenv("HUMANVID_TUNING", "7=0")
-    closures = _run_two_ranks(tmp_path, "overlap_closures.pt", check_stats=False)
+    closures = _run_two_ranks(tmp_path, "overlap_closures.pt", check_stats=False, hw=32)
     for i, (a, b) in enumerate(zip(serial, closures)):
         assert torch.equal(a, b), (i, float((a - b).abs().max()))

@@ -131,6 +131,7 @@ int hv_set_tuning(int key, int value) {
     else if (key == HV_TUNE_GEMM_STAGGER && (value == 0 || value == 2 || value == 4 || value == 8)) hvk_gemm_stagger(value);
     else if (key == HV_TUNE_CONV_GLDS && (value == 0 || value == 1)) hvk_conv_use_glds(value);
     else if (key == HV_TUNE_CONV_BIG && (value >= 0 && value <= 3)) hvk_conv_use_big(value);
+    else if (key == HV_TUNE_CONV_RASTER && (value >= 0 && value <= 2)) hvk_conv_raster(value);
     else if (key == HV_TUNE_CMDLIST_GRAPHS && (value == 0 || value == 1)) g_hv_cmdlist_graphs = value;
     else return hv_fail(HV_EINVAL, "hv_set_tuning: unknown key/value");
     return HV_OK;
@@ -173,8 +174,8 @@ int hv_plucker_unshuffle(const float* K, const float* c2w, int F, int H, int W, 
 int hv_affine_apply(const uint16_t* X, long ldx, int rows, int rows_per_image, int C, const float* scale, const float* shift,
                     int act, uint16_t* Y, long ldy, void* stream) {
     if (!X || !Y || !scale || !shift) return hv_fail(HV_EINVAL, "hv_affine_apply: null operand");
-    if (rows <= 0 || rows_per_image <= 0 || C <= 0 || C % 8 != 0 || ldx % 8 != 0 || ldy % 8 != 0)
-        return hv_fail(HV_EINVAL, "hv_affine_apply: need C % 8 == 0 and 16-byte aligned rows");
+    if (rows <= 0 || rows_per_image <= 0 || rows % rows_per_image != 0 || C <= 0 || C % 8 != 0 || C > 2560 || ldx % 8 != 0 || ldy % 8 != 0)
+        return hv_fail(HV_EINVAL, "hv_affine_apply: need whole images (rows % rows_per_image == 0), C % 8 == 0, C <= 2560 and 16-byte aligned rows");
     hvk_affine_apply(X, ldx, rows, rows_per_image, C, nullptr, 0, 0, scale, shift, act, Y, ldy, (hipStream_t)stream);
     return hv_check_launch("hv_affine_apply");
 }
@@ -182,9 +183,9 @@ int hv_affine_apply(const uint16_t* X, long ldx, int rows, int rows_per_image, i
 int hv_affine_apply_cat(const uint16_t* X, long ldx, int C, const uint16_t* X2, long ldx2, int C2, int rows, int rows_per_image,
                         const float* scale, const float* shift, int act, uint16_t* Y, long ldy, void* stream) {
     if (!X || !X2 || !Y || !scale || !shift) return hv_fail(HV_EINVAL, "hv_affine_apply_cat: null operand");
-    if (rows <= 0 || rows_per_image <= 0 || C <= 0 || C2 <= 0 || C % 8 != 0 || C2 % 8 != 0 || ldx % 8 != 0 || ldx2 % 8 != 0 ||
-        ldy % 8 != 0 || ldy < C + C2)
-        return hv_fail(HV_EINVAL, "hv_affine_apply_cat: need C % 8 == 0, C2 % 8 == 0, 16-byte aligned rows, ldy >= C + C2");
+    if (rows <= 0 || rows_per_image <= 0 || rows % rows_per_image != 0 || C <= 0 || C2 <= 0 || C % 8 != 0 || C2 % 8 != 0 || C + C2 > 2560 ||
+        ldx % 8 != 0 || ldx2 % 8 != 0 || ldy % 8 != 0 || ldy < C + C2)
+        return hv_fail(HV_EINVAL, "hv_affine_apply_cat: need whole images, C % 8 == 0, C2 % 8 == 0, C + C2 <= 2560, 16-byte aligned rows, ldy >= C + C2");
     hvk_affine_apply(X, ldx, rows, rows_per_image, C, X2, ldx2, C2, scale, shift, act, Y, ldy, (hipStream_t)stream);
     return hv_check_launch("hv_affine_apply_cat");
 }

@@ -20,10 +20,6 @@
 #include "hv_gemm.h"  // hv_swz
 #include "humanvid_hip.h"
 
-#ifndef HV_CONV_ABL
-#define HV_CONV_ABL 0  // timing-only ablation builds (tools/conv_ablation.sh; results are wrong): 1 no halo global loads, 2 no halo
-                       // LDS stores, 4 no weight LDS-DMA (and no waits for it), 8 no fragment ds_reads, 16 no MFMAs, 32 no stores
-#endif
 #ifndef HV_CONV_HBUFS1
 #define HV_CONV_HBUFS1 1  // one halo buffer for every variant (0: two for CK = 32, the round-2 layout; same-box A/B in profiles/r03_conv_lds_ab.txt)
 #endif
@@ -83,7 +79,7 @@ struct HvConvGeom {
 // the finding behind the GEMM's BK = 64), every tap step carries 32 MFMAs per wave behind its barrier instead of 16, and the
 // number of steps, barriers and DMA instructions halves.  74 KiB of LDS (one 26 KiB halo buffer, three 16 KiB weight slots).
 template <int TW, int MODE, bool GLDS, int NPIX, int WPX = 64, int CK = 32>
-__global__ __launch_bounds__(2 * 64 * (NPIX / WPX), (WPX == 128 ? 2 : 1)) void hv_conv3x3_kernel(hv_conv3x3_params p) {
+__global__ __launch_bounds__(2 * 64 * (NPIX / WPX), (WPX == 128 ? 2 : 1)) void hv_conv3x3_kernel(hv_conv3x3_params p, int raster) {
     using G = HvConvGeom<TW, MODE, NPIX, WPX, CK>;
     static_assert(CK == 32 || (CK == 64 && GLDS), "64-channel chunks stream their weights by LDS-DMA");
     constexpr int TH = G::TH;
@@ -104,8 +100,20 @@ __global__ __launch_bounds__(2 * 64 * (NPIX / WPX), (WPX == 128 ? 2 : 1)) void h
     const int cpx = gridDim.x / 8;
     int t = (blockIdx.x % 8) * cpx + blockIdx.x / 8;
     if (t >= total) return;
-    const int n0 = (t % tiles_n) * 128;
-    t /= tiles_n;
+    // Workgroup raster inside an XCD's contiguous range of t.  0: the output-channel tiles of a pixel patch are adjacent (its
+    // halo is fetched once and re-read from L2 by the tiles_n workgroups; the XCD's concurrent workgroups then stream ALL
+    // weight tiles, 29 MB at 1280 -> 1280 channels against 4 MB of L2: profiles/r03_pmc_traffic.json counts the weights
+    // 15-24 x).  1: the pixel patches of ONE output-channel tile are adjacent (its 9 x Cin x 128 weights stay in L2 while the
+    // XCD walks the patches; every patch's halo is fetched once per channel tile instead).
+    int n0;
+    if (raster == 0) {
+        n0 = (t % tiles_n) * 128;
+        t /= tiles_n;
+    } else {
+        const int npatch = p.n_images * tiles_y * tiles_x;
+        n0 = (t / npatch) * 128;
+        t %= npatch;
+    }
     const int x0 = (t % tiles_x) * TW;
     t /= tiles_x;
     const int y0 = (t % tiles_y) * TH;
@@ -143,7 +151,7 @@ __global__ __launch_bounds__(2 * 64 * (NPIX / WPX), (WPX == 128 ? 2 : 1)) void h
             u32x4 v = {0u, 0u, 0u, 0u};
             if (hp < G::HP) {
                 const int iy = in_y0 + hp / G::HW, ix = in_x0 + hp % G::HW;
-                if (!(HV_CONV_ABL & 1) && iy >= 0 && iy < p.Hs && ix >= 0 && ix < p.Ws)
+                if (iy >= 0 && iy < p.Hs && ix >= 0 && ix < p.Ws)
                     v = hv_ld16(base + ((long)(img * p.Hs + iy) * p.Ws + ix) * cs + cc);
             }
             hreg[j] = v;
@@ -179,7 +187,7 @@ __global__ __launch_bounds__(2 * 64 * (NPIX / WPX), (WPX == 128 ? 2 : 1)) void h
                     v = hv_pack8(f);
                 }
             }
-            if (!(HV_CONV_ABL & 2) || v[0] == 0x12345u) hv_st16(halo + buf * G::HALO_BYTES + hp * G::PS + hc * 16, v);
+            hv_st16(halo + buf * G::HALO_BYTES + hp * G::PS + hc * 16, v);
         }
     };
 
@@ -233,7 +241,7 @@ __global__ __launch_bounds__(2 * 64 * (NPIX / WPX), (WPX == 128 ? 2 : 1)) void h
         hv_static_for<WQ>([&](auto Q) __attribute__((always_inline)) {
             constexpr int q = decltype(Q)::value;
             // base = the kernel argument: always an SGPR pair
-            if (!(HV_CONV_ABL & 4)) hv_glds16_s(p.W, hv_pick4<q>(wofs0, wofs1, wofs2, wofs3) + step, slot + (wave_u + NW * q) * 1024);
+            hv_glds16_s(p.W, hv_pick4<q>(wofs0, wofs1, wofs2, wofs3) + step, slot + (wave_u + NW * q) * 1024);
         });
         if (++iw_slot == 3) iw_slot = 0;
         if (++iw_tap == 9) {
@@ -286,8 +294,7 @@ __global__ __launch_bounds__(2 * 64 * (NPIX / WPX), (WPX == 128 ? 2 : 1)) void h
                 store_halo(chunk, hbuf);
             }
             if (GLDS) {
-                if (HV_CONV_ABL & 4) {
-                } else if (s + 1 < nsteps)
+                if (s + 1 < nsteps)
                     hv_vm_wait<WQ>();  // tap tile s landed, tile s+1 may stay in flight
                 else
                     hv_vm_wait<0>();
@@ -310,12 +317,7 @@ __global__ __launch_bounds__(2 * 64 * (NPIX / WPX), (WPX == 128 ? 2 : 1)) void h
                 bf16x8 wf[4];
 #pragma unroll
                 for (int f = 0; f < 4; ++f)
-                    if (HV_CONV_ABL & 8) {
-                        u32x4 z = {(unsigned)lane, (unsigned)lane, (unsigned)lane, (unsigned)lane};
-                        asm volatile("" : "+v"(z));
-                        wf[f] = hv_as_bf16x8(z);
-                    } else
-                        wf[f] = hv_as_bf16x8(hv_ld16(wb + hv_swz_conv<CK>(64 * wn + 16 * f + r16, kk * 4 + quad)));
+                    wf[f] = hv_as_bf16x8(hv_ld16(wb + hv_swz_conv<CK>(64 * wn + 16 * f + r16, kk * 4 + quad)));
                 // pixel fragments in groups of four (16 registers of operands at a time)
 #pragma unroll
                 for (int g = 0; g < NMF; g += 4) {
@@ -329,20 +331,13 @@ __global__ __launch_bounds__(2 * 64 * (NPIX / WPX), (WPX == 128 ? 2 : 1)) void h
                             lp = lpb[g + f] + dy * G::HW + dx;
                         else
                             lp = ((py[g + f] + dy + 1) >> 1) * G::HW + ((px[g + f] + dx + 1) >> 1);
-                        if (HV_CONV_ABL & 8) {
-                            u32x4 z = {(unsigned)lp, (unsigned)lane, (unsigned)lane, (unsigned)lane};
-                            asm volatile("" : "+v"(z));
-                            xf[f] = hv_as_bf16x8(z);
-                        } else
-                            xf[f] = hv_as_bf16x8(hv_ld16(hb + lp * G::PS + kk * 64));
+                        xf[f] = hv_as_bf16x8(hv_ld16(hb + lp * G::PS + kk * 64));
                     }
 #pragma unroll
                     for (int nf = 0; nf < 4; ++nf)
 #pragma unroll
                         for (int mf = 0; mf < 4; ++mf)
-                            if (HV_CONV_ABL & 16) asm volatile("" : "+v"(acc[nf][g + mf]) : "v"(wf[nf]), "v"(xf[mf]));
-                            else
-                                acc[nf][g + mf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nf], xf[mf], acc[nf][g + mf], 0, 0, 0);
+                            acc[nf][g + mf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nf], xf[mf], acc[nf][g + mf], 0, 0, 0);
                 }
             }
         });
@@ -423,7 +418,7 @@ __global__ __launch_bounds__(2 * 64 * (NPIX / WPX), (WPX == 128 ? 2 : 1)) void h
         for (int nf = 0; nf < 4; ++nf) {
             const int n = n0 + 64 * wn + 16 * nf + 4 * quad;
             if (n >= p.Cout) continue;
-            if (!(HV_CONV_ABL & 32) || outp[nf][mf][0] == 0x12345u) hv_st8(p.Y + opix[mf] * p.Cout + n, outp[nf][mf]);
+            hv_st8(p.Y + opix[mf] * p.Cout + n, outp[nf][mf]);
         }
     }
 }
@@ -431,6 +426,7 @@ __global__ __launch_bounds__(2 * 64 * (NPIX / WPX), (WPX == 128 ? 2 : 1)) void h
 static int g_hv_conv_glds = 1;  // tuning knob (hv_set_tuning): LDS-DMA weight tiles
 
 static int g_hv_conv_big = 1;  // tuning knob: 256-pixel tiles (8 waves) on images that fill them
+static int g_hv_conv_raster = 0;  // tuning knob (hv_set_tuning key 9): 0 / 1 always that raster, 2 = raster 1 where the weights exceed the XCD's L2 (Cin x Cout >= 640 x 640)
 
 template <int TW, int MODE, int NPIX, int WPX = 64, int CK = 32>
 static inline void hv_conv3x3_launch_t(const hv_conv3x3_params& p, hipStream_t stream) {
@@ -441,10 +437,11 @@ static inline void hv_conv3x3_launch_t(const hv_conv3x3_params& p, hipStream_t s
     hv_note("hv_conv3x3_kernel<%d,%d,%d,%d%s%s> | n=%d Hs=%d Ws=%d Ho=%d Wo=%d Cin=%d Cout=%d gn=%d res=%d", TW, MODE,
             g_hv_conv_glds, NPIX, WPX == 128 ? ",128" : "", CK == 64 ? ",ck64" : "", p.n_images, p.Hs, p.Ws, p.Ho, p.Wo, p.C1 + p.C2,
             p.Cout, p.pro_scale != nullptr, p.residual != nullptr);
+    const int raster = g_hv_conv_raster == 2 ? ((long)(p.C1 + p.C2) * p.Cout >= 640L * 640 ? 1 : 0) : g_hv_conv_raster;
     if (g_hv_conv_glds || WPX == 128 || CK == 64)
-        hv_launch(hv_conv3x3_kernel<TW, MODE, true, NPIX, WPX, CK>, dim3(grid), dim3(NT), stream, p);
+        hv_launch(hv_conv3x3_kernel<TW, MODE, true, NPIX, WPX, CK>, dim3(grid), dim3(NT), stream, p, raster);
     else if constexpr (CK == 32)
-        hv_launch(hv_conv3x3_kernel<TW, MODE, false, NPIX, WPX, CK>, dim3(grid), dim3(NT), stream, p);
+        hv_launch(hv_conv3x3_kernel<TW, MODE, false, NPIX, WPX, CK>, dim3(grid), dim3(NT), stream, p, raster);
 }
 
 // (tile rows, tile columns, pixel halves per tile) of the kernel hv_conv3x3_launch selects for this problem: the layout of

@@ -226,35 +226,57 @@ static inline void hv_cfg_ddim_launch(float* latents, float* acc, float* counter
 // Two sources (X2 != nullptr): the channel concatenation [X | X2] of a decoder ResnetBlock3D's input
 // (unet_3d_blocks.py: torch.cat([hidden_states, res_hidden_states], dim=1) in front of resnet.py:215-245) is written as ONE
 // [rows, C + C2] activation, so the convolution behind it reads a single source; scale / shift rows are C + C2 wide.
-__global__ __launch_bounds__(256) void hv_affine_apply_kernel(const bf16_t* X, long ldx, int rows, int rows_per_image, int C,
-                                                              const bf16_t* X2, long ldx2, int C2, const float* scale,
-                                                              const float* shift, int act, bf16_t* Y, long ldy) {
-    const int cvs = (C + C2) / 8, cv1 = C / 8;
-    const long total = (long)rows * cvs;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const int cv = (int)(i % cvs);
-        const long row = i / cvs;
-        const long so = (row / rows_per_image) * (C + C2) + cv * 8;
+// Round 4 form: a thread keeps ONE 8-channel slot of ONE image (its scale / shift pairs stay in 16 registers) and walks rows of
+// that image, four independent 16-byte loads in flight -- the round-3 form re-derived (row, slot, image) with 64-bit
+// divisions and re-loaded 64 bytes of scale / shift for every 16 bytes of payload (five VMEM instructions per store): it ran
+// at 4.1 TB/s where a copy reaches 6.3.  Block = cvs x RB threads (cvs = 8-channel slots per row, RB rows side by side);
+// grid = (row groups, images).
+__global__ __launch_bounds__(320) void hv_affine_apply_kernel(const bf16_t* X, long ldx, int rows_per_image, int C, const bf16_t* X2,
+                                                              long ldx2, int C2, const float* scale, const float* shift, int act,
+                                                              bf16_t* Y, long ldy, int cvs, int rb) {
+    const int cv = threadIdx.x % cvs, r0 = threadIdx.x / cvs;
+    if (r0 >= rb) return;
+    const int img = blockIdx.y;
+    const long so = (long)img * (C + C2) + cv * 8;
+    const f32x4 s0 = *reinterpret_cast<const f32x4*>(scale + so), s1 = *reinterpret_cast<const f32x4*>(scale + so + 4);
+    const f32x4 t0 = *reinterpret_cast<const f32x4*>(shift + so), t1 = *reinterpret_cast<const f32x4*>(shift + so + 4);
+    const bool second = cv * 8 >= C;
+    const bf16_t* src = second ? X2 + (cv * 8 - C) : X + cv * 8;
+    const long lds = second ? ldx2 : ldx;
+    const long row0 = (long)img * rows_per_image;
+    const int step = gridDim.x * rb;
+    auto apply = [&](u32x4 v) __attribute__((always_inline)) {
         float f[8];
-        hv_unpack8(cv < cv1 ? hv_ld16(X + row * ldx + cv * 8) : hv_ld16(X2 + row * ldx2 + (cv - cv1) * 8), f);
-        const f32x4 s0 = *reinterpret_cast<const f32x4*>(scale + so), s1 = *reinterpret_cast<const f32x4*>(scale + so + 4);
-        const f32x4 t0 = *reinterpret_cast<const f32x4*>(shift + so), t1 = *reinterpret_cast<const f32x4*>(shift + so + 4);
+        hv_unpack8(v, f);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             f[e] = hv_act(f[e] * s0[e] + t0[e], act);
             f[4 + e] = hv_act(f[4 + e] * s1[e] + t1[e], act);
         }
-        hv_st16(Y + row * ldy + cv * 8, hv_pack8(f));
+        return hv_pack8(f);
+    };
+    int r = blockIdx.x * rb + r0;
+    for (; r + 3 * step < rows_per_image; r += 4 * step) {
+        u32x4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = hv_ld16(src + (row0 + r + u * step) * lds);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) hv_st16(Y + (row0 + r + u * step) * ldy + cv * 8, apply(v[u]));
     }
+    for (; r < rows_per_image; r += step) hv_st16(Y + (row0 + r) * ldy + cv * 8, apply(hv_ld16(src + (row0 + r) * lds)));
 }
 
 static inline void hv_affine_apply_launch(const bf16_t* X, long ldx, int rows, int rows_per_image, int C, const bf16_t* X2, long ldx2,
                                           int C2, const float* scale, const float* shift, int act, bf16_t* Y, long ldy,
                                           hipStream_t stream) {
-    const long total = (long)rows * ((C + C2) / 8);
-    long blocks = (total + 255) / 256;
-    if (blocks > 256 * 16) blocks = 256 * 16;
+    const int cvs = (C + C2) / 8;                       // <= 320 (checked by the callers: C + C2 <= 2560)
+    const int rb = cvs >= 160 ? 1 : (cvs > 64 ? 2 : (256 / cvs));
+    const int n_images = rows / rows_per_image;
+    long gx = ((long)rows_per_image + 4 * rb - 1) / (4 * rb);  // ~ four rows per thread
+    const long cap = (256L * 12 + n_images - 1) / n_images;     // ~ 12 blocks per CU over the whole grid
+    if (gx > cap) gx = cap;
+    if (gx < 1) gx = 1;
     hv_note("hv_affine_apply_kernel | rows=%d C=%d C2=%d act=%d", rows, C, C2, act);
-    hv_launch(hv_affine_apply_kernel, dim3((unsigned)blocks), dim3(256), stream, X, ldx, rows, rows_per_image, C, X2, ldx2, C2, scale,
-              shift, act, Y, ldy);
+    hv_launch(hv_affine_apply_kernel, dim3((unsigned)gx, (unsigned)n_images), dim3((unsigned)((cvs * rb + 63) / 64 * 64)), stream, X, ldx,
+              rows_per_image, C, X2, ldx2, C2, scale, shift, act, Y, ldy, cvs, rb);
 }

@@ -116,6 +116,8 @@ def test_affine_apply(cx):
     kc.case_affine_apply(cx, n_img=3, rows=50, C=64)
     kc.case_affine_apply(cx, n_img=2, rows=33, C=320, act=A.ACT_SILU, seed=41)
     kc.case_affine_apply_cat(cx, n_img=3, rows=50, C1=64, C2=32)
+    kc.case_affine_apply_cat(cx, n_img=2, rows=21, C1=1280, C2=1280, seed=44)  # 320 slots per row: one row per 320-thread block
+    kc.case_affine_apply(cx, n_img=2, rows=70, C=960, seed=45)                  # 120 slots: two rows side by side, 4-row unroll + tail
 
 
 def test_gemm_grouped_tile_raster(cx):
@@ -254,6 +256,19 @@ def test_conv_register_staged_variant(cx):
         kc.case_conv(cx, n=1, H=12, W=8, C1=32, C2=32, Cout=36, pro=True)
     finally:
         cx.lib.call("hv_set_tuning", 4, 1)
+
+
+def test_conv_patch_major_raster(cx):
+    """workgroup raster 1 (tuning key 9): the pixel patches of one output-channel tile adjacent instead of the channel tiles
+    of one patch -- several channel tiles x several patches x several images, all three modes, with the fused statistics"""
+    cx.lib.call("hv_set_tuning", 9, 1)
+    try:
+        kc.case_conv(cx, n=2, H=20, W=24, C1=32, Cout=260, mode=A.CONV_S1, seed=91)
+        kc.case_conv(cx, n=2, H=9, W=10, C1=32, C2=32, Cout=132, mode=A.CONV_UP2, seed=92)
+        kc.case_conv(cx, n=1, H=17, W=18, C1=64, Cout=136, mode=A.CONV_S2, seed=93)
+        kc.case_gn_parts_conv(cx, n=2, H=16, W=16, Cin=32, Cout=320)
+    finally:
+        cx.lib.call("hv_set_tuning", 9, 0)
 
 
 def test_conv_two_source_narrow(cx):

@@ -1288,8 +1288,10 @@ HV_DEV void hv_gemm_epilogue_wide(const HvGemmParams& p, f32x4 (&acc)[5][4][2], 
 //   slot (s+1) % 2), issue k-tile s+1, multiply from slot s % 2.  The DMA goes out from inline asm (hv_glds16_s): hipcc
 //   does not see it and puts no vmcnt(0) in front of the fragment reads.
 //   Same swizzles, permuted channel assignment and epilogues (per 64-column block, NMF = 2) as hv_gemm_glds_kernel.
+template <int BN>  // (a template also keeps the kernel out of the translation units that include this header for its helpers)
 __global__ __launch_bounds__(512, 2) void hv_gemm_wide_kernel(HvGemmParams p, int form, int stagger) {
-    constexpr int BM = 256, BN = 320, BK = 64, NS = 2, NW = 8, NB = BN / 64, NMF = 2;
+    static_assert(BN == 320, "five 64-column blocks per wave");
+    constexpr int BM = 256, BK = 64, NS = 2, NW = 8, NB = BN / 64, NMF = 2;
     constexpr int XT = BM * BK * 2, WT = BN * BK * 2, SLOT = XT + WT;
     constexpr int RPI = 8, CPR = 8, RPB = 2;  // rows per 1 KiB wave-instruction, 16-byte chunks per row, rows per bank row
     constexpr int XQ = BM / RPI / NW, WQ = BN / RPI / NW;  // 4 + 5 DMA instructions per wave and k-tile
@@ -1548,7 +1550,7 @@ static inline int hv_gemm_launch(const HvGemmParams& p, hipStream_t stream) {
         if (grid > g_hv_gemm_max_grid) grid = g_hv_gemm_max_grid;
         hv_note("hv_gemm_wide_kernel | %s", shape);
         const int stg = hv_gemm_stagger_arg((p.K / 64) * 3000 + 8000, tw / grid);
-        hv_launch(hv_gemm_wide_kernel, dim3(grid), dim3(512), stream, p, c.form, stg);
+        hv_launch(hv_gemm_wide_kernel<320>, dim3(grid), dim3(512), stream, p, c.form, stg);
         return 0;
     }
     if (c.kernel == 2) {

@@ -123,7 +123,7 @@ int hv_attention_fp8(const hv_attention_params* p, const float* kscale, const fl
 
 static int g_hv_cmdlist_graphs = 1;  // hv_set_tuning(HV_TUNE_CMDLIST_GRAPHS): 0 = hv_cmdlist_run re-issues the closures on every run (A/B)
 int hv_set_tuning(int key, int value) {
-    if (key == HV_TUNE_ATTN_D40 && (value >= 0 && value <= 2)) hvk_attention_tune(40, value);
+    if (key == HV_TUNE_ATTN_D40 && (value == 0 || value == 2)) hvk_attention_tune(40, value);
     else if (key == HV_TUNE_ATTN_QT_D160 && (value == 1 || value == 2)) hvk_attention_tune(160, value);
     else if (key == HV_TUNE_GEMM_MAX_GRID && value >= 8 && value % 8 == 0) hvk_gemm_tune(value);
     else if (key == HV_TUNE_GEMM_GLDS && ((value >= 0 && value <= 3) || value == 6)) hvk_gemm_use_glds(value);

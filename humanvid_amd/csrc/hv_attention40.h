@@ -72,7 +72,7 @@ struct HvAttn40Geom {
 };
 
 template <bool MASK>
-__global__ __launch_bounds__(512, 4) void hv_attention40_kernel(hv_attention_params p, int head_major) {
+__global__ __launch_bounds__(512, 4) void hv_attention40_kernel(hv_attention_params p) {
     using G = HvAttn40Geom;
     constexpr int D = G::D;
     __shared__ __attribute__((aligned(16))) unsigned char smem[2 * (G::KBYTES + G::VBYTES)];
@@ -92,19 +92,13 @@ __global__ __launch_bounds__(512, 4) void hv_attention40_kernel(hv_attention_par
     const int cpx = gridDim.x / 8;
     int t = (blockIdx.x % 8) * cpx + blockIdx.x / 8;  // XCD x walks the contiguous range [x cpx, (x + 1) cpx)
     if (t >= total) return;
-    int qb, head;
-    if (head_major) {  // the 8 heads of a query block run next to each other: their 80-byte output pieces fill whole lines in L2
-        head = t % p.heads;
-        t /= p.heads;
-        qb = t % nqb;
-        t /= nqb;
-    } else {  // the query blocks of an (image, head) run next to each other: its K / V^T stream through L2 once
-        qb = t % nqb;
-        t /= nqb;
-        head = t % p.heads;
-        t /= p.heads;
-    }
-    int img = t;
+    // the query blocks of an (image, head) run next to each other: its K / V^T stream through L2 once.  (The other raster --
+    // the 8 heads of a query block adjacent, so that their 80-byte output pieces fill whole lines in L2 -- measured 2 % slower
+    // on MI355X, profiles/r04_s1.txt: this kernel moves 0.45 TB/s, it is not bound by its HBM bytes.)
+    const int qb = t % nqb;
+    t /= nqb;
+    const int head = t % p.heads;
+    int img = t / p.heads;
     // alternate between the CFG halves (the conditional images attend to twice the keys): every XCD gets the same mix
     if ((p.n_images & 1) == 0) img = (img & 1) * (p.n_images >> 1) + (img >> 1);
     const int sel = (p.bank_sel != nullptr && p.L2 > 0) ? p.bank_sel[img] : -1;
@@ -342,16 +336,16 @@ __global__ __launch_bounds__(512, 4) void hv_attention40_kernel(hv_attention_par
     }
 }
 
-// tuning knobs (hv_set_tuning): 1 = this kernel for head dim 40 (default), 0 = the generic kernel; workgroup raster
-static int g_hv_attn40 = 1, g_hv_attn40_head_major = 0;
+// tuning knob (hv_set_tuning): 1 = this kernel for head dim 40 (default), 0 = the generic kernel
+static int g_hv_attn40 = 1;
 
 static inline void hv_attention40_launch(const hv_attention_params& p, hipStream_t stream) {
     using G = HvAttn40Geom;
     const int total = ((p.Lq + G::BQ - 1) / G::BQ) * p.heads * p.n_images;
     const int grid = ((total + 7) / 8) * 8;
     const bool ragged = (p.L1 % 64) != 0 || (p.L2 % 64) != 0;
-    hv_note("hv_attention40_kernel<%s> | n=%d heads=%d D=%d Lq=%d L1=%d L2=%d bank=%d", g_hv_attn40_head_major ? "hm" : "qm",
-            p.n_images, p.heads, p.D, p.Lq, p.L1, p.L2, p.bank_sel != nullptr && p.L2 > 0);
-    if (ragged) hv_launch(hv_attention40_kernel<true>, dim3(grid), dim3(512), stream, p, g_hv_attn40_head_major);
-    else hv_launch(hv_attention40_kernel<false>, dim3(grid), dim3(512), stream, p, g_hv_attn40_head_major);
+    hv_note("hv_attention40_kernel | n=%d heads=%d D=%d Lq=%d L1=%d L2=%d bank=%d", p.n_images, p.heads, p.D, p.Lq, p.L1, p.L2,
+            p.bank_sel != nullptr && p.L2 > 0);
+    if (ragged) hv_launch(hv_attention40_kernel<true>, dim3(grid), dim3(512), stream, p);
+    else hv_launch(hv_attention40_kernel<false>, dim3(grid), dim3(512), stream, p);
 }

@@ -94,30 +94,8 @@ HV_DEV u32x4 hv_ld16(const void* p) { return *reinterpret_cast<const u32x4*>(p);
 HV_DEV void hv_st16(void* p, u32x4 v) { *reinterpret_cast<u32x4*>(p) = v; }
 HV_DEV u32x2 hv_ld8(const void* p) { return *reinterpret_cast<const u32x2*>(p); }
 HV_DEV void hv_st8(void* p, u32x2 v) { *reinterpret_cast<u32x2*>(p) = v; }
-// 8-byte streaming store for kernel OUTPUTS: a relaxed agent-scope atomic store lowers to
-// `global_store_dwordx2 ... sc1` (write-through, the line is not retained in the XCD's L2), so the
-// hundreds of MB an epilogue writes do not evict the operand panels the other workgroups re-read.
-#ifndef HV_STORE_SC1
-#define HV_STORE_SC1 0
-#endif
-#ifndef HV_STORE_NT
-#define HV_STORE_NT 0
-#endif
-HV_DEV void hv_st8_stream(void* p, u32x2 v) {
-#if !defined(HV_EMU) && HV_STORE_NT
-    // non-temporal hint (global_store_dwordx2 ... nt): the output tile is not read again by this kernel
-    __builtin_nontemporal_store(v, reinterpret_cast<u32x2*>(p));
-#elif !defined(HV_EMU) && HV_STORE_SC1
-    union {
-        u32x2 v;
-        unsigned long long u;
-    } c;
-    c.v = v;
-    __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), c.u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#else
-    *reinterpret_cast<u32x2*>(p) = v;
-#endif
-}
+// (the write-through / non-temporal forms of the output stores measured no gain in rounds 1-2 and are gone)
+HV_DEV void hv_st8_stream(void* p, u32x2 v) { *reinterpret_cast<u32x2*>(p) = v; }
 
 HV_DEV bf16x8 hv_as_bf16x8(u32x4 v) {
     union {

@@ -98,19 +98,7 @@ __device__ unsigned long long g_hv_trace[8192];
 #define HV_TRACE_ARG
 #define HV_TRACE(id)
 #endif
-#ifndef HV_GEMM_DEFER
-// 1: tiles whose epilogue has one of the hot forms run hv_gemm_epilogue_fast (below); 0 = the round-1 epilogue, for A/Bs.
-#define HV_GEMM_DEFER 1
-#endif
-#ifndef HV_GEMM_EPI_SB
-#define HV_GEMM_EPI_SB 1
-#endif
-#ifndef HV_GEMM_EPI_G
-#define HV_GEMM_EPI_G 2
-#endif
-#ifndef HV_GEMM_DBG
-#define HV_GEMM_DBG 0  // experiment mask: 1 no epilogue, 2 no epilogue stores, 4 no ds_reads, 8 no LDS-DMA, 16 X from L2
-#endif
+constexpr int HV_GEMM_EPI_G = 2;  // row fragments per load group of the fast epilogues (the register budget of the 256 x 256 kernel)
 
 // ---- epilogue of one wave's (16*NMF) x 64 sub-tile: lane owns token m (column of the MFMA tile) and 4
 //      consecutive channels n; m_base / n_base are the sub-tile origin.
@@ -222,9 +210,6 @@ HV_DEV void hv_gemm_epilogue_t(const HvGemmParams& p, f32x4 (&acc)[4][NMF], int 
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[r] = hv_act(v[r], out_act);
             }
-#if HV_GEMM_DBG & 2
-            if (v[0] != 1.2345f) continue;
-#endif
             if (!valid) continue;
             if (has_t && n >= p.n_split) {
                 bf16_t* yt = p.Yt + (long)(n - p.n_split) * p.ldyt + m;
@@ -247,7 +232,7 @@ HV_DEV void hv_gemm_epilogue_t(const HvGemmParams& p, f32x4 (&acc)[4][NMF], int 
 }
 
 // ---- fast epilogue for the hot output forms (round 2).  What was wrong with the one above, measured with gemm_trace and the
-// -DHV_GEMM_DBG builds: it costs ~20 000 cycles per K = 320 tile against ~24 000 for the tile's ten k-steps, and 0.18 of the
+// timing-only builds: it costs ~20 000 cycles per K = 320 tile against ~24 000 for the tile's ten k-steps, and 0.18 of the
 // 0.47 ms of the level-0 QKV GEMM remain when its stores are compiled out.  The stores of row fragment mf sit in front of the
 // loads of fragment mf+1; hipcc may not hoist those loads (Y can alias the residual -- the residual stream IS updated in
 // place), and with LDS-DMA in flight every wait for them is a vmcnt(0), which on gfx9 also waits for the just-issued stores
@@ -314,7 +299,7 @@ HV_DEV void hv_gemm_epilogue_fast(const HvGemmParams& p, f32x4 (&acc)[4][NMF], i
                     res2[j][nf] = hv_ld8(reinterpret_cast<const char*>(p.residual) + (ro + 2u * (unsigned)nc[nf]));
             }
         }
-#if !defined(HV_EMU) && HV_GEMM_EPI_SB
+#if !defined(HV_EMU)
         __builtin_amdgcn_sched_barrier(0);  // the group's loads stay together, ahead of its arithmetic
 #endif
         if (g == 0) HV_TRACE(7);
@@ -344,7 +329,7 @@ HV_DEV void hv_gemm_epilogue_fast(const HvGemmParams& p, f32x4 (&acc)[4][NMF], i
                 }
             }
         }
-#if !defined(HV_EMU) && HV_GEMM_EPI_SB
+#if !defined(HV_EMU)
         __builtin_amdgcn_sched_barrier(0);  // ... and the next group's loads are not hoisted over it (register budget)
 #endif
     }
@@ -363,9 +348,6 @@ HV_DEV void hv_gemm_epilogue_fast(const HvGemmParams& p, f32x4 (&acc)[4][NMF], i
     // LDS-DMA of the next k-tiles follow): vmcnt(0), lgkmcnt / expcnt untouched.  No store has been issued yet, so this
     // waits for loads only.
     __builtin_amdgcn_s_waitcnt(0x0F70);
-#endif
-#if HV_GEMM_DBG & 2
-    if (acc[0][0][0] != 1.2345f) return;
 #endif
     char* const yb = reinterpret_cast<char*>(p.Y);
     char* const ytb = reinterpret_cast<char*>(p.Yt);
@@ -480,7 +462,7 @@ HV_DEV void hv_gemm_epilogue_fast_perm(const HvGemmParams& p, f32x4 (&acc)[4][NM
                     res4[j][h] = hv_ld16(reinterpret_cast<const char*>(p.residual) + (ro + 2u * (unsigned)nc[h]));
             }
         }
-#if !defined(HV_EMU) && HV_GEMM_EPI_SB
+#if !defined(HV_EMU)
         __builtin_amdgcn_sched_barrier(0);  // the group's loads stay together, ahead of its arithmetic
 #endif
         if (g == 0) HV_TRACE(7);
@@ -516,7 +498,7 @@ HV_DEV void hv_gemm_epilogue_fast_perm(const HvGemmParams& p, f32x4 (&acc)[4][NM
                 outp[mf][h] = o;
             }
         }
-#if !defined(HV_EMU) && HV_GEMM_EPI_SB
+#if !defined(HV_EMU)
         __builtin_amdgcn_sched_barrier(0);  // ... and the next group's loads are not hoisted over it (register budget)
 #endif
     }
@@ -616,7 +598,7 @@ HV_DEV void hv_gemm_epilogue_fast_perm_geglu(const HvGemmParams& p, f32x4 (&acc)
             mean[j] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(p.row_mean) + 4u * (unsigned)mc);
             rstd[j] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(p.row_rstd) + 4u * (unsigned)mc);
         }
-#if !defined(HV_EMU) && HV_GEMM_EPI_SB
+#if !defined(HV_EMU)
         __builtin_amdgcn_sched_barrier(0);
 #endif
         if (g == 0) HV_TRACE(7);
@@ -634,7 +616,7 @@ HV_DEV void hv_gemm_epilogue_fast_perm_geglu(const HvGemmParams& p, f32x4 (&acc)
             }
             outp[mf] = o;
         }
-#if !defined(HV_EMU) && HV_GEMM_EPI_SB
+#if !defined(HV_EMU)
         __builtin_amdgcn_sched_barrier(0);
 #endif
     }
@@ -674,7 +656,6 @@ HV_DEV void hv_gemm_epilogue(const HvGemmParams& p, f32x4 (&acc)[4][NMF], int m_
 enum { HV_FORM_NONE = -1, HV_FORM_LN = 0, HV_FORM_LN_YT = 1, HV_FORM_LN_GEGLU = 2, HV_FORM_RES = 3, HV_FORM_PLAIN = 4 };
 
 static inline int hv_gemm_fast_form(const HvGemmParams& p, int rows_per_wave) {
-    if (!HV_GEMM_DEFER) return HV_FORM_PLAIN;  // A/B build: the kernel uses the general epilogue, every form is accepted
     if (p.out_act != HV_ACT_NONE || p.out_f32 || p.perm_p != 0) return HV_FORM_NONE;
     if (p.pe != nullptr && p.rowvec != nullptr) return HV_FORM_NONE;
     // one table row per wave sub-tile: sub-tiles start at multiples of rows_per_wave
@@ -690,9 +671,6 @@ static inline int hv_gemm_fast_form(const HvGemmParams& p, int rows_per_wave) {
 template <int NMF, bool PERM = false, int STATS = 0>
 HV_DEV void hv_gemm_epilogue_form(int form, const HvGemmParams& p, f32x4 (&acc)[4][NMF], int m_base, int n_base, int r16,
                                   int quad HV_TRACE_PARAM) {
-#if !HV_GEMM_DEFER
-    hv_gemm_epilogue<NMF>(p, acc, m_base, n_base, r16, quad HV_TRACE_ARG);
-#else
 #ifndef HV_EMU
     const int m_first = __builtin_amdgcn_readfirstlane(min(m_base, p.M - 1));  // wave-uniform: the table row is a scalar base
 #else
@@ -717,7 +695,6 @@ HV_DEV void hv_gemm_epilogue_form(int form, const HvGemmParams& p, f32x4 (&acc)[
         case HV_FORM_RES: hv_gemm_epilogue_fast<NMF, false, true, 0>(p, acc, m_base, n_base, r16, quad, tab HV_TRACE_ARG); break;
         default: hv_gemm_epilogue_fast<NMF, false, false, 0>(p, acc, m_base, n_base, r16, quad, tab HV_TRACE_ARG); break;
     }
-#endif
 }
 
 template <int Q>
@@ -930,7 +907,7 @@ __global__ __launch_bounds__(NW * 64, 2) void hv_gemm_glds_kernel(HvGemmParams p
     constexpr int CPR = BK / 8, RPB = 16 / CPR;  // 16-byte chunks per row, rows per 256-byte bank row
     constexpr int XQ = BM / RPI / NW, WQ = BN / RPI / NW;  // DMA instructions per wave and k-tile
     static_assert(PH == 1 || PH == 2, "issue cadence");
-    static_assert(XQ == 4 && WQ == 4 && WAVES_M == 2 && NMF % 2 == 0 && HV_GEMM_DEFER,
+    static_assert(XQ == 4 && WQ == 4 && WAVES_M == 2 && NMF % 2 == 0,
                   "the two-group k-loop is written for the 256 x 256 x 64 tile on 8 waves and the 128 x 128 x 64 tile on 4");
     __shared__ __attribute__((aligned(16))) unsigned char smem[NS * SLOT];
 
@@ -1176,7 +1153,6 @@ __global__ __launch_bounds__(NW * 64, 2) void hv_gemm_glds_kernel(HvGemmParams p
         HV_TRACE(5);
         if (++c_k == nk) {
             c_k = 0;
-            if (!(HV_GEMM_DBG & 1) || acc[0][0][0] == 1.2345f)
             {
                 int m0, n0;
                 tile_origin(c_tile, m0, n0);

@@ -37,33 +37,6 @@ def import_filename(filename):
     return module
 
 
-def save_checkpoint(model, save_dir, prefix, ckpt_num, total_limit=None, logger=None):
-    """<save_dir>/<prefix>-<ckpt_num>.pth, keeping at most `total_limit` files of that prefix (oldest removed first);
-    prefix "motion_module" stores only the motion-module tensors (/root/reference/src/utils/util.py:17-44)."""
-    if total_limit is not None:
-        old = sorted((d for d in os.listdir(save_dir) if d.startswith(prefix)),
-                     key=lambda name: int(name.split("-")[1].split(".")[0]))
-        drop = old[:max(0, len(old) - total_limit + 1)]
-        if drop and logger is not None:
-            logger.info(f"{len(old)} checkpoints already exist, removing {len(drop)} checkpoints")
-            logger.info(f"removing checkpoints: {', '.join(drop)}")
-        for name in drop:
-            os.remove(osp.join(save_dir, name))
-    sd = model.state_dict()
-    if prefix == "motion_module":
-        sd = type(sd)((k, v) for k, v in sd.items() if "motion_module" in k)
-    torch.save(sd, osp.join(save_dir, f"{prefix}-{ckpt_num}.pth"))
-
-
-def delete_additional_ckpt(base_path, num_keep):
-    """keep the `num_keep` newest checkpoint-<step> directories under base_path"""
-    steps = sorted(int(d.split("-")[-1]) for d in os.listdir(base_path) if d.startswith("checkpoint-"))
-    for s in steps[:max(0, len(steps) - num_keep)]:
-        path = osp.join(base_path, f"checkpoint-{s}")
-        if osp.exists(path):
-            shutil.rmtree(path)
-
-
 def _av():
     try:
         import av  # noqa: PLC0415
@@ -139,16 +112,6 @@ def save_image_grid(images: torch.Tensor, path: str, n_rows=6):
     x = make_grid(images, nrow=n_rows).permute(1, 2, 0)
     os.makedirs(os.path.dirname(path) or ".", exist_ok=True)
     Image.fromarray((x * 255).numpy().astype(np.uint8)).save(path)
-
-
-def show_image_grid(images: torch.Tensor, n_rows=6):
-    """interactive preview of an image grid (needs matplotlib, imported lazily; /root/reference/src/utils/util.py:165-172)"""
-    import matplotlib.pyplot as plt  # noqa: PLC0415
-
-    x = make_grid(images, nrow=n_rows).permute(1, 2, 0)
-    plt.imshow(Image.fromarray((x * 255).numpy().astype(np.uint8)))
-    plt.axis("off")
-    plt.show()
 
 
 def read_frames(video_path):

@@ -217,7 +217,7 @@ int hv_attention_fp8(const hv_attention_params* p, const float* kscale, const fl
                      const float* vamax2, void* stream);
 
 /* kernel-variant selection for A/B measurements (process-global; not needed for correctness) */
-#define HV_TUNE_ATTN_D40 0     /* head dim 40: 0 (default) = the dedicated 8-wave kernel (32x32x16 QK^T, 256 queries per workgroup), query-major workgroup raster; 1 = the same with the 8 heads of a query block adjacent (A/B); 2 = the generic kernel (A/B) */
+#define HV_TUNE_ATTN_D40 0     /* head dim 40: 0 (default) = the dedicated 8-wave kernel (hv_attention40.h: 32x32x16 QK^T, 256 queries per workgroup); 2 = the generic kernel (A/B) */
 #define HV_TUNE_ATTN_QT_D160 1 /* for head dim 160: 1 or 2 (default 2) */
 #define HV_TUNE_GEMM_MAX_GRID 2 /* persistent GEMM workgroups (multiple of 8, default 512) */
 #define HV_TUNE_GEMM_GLDS 3     /* GEMM kernel selection: 1 = default -- LDS-DMA kernels: 256x320x64 wide tiles for N = 320, K >= 640, M % 256 == 0 (plain-output forms); otherwise 256x256x64 tiles (one 8-wave workgroup per CU) when N >= 960 and the tiles fill the last round over the 256 CUs to >= 90 %, 128x128x64 (two 4-wave workgroups per CU) otherwise; 2 = 256x256x64 wherever the shape allows, 3 = 128x128x64 everywhere, 0 = register-staged kernel (A/Bs; results are bit-identical across 0 / 2 / 3 / 6); 6 = no wide tiles (the round-3 default) */

@@ -146,10 +146,10 @@ def test_config5_shape_attention(cx, D, L, fp8):
 
 
 def test_attention_variants(cx):
-    """head dim 40: the generic kernel (tuning value 2) and the dedicated kernel's head-major raster (1) compute the same
-    function as the default (0); head dim 160: one query fragment per wave"""
+    """head dim 40: the generic kernel (tuning value 2) computes the same function as the dedicated one (0); head dim 160:
+    one query fragment per wave"""
     try:
-        for v in (2, 1, 0):
+        for v in (2, 0):
             cx.lib.call("hv_set_tuning", 0, v)
             kc.case_attention(cx, D=40, n_img=4, Lq=520, Lb=264)
             kc.case_attention(cx, D=40, n_img=4, Lq=1536, Lb=1536, spike=True, seed=73, check=(0, 3), q_stride=4)

@@ -153,7 +153,7 @@ def main():
             sel = torch.tensor([-1] * (n // 2) + [1] * (n - n // 2), dtype=torch.int32, device=dev)
             variants = [None]
             if D == 40:
-                variants = [2, 1, 0]  # generic kernel, hv_attention40 head-major raster, hv_attention40 (default)
+                variants = [2, 0]  # generic kernel, hv_attention40 (default)
             if D == 160:
                 variants = [2, 1]
             for var in variants:

@@ -710,24 +710,10 @@ struct HvInt {
     static constexpr int value = N;
 };
 
-// Phase stagger of the persistent workgroups (hv_set_tuning key HV_TUNE_GEMM_STAGGER; round 4).  All workgroups of a launch
-// start together and walk tiles of identical cost, so every CU reaches its epilogue at the same moment: the phase timeline
-// (profiles/r03_gemm_trace.txt) shows 5500-7400 of a K = 320 tile's ~32 000 cycles as "store issue" -- eight store
-// instructions per wave that wait because 256 CUs x 64 KB hit the memory system at once (16 MB: ~3 us at the HBM write rate),
-// while the k-loops in between leave it idle.  Delaying the workgroups of an XCD by (index mod phases) x a fraction of a tile
-// once, at the start, spreads the bursts; the order of tiles and every result are unchanged.
-// stagger = phases << 8 | s_sleep(127) units (8128 cycles each) per phase step; 0 = off.
-HV_DEV void hv_gemm_stagger(int stagger) {
-#ifndef HV_EMU
-    if (stagger == 0) return;
-    const int phases = stagger >> 8, unit = stagger & 255;
-    const int n = ((int)(blockIdx.x >> 3) % phases) * unit;
-    for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(127);
-#else
-    (void)stagger;
-#endif
-}
-
+// (Round 4, measured and removed: starting the workgroups of an XCD a fraction of a tile apart -- 2 / 4 / 8 phase groups -- so that
+//  the CUs' epilogue store bursts do not coincide.  Same-box A/B, profiles/r04_s2.txt: every GEMM shape of the step within
+//  -3 % .. +12 % of the unstaggered time, the step 109.4 -> 110.2 / 110.5 / 111.9 ms: the "store issue" share of a tile
+//  (profiles/r03_gemm_trace.txt) is not a burst effect.)
 // Persistent workgroups: each walks a strided list of output tiles of its XCD's contiguous tile
 // range; the (tile, k-step) sequence is flattened so that the register prefetch (two k-tiles in
 // flight per workgroup) runs across tile boundaries and the epilogue of tile i overlaps the loads
@@ -898,7 +884,7 @@ __global__ __launch_bounds__(256, 2) void hv_gemm_kernel(HvGemmParams p) {
 //   STATS (with PERM): the plain / residual epilogue also leaves GroupNorm (1, p.gn_part) or LayerNorm (2, p.ln_part) partial
 //   statistics of its tile.
 template <int BN, int NW, int BM, int PH, bool PERM = false, int STATS = 0>
-__global__ __launch_bounds__(NW * 64, 2) void hv_gemm_glds_kernel(HvGemmParams p, int gm, int form, int stagger) {
+__global__ __launch_bounds__(NW * 64, 2) void hv_gemm_glds_kernel(HvGemmParams p, int gm, int form) {
     constexpr int BK = 64, NS = 2;
     constexpr int WAVES_N = BN / 64, WAVES_M = NW / WAVES_N;
     constexpr int WTM = BM / WAVES_M, NMF = WTM / 16;
@@ -949,7 +935,6 @@ __global__ __launch_bounds__(NW * 64, 2) void hv_gemm_glds_kernel(HvGemmParams p
     const int first = t_begin + wg;
     const int tstep = wg_per_xcd;
     if (first >= t_end) return;
-    hv_gemm_stagger(stagger);
     const int my_tiles = (t_end - first + wg_per_xcd - 1) / wg_per_xcd;
     const int nk = p.K / BK;
     const int nsteps = my_tiles * nk;
@@ -1265,7 +1250,7 @@ HV_DEV void hv_gemm_epilogue_wide(const HvGemmParams& p, f32x4 (&acc)[5][4][2], 
 //   does not see it and puts no vmcnt(0) in front of the fragment reads.
 //   Same swizzles, permuted channel assignment and epilogues (per 64-column block, NMF = 2) as hv_gemm_glds_kernel.
 template <int BN>  // (a template also keeps the kernel out of the translation units that include this header for its helpers)
-__global__ __launch_bounds__(512, 2) void hv_gemm_wide_kernel(HvGemmParams p, int form, int stagger) {
+__global__ __launch_bounds__(512, 2) void hv_gemm_wide_kernel(HvGemmParams p, int form) {
     static_assert(BN == 320, "five 64-column blocks per wave");
     constexpr int BM = 256, BK = 64, NS = 2, NW = 8, NB = BN / 64, NMF = 2;
     constexpr int XT = BM * BK * 2, WT = BN * BK * 2, SLOT = XT + WT;
@@ -1287,7 +1272,6 @@ __global__ __launch_bounds__(512, 2) void hv_gemm_wide_kernel(HvGemmParams p, in
     const int t_begin = xcd * per_xcd, t_end = min(total, t_begin + per_xcd);
     const int first = t_begin + wg;
     if (first >= t_end) return;
-    hv_gemm_stagger(stagger);
     const int my_tiles = (t_end - first + wg_per_xcd - 1) / wg_per_xcd;
     const int nk = p.K / BK, nsteps = my_tiles * nk;
 
@@ -1401,7 +1385,6 @@ static int g_hv_gemm_max_grid = 512;  // tuning knob (hv_set_tuning): persistent
 //   0: the register-staged kernel for everything (A/Bs; also what problems outside the fast epilogue forms run on)
 //   6: as 1 without the wide tiles (the round-3 default; A/B)
 static int g_hv_gemm_glds = 1;
-static int g_hv_gemm_stagger = 0;  // tuning knob (hv_set_tuning key 8): phase groups of the persistent workgroups (0 = off, 2, 4, 8)
 static int g_hv_gemm_perm = 1;  // tuning knob (hv_set_tuning key 6): 16-byte epilogue through the permuted channel assignment (A/B)
 
 // Which kernel hv_gemm_launch takes for a problem: 0 register-staged, 1 = 256x256x64, 2 = 128x128x64 (LDS-DMA); perm = the
@@ -1477,16 +1460,6 @@ static inline int hv_gemm_ln_parts_of(const HvGemmParams& p) {
     return p.N / 64;
 }
 
-// stagger argument of a launch: `tile_cycles` = rough duration of one tile (k-steps x cycles per k-step + epilogue), `tiles_per_wg`
-// how many tiles a workgroup walks (short walks are not staggered: the delay would not be amortised)
-static inline int hv_gemm_stagger_arg(int tile_cycles, int tiles_per_wg) {
-    if (g_hv_gemm_stagger <= 1 || tiles_per_wg < 4) return 0;
-    int unit = (tile_cycles / g_hv_gemm_stagger + 4064) / 8128;
-    if (unit < 1) unit = 1;
-    if (unit > 255) unit = 255;
-    return (g_hv_gemm_stagger << 8) | unit;
-}
-
 static inline int hv_gemm_launch(const HvGemmParams& p, hipStream_t stream) {
     if (p.M <= 0 || p.N <= 0 || p.K <= 0) return -1;
     if (p.K % 64 != 0 || p.N % 4 != 0) return -1;
@@ -1509,13 +1482,12 @@ static inline int hv_gemm_launch(const HvGemmParams& p, hipStream_t stream) {
         int grid = ((t256 + 7) / 8) * 8;
         if (grid > 256) grid = 256;
         if (grid > g_hv_gemm_max_grid) grid = g_hv_gemm_max_grid;
-        const int stg = hv_gemm_stagger_arg((p.K / 64) * 4500 + 9000, t256 / grid);
         if (c.perm) {
             hv_note("hv_gemm_glds_kernel<256,8,256,1,perm> | %s", shape);
-            hv_launch(hv_gemm_glds_kernel<256, 8, 256, 1, true>, dim3(grid), dim3(512), stream, p, c.gm, c.form, stg);
+            hv_launch(hv_gemm_glds_kernel<256, 8, 256, 1, true>, dim3(grid), dim3(512), stream, p, c.gm, c.form);
         } else {
             hv_note("hv_gemm_glds_kernel<256,8,256,1> | %s", shape);
-            hv_launch(hv_gemm_glds_kernel<256, 8, 256, 1, false>, dim3(grid), dim3(512), stream, p, c.gm, c.form, stg);
+            hv_launch(hv_gemm_glds_kernel<256, 8, 256, 1, false>, dim3(grid), dim3(512), stream, p, c.gm, c.form);
         }
         return 0;
     }
@@ -1525,8 +1497,7 @@ static inline int hv_gemm_launch(const HvGemmParams& p, hipStream_t stream) {
         if (grid > 256) grid = 256;
         if (grid > g_hv_gemm_max_grid) grid = g_hv_gemm_max_grid;
         hv_note("hv_gemm_wide_kernel | %s", shape);
-        const int stg = hv_gemm_stagger_arg((p.K / 64) * 3000 + 8000, tw / grid);
-        hv_launch(hv_gemm_wide_kernel<320>, dim3(grid), dim3(512), stream, p, c.form, stg);
+        hv_launch(hv_gemm_wide_kernel<320>, dim3(grid), dim3(512), stream, p, c.form);
         return 0;
     }
     if (c.kernel == 2) {
@@ -1534,19 +1505,18 @@ static inline int hv_gemm_launch(const HvGemmParams& p, hipStream_t stream) {
         int grid6 = ((tiles6 + 7) / 8) * 8;
         if (grid6 > 512) grid6 = 512;
         if (grid6 > g_hv_gemm_max_grid) grid6 = g_hv_gemm_max_grid;
-        const int stg = hv_gemm_stagger_arg((p.K / 64) * 2800 + 7700, tiles6 / grid6);
         if (c.perm && p.gn_part != nullptr) {
             hv_note("hv_gemm_glds_kernel<128,4,128,2,perm,gn> | %s", shape);
-            hv_launch(hv_gemm_glds_kernel<128, 4, 128, 2, true, 1>, dim3(grid6), dim3(256), stream, p, c.gm, c.form, stg);
+            hv_launch(hv_gemm_glds_kernel<128, 4, 128, 2, true, 1>, dim3(grid6), dim3(256), stream, p, c.gm, c.form);
         } else if (c.perm && p.ln_part != nullptr) {
             hv_note("hv_gemm_glds_kernel<128,4,128,2,perm,ln> | %s", shape);
-            hv_launch(hv_gemm_glds_kernel<128, 4, 128, 2, true, 2>, dim3(grid6), dim3(256), stream, p, c.gm, c.form, stg);
+            hv_launch(hv_gemm_glds_kernel<128, 4, 128, 2, true, 2>, dim3(grid6), dim3(256), stream, p, c.gm, c.form);
         } else if (c.perm) {
             hv_note("hv_gemm_glds_kernel<128,4,128,2,perm> | %s", shape);
-            hv_launch(hv_gemm_glds_kernel<128, 4, 128, 2, true>, dim3(grid6), dim3(256), stream, p, c.gm, c.form, stg);
+            hv_launch(hv_gemm_glds_kernel<128, 4, 128, 2, true>, dim3(grid6), dim3(256), stream, p, c.gm, c.form);
         } else {
             hv_note("hv_gemm_glds_kernel<128,4,128,2> | %s", shape);
-            hv_launch(hv_gemm_glds_kernel<128, 4, 128, 2, false>, dim3(grid6), dim3(256), stream, p, c.gm, c.form, stg);
+            hv_launch(hv_gemm_glds_kernel<128, 4, 128, 2, false>, dim3(grid6), dim3(256), stream, p, c.gm, c.form);
         }
         return 0;
     }

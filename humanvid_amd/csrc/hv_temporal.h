@@ -23,7 +23,7 @@
 // bytes each) are staged row-major in LDS with coalesced 16-byte loads; Q and K fragments are one ds_read_b128 each, a
 // V^T fragment is eight 2-byte reads (lanes of a quad read adjacent channels of one key row: conflict-free; transposing
 // V while staging it instead put 40 lanes on one bank per store).
-template <int D>
+template <int D, int FR = 32>
 struct HvTemporalGeom {
     static constexpr int HG = 320 / D;                // heads per workgroup (one wave each): 8 / 4 / 2
     static constexpr int CB = HG * D;                 // channels per workgroup (320)
@@ -31,83 +31,22 @@ struct HvTemporalGeom {
     static constexpr int NFULL = D / 32;
     static constexpr bool TAIL = (D % 32) != 0;
     static constexpr int DT = (D + 15) / 16;
-    static constexpr int LDS_BYTES = 96 * RS;          // 32 rows each of Q, K, V
+    static constexpr int LDS_BYTES = 3 * FR * RS;      // FR rows each of Q, K, V (FR = 24 for windows of <= 24 frames: 47 KB,
+                                                       // three workgroups per CU instead of two -- more rows in flight for an HBM-bound op)
 };
 
-// Mixed-shape MFMA chains.  Round 1 shipped this kernel with every MFMA fenced (scheduling barrier + 16 wait states): the
-// unfenced d = 80 instantiation was wrong and irreproducible run to run once two workgroups shared a CU (F = 24, P = 1536)
-// while correct on the host emulator and at small grids.  Round 2 root-caused it on the hardware with ten diagnosis builds
-// (tools/diag_fence.py; table in profiles/r02_mfma_chain_hazard.md):
-//   * the fault needs the 16-deep v_mfma_f32_16x16x16_bf16 (head-dim remainder: d = 40, 80) in the SAME accumulation
-//     chain as the 32-deep v_mfma_f32_16x16x32_bf16 steps: hipcc (ROCm 7.2) issues the two back to back
-//         v_mfma_f32_16x16x32_bf16 a[12:15], v[4:7], v[20:23], a[12:15]
-//         s_waitcnt lgkmcnt(0)
-//         v_mfma_f32_16x16x16_bf16 a[12:15], v[10:11], v[0:1], a[12:15]
-//     as if they were a same-shape accumulate pair (SrcC forwarded), but their pass counts differ and the second reads
-//     an accumulator the first has not finished writing.  How much is wrong depends on what shares the SIMD's matrix
-//     pipe at that moment, hence the run-to-run differences and the dependence on occupancy;
-//   * with NO 16-deep MFMA (remainder as a zero-padded 32-deep step) the unfenced kernel is bit-reproducible and equal
-//     to the VALU kernel at every shape; with the 16-deep MFMA FIRST in the chain d = 40 fails as well (116 k wrong
-//     rows); wait states around the 16-deep MFMA alone, or scheduling barriers alone, also cure it; fencing only the
-//     O^T MFMAs does not (the O^T products are single MFMAs with C = 0: no chain).
-// Rule adopted for every kernel of the library: all MFMAs of one accumulation chain have the same shape (HV_TEMPORAL_TAIL
-// = 1 here, HV_ATTN_PAD32 in hv_attention.h).  The fence is gone (HV_TEMPORAL_FENCE = 0); the macros below remain for
-// the diagnosis builds only.
-// HV_TEMPORAL_FENCE selects the guard for the diagnosis builds of tools/diag_fence.py:
-//   0 none | 1 scheduling barrier + 16 wait states after every MFMA (default) | 2 scheduling barriers only
-//   3 wait states only | 4 guard the S^T MFMAs only | 5 guard the O^T MFMAs only | 6 scheduling barrier + 2 wait states
-#ifndef HV_TEMPORAL_FENCE
-#define HV_TEMPORAL_FENCE 0
-#endif
-// HV_TEMPORAL_TAIL: how the head-dim remainder (d = 40: 8, d = 80: 16 channels) enters the S^T accumulation chain:
-//   0 a 16-deep mfma_16x16x16 after the 32-deep steps (round 1) | 1 a zero-padded 32-deep step (same shape as the rest)
-//   2 the 16-deep MFMA first | 3 as 0, with wait states around the 16-deep MFMA only
-#ifndef HV_TEMPORAL_TAIL
-#define HV_TEMPORAL_TAIL 1
-#endif
-#if defined(HV_EMU) || HV_TEMPORAL_FENCE == 0
-#define HV_MFMA_GUARD_QK()
-#define HV_MFMA_GUARD_PV()
-#else
-#if HV_TEMPORAL_FENCE == 2
-#define HV_MFMA_GUARD_() __builtin_amdgcn_sched_barrier(0)
-#elif HV_TEMPORAL_FENCE == 3
-#define HV_MFMA_GUARD_() asm volatile("s_nop 15" ::: "memory")
-#elif HV_TEMPORAL_FENCE == 6
-#define HV_MFMA_GUARD_()                         \
-    do {                                         \
-        __builtin_amdgcn_sched_barrier(0);       \
-        asm volatile("s_nop 1" ::: "memory");    \
-        __builtin_amdgcn_sched_barrier(0);       \
-    } while (0)
-#else
-#define HV_MFMA_GUARD_()                         \
-    do {                                         \
-        __builtin_amdgcn_sched_barrier(0);       \
-        asm volatile("s_nop 15" ::: "memory");   \
-        __builtin_amdgcn_sched_barrier(0);       \
-    } while (0)
-#endif
-#if HV_TEMPORAL_FENCE == 5
-#define HV_MFMA_GUARD_QK()
-#else
-#define HV_MFMA_GUARD_QK() HV_MFMA_GUARD_()
-#endif
-#if HV_TEMPORAL_FENCE == 4
-#define HV_MFMA_GUARD_PV()
-#else
-#define HV_MFMA_GUARD_PV() HV_MFMA_GUARD_()
-#endif
-#endif
-
-template <int D>
-__global__ __launch_bounds__(HvTemporalGeom<D>::HG * 64) void hv_temporal_mfma_kernel(hv_temporal_attention_params p) {
-    using G = HvTemporalGeom<D>;
+// Mixed-shape MFMA chains: a 16-deep v_mfma_f32_16x16x16_bf16 chained to 32-deep v_mfma_f32_16x16x32_bf16 steps on the same
+// accumulator reads a partially written accumulator on gfx950 with hipcc / ROCm 7.2 (root-caused on the hardware in round 2:
+// profiles/r02_mfma_chain_hazard.md).  Rule for every kernel of the library: all MFMAs of one accumulation chain have the same
+// shape -- the head-dim remainder (d = 40: 8, d = 80: 16 channels) enters as a zero-padded 32-deep step.
+template <int D, int FR>
+__global__ __launch_bounds__((HvTemporalGeom<D, FR>::HG * 64)) void hv_temporal_mfma_kernel(hv_temporal_attention_params p) {
+    using G = HvTemporalGeom<D, FR>;
     constexpr int HG = G::HG, CB = G::CB, RS = G::RS, NFULL = G::NFULL, DT = G::DT;
     __shared__ __attribute__((aligned(16))) unsigned char smem[G::LDS_BYTES];
-    unsigned char* Qs = smem;            // [32][RS]
-    unsigned char* Ks = smem + 32 * RS;  // [32][RS]
-    unsigned char* Vs = smem + 64 * RS;  // [32][RS]
+    unsigned char* Qs = smem;                // [FR][RS]
+    unsigned char* Ks = smem + FR * RS;      // [FR][RS]
+    unsigned char* Vs = smem + 2 * FR * RS;  // [FR][RS]
     const int tid = threadIdx.x, nthr = HG * 64;
     const int lane = tid & 63, wave = tid >> 6, r16 = lane & 15, quad = lane >> 4;
     const int F = p.Fkv, FQ = p.Fq;
@@ -128,7 +67,7 @@ __global__ __launch_bounds__(HvTemporalGeom<D>::HG * 64) void hv_temporal_mfma_k
     // every load of the workgroup's Q / K / V rows is issued before the first LDS store (compile-time trip count, predicated):
     // as runtime-trip-count loops hipcc emitted load -> vmcnt(0) -> ds_write per trip, i.e. four dependent HBM round trips
     // per workgroup with one or two 16-byte loads in flight per thread (3.7 TB/s at level 0)
-    constexpr int NIT = (32 * CV + HG * 64 - 1) / (HG * 64);
+    constexpr int NIT = (FR * CV + HG * 64 - 1) / (HG * 64);
     u32x4 qr[NIT], kr[NIT], vr[NIT];
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {  // unconditional loads from clamped (always valid) rows: no branch, no wait between them
@@ -159,39 +98,13 @@ __global__ __launch_bounds__(HvTemporalGeom<D>::HG * 64) void hv_temporal_mfma_k
     f32x4 sacc[2][2];  // [key tile][query tile]: lane = (query r16, quad), reg r <-> key 16*kt + 4*quad + r
     // remainder of the head dim past the 32-deep steps (8 channels for d = 40, 16 for d = 80)
     auto acc_tail = [&](f32x4& acc, const unsigned char* krow, const unsigned char* qrow) {
-#if HV_TEMPORAL_TAIL == 1
-        // zero-padded 32-deep step: quads whose 8 channels lie past D contribute zeros.  Keeps every MFMA of a
-        // dependent accumulation chain the same shape (see HV_TEMPORAL_TAIL above)
+        // zero-padded 32-deep step: quads whose 8 channels lie past D contribute zeros (same MFMA shape as the rest of the chain)
         u32x4 ka = {0u, 0u, 0u, 0u}, qa = {0u, 0u, 0u, 0u};
         if (32 * NFULL + 8 * quad + 8 <= D) {
             ka = hv_ld16(krow + NFULL * 64 + quad * 16);
             qa = hv_ld16(qrow + NFULL * 64 + quad * 16);
         }
         acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(hv_as_bf16x8(ka), hv_as_bf16x8(qa), acc, 0, 0, 0);
-#else
-        union {
-            u32x2 u;
-            bf16x4 v;
-        } ka, qa;
-        ka.u = u32x2{0u, 0u};
-        qa.u = u32x2{0u, 0u};
-        if (32 * NFULL + 4 * quad + 4 <= D) {
-            ka.u = hv_ld8(krow + NFULL * 64 + quad * 8);
-            qa.u = hv_ld8(qrow + NFULL * 64 + quad * 8);
-        }
-#if HV_TEMPORAL_TAIL == 3
-        __builtin_amdgcn_sched_barrier(0);
-        asm volatile("s_nop 15" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-#endif
-        acc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ka.v, qa.v, acc, 0, 0, 0);
-#if HV_TEMPORAL_TAIL == 3
-        __builtin_amdgcn_sched_barrier(0);
-        asm volatile("s_nop 15" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-#endif
-#endif
-        HV_MFMA_GUARD_QK();
     };
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt)
@@ -205,20 +118,14 @@ __global__ __launch_bounds__(HvTemporalGeom<D>::HG * 64) void hv_temporal_mfma_k
         for (int qt = 0; qt < 2; ++qt) {
             if (qt >= nqt) break;
             const unsigned char* qrow = Qs + min(16 * qt + r16, FQ - 1) * RS + hd * 2;
-#if HV_TEMPORAL_TAIL == 2
-            if (G::TAIL) acc_tail(sacc[kt][qt], krow, qrow);
-#endif
 #pragma unroll
             for (int s = 0; s < NFULL; ++s)
             {
                 sacc[kt][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(hv_as_bf16x8(hv_ld16(krow + s * 64 + quad * 16)),
                                                                        hv_as_bf16x8(hv_ld16(qrow + s * 64 + quad * 16)),
                                                                        sacc[kt][qt], 0, 0, 0);
-                HV_MFMA_GUARD_QK();
             }
-#if HV_TEMPORAL_TAIL != 2
             if (G::TAIL) acc_tail(sacc[kt][qt], krow, qrow);
-#endif
         }
     }
     // ---- softmax over the keys of each query column (all keys are here: no running state) ----
@@ -270,7 +177,6 @@ __global__ __launch_bounds__(HvTemporalGeom<D>::HG * 64) void hv_temporal_mfma_k
         for (int qt = 0; qt < 2; ++qt) {
             if (qt >= nqt) break;
             f32x4 o = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[qt], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-            HV_MFMA_GUARD_PV();
             const int q = 16 * qt + r16, d = 16 * dt + 4 * quad;
             if (q < FQ && d < D) {
                 const u32x2 st = {hv_pack2(o[0] * inv_l[qt], o[1] * inv_l[qt]), hv_pack2(o[2] * inv_l[qt], o[3] * inv_l[qt])};
@@ -287,10 +193,20 @@ static inline int hv_temporal_launch(const hv_temporal_attention_params& p, hipS
     if (p.qo_chunked && p.Fq != p.Fkv) return -1;
     if (p.Fkv > 32) return -2;  // one 32-key MFMA tile per (batch, pixel, head): the positional encoding caps windows at 32 frames
     hv_note("hv_temporal_mfma_kernel<%d> | B=%d Fq=%d Fkv=%d P=%d", p.D, p.B, p.Fq, p.Fkv, p.P);
+    const bool fr24 = p.Fkv <= 24;
     switch (p.D) {
-        case 40: hv_launch(hv_temporal_mfma_kernel<40>, dim3(p.B * p.P), dim3(512), stream, p); return 0;
-        case 80: hv_launch(hv_temporal_mfma_kernel<80>, dim3(p.B * p.P * 2), dim3(256), stream, p); return 0;
-        case 160: hv_launch(hv_temporal_mfma_kernel<160>, dim3(p.B * p.P * 4), dim3(128), stream, p); return 0;
+        case 40:
+            if (fr24) hv_launch(hv_temporal_mfma_kernel<40, 24>, dim3(p.B * p.P), dim3(512), stream, p);
+            else hv_launch(hv_temporal_mfma_kernel<40, 32>, dim3(p.B * p.P), dim3(512), stream, p);
+            return 0;
+        case 80:
+            if (fr24) hv_launch(hv_temporal_mfma_kernel<80, 24>, dim3(p.B * p.P * 2), dim3(256), stream, p);
+            else hv_launch(hv_temporal_mfma_kernel<80, 32>, dim3(p.B * p.P * 2), dim3(256), stream, p);
+            return 0;
+        case 160:
+            if (fr24) hv_launch(hv_temporal_mfma_kernel<160, 24>, dim3(p.B * p.P * 4), dim3(128), stream, p);
+            else hv_launch(hv_temporal_mfma_kernel<160, 32>, dim3(p.B * p.P * 4), dim3(128), stream, p);
+            return 0;
         default: return -2;
     }
 }

@@ -85,17 +85,14 @@ def test_gemm_fast_epilogue_forms(cx):
 
 def test_gemm_wide_tile_kernel(cx):
     """hv_gemm_wide_kernel (256 x 320 x 64 tiles: the default for N = 320, K >= 640, M % 256 == 0, plain-output forms with a
-    bias): its three output forms, several tiles per persistent workgroup, a table row per 32-row wave block, the phase
-    stagger of the persistent workgroups; problems it does not take (ragged M, K < 640, statistics wanted) run on the
+    bias): its three output forms, several tiles per persistent workgroup, a table row per 32-row wave block; problems it does not take (ragged M, K < 640, statistics wanted) run on the
     square tiles and give the same results as with the wide tiles switched off (tuning value 6)"""
     cx.lib.call("hv_set_tuning", 2, 8)
     try:
         for form in ("ln", "res", "plain"):
             kc.case_gemm_forms(cx, M=768, C=640, N=320, P=128, form=form, seed=71)     # 3 tiles, 10 k-steps each
         kc.case_gemm_forms(cx, M=2560, C=704, N=320, P=32, form="ln", seed=73)          # 10 tiles over 8 workgroups; table row per 32-row block
-        cx.lib.call("hv_set_tuning", 8, 4)                                              # four phase groups (timing only)
         kc.case_gemm_forms(cx, M=2560, C=640, N=320, P=128, form="res", seed=77)
-        cx.lib.call("hv_set_tuning", 8, 0)
         kc.case_gn_parts_gemm(cx, n=4, rows=128, C=320, K=640, seed=74)                 # statistics wanted: square tiles, 64-row parts
         kc.case_ln_parts_gemm(cx, M=768, C=320, K=640, seed=75)
         kc.case_gemm_forms(cx, M=520, C=640, N=320, P=128, form="res", seed=76)         # M % 256 != 0: square tiles
@@ -103,7 +100,6 @@ def test_gemm_wide_tile_kernel(cx):
         cx.lib.call("hv_set_tuning", 3, 6)
         kc.case_gemm_forms(cx, M=768, C=640, N=320, P=128, form="res", seed=71)
     finally:
-        cx.lib.call("hv_set_tuning", 8, 0)
         cx.lib.call("hv_set_tuning", 3, 1)
         cx.lib.call("hv_set_tuning", 2, 512)
 

@@ -39,19 +39,13 @@ def test_gemm_fused(cx):
 
 def test_gemm_wide_tile_kernel(cx):
     """the 256 x 320 x 64 wide-tile kernel (default for N = 320, K >= 640, M % 256 == 0) at the level-0 feed-forward output
-    shape of a frame shard (M = 36 864) and with several tiles per workgroup (M = 147 456), with and without the phase
-    stagger of the persistent workgroups; a problem that wants statistics stays on the square tiles (64-row parts)"""
-    try:
-        for stagger in (0, 4):
-            cx.lib.call("hv_set_tuning", 8, stagger)
-            for form in ("res", "ln", "plain"):
-                kc.case_gemm_forms(cx, M=36864, C=1280, N=320, P=768, form=form, seed=81)
-            kc.case_gemm_forms(cx, M=147456, C=640, N=320, P=6144, form="res", seed=82)
-            kc.case_gemm_geglu(cx, M=73728, C=320, seed=88)                                  # the 256 x 256 kernel under the stagger
-        kc.case_gn_parts_gemm(cx, n=6, rows=6144, C=320, K=1280, seed=83)
-        kc.case_ln_parts_gemm(cx, M=36864, C=320, K=640, seed=84)
-    finally:
-        cx.lib.call("hv_set_tuning", 8, 0)
+    shape of a frame shard (M = 36 864) and with several tiles per workgroup (M = 147 456); a problem that wants statistics
+    stays on the square tiles (64-row parts)"""
+    for form in ("res", "ln", "plain"):
+        kc.case_gemm_forms(cx, M=36864, C=1280, N=320, P=768, form=form, seed=81)
+    kc.case_gemm_forms(cx, M=147456, C=640, N=320, P=6144, form="res", seed=82)
+    kc.case_gn_parts_gemm(cx, n=6, rows=6144, C=320, K=1280, seed=83)
+    kc.case_ln_parts_gemm(cx, M=36864, C=320, K=640, seed=84)
 
 
 def test_gemm_epilogue_forms(cx):

@@ -21,6 +21,12 @@
 //    head-dim index 40, Q by -m there: the MFMA delivers s - m with C = 0 -- no accumulator initialisation moves, no
 //    subtraction), the "some probability exceeds 2^THR" test runs on the PACKED bf16 pairs (v_pk_max_u16: positive bf16
 //    order like unsigned integers -- 15 instead of 31 maxima), exponentials in the exp2 domain as before.
+//  * OPTIMISTIC reference maximum: the first tile's maximum is kept as the reference for the whole key loop and NO per-tile
+//    test runs (the "some probability exceeds 2^THR" test of the generic kernel -- 15 packed maxima, a compare and a
+//    wave vote per tile -- measured 6.3 % of the kernel, profiles/r04_s3.txt).  bf16 probabilities and fp32 accumulators
+//    keep their relative precision at any magnitude, so nothing is lost until a later score exceeds the reference by ~2^7
+//    in the exp2 domain and the exponential overflows; the denominator row of O^T then is not finite, the workgroup votes
+//    once after the loop, and -- only then -- runs the loop again in the careful form (test + deferred rescale per tile).
 // The reference maximum therefore lives in bf16 (it is an element of the Q operand); the rescale factors are computed from
 // the rounded values, so every tile of a query is exponentiated against exactly the maximum its O^T / denominator carry
 // (the softmax is invariant to the choice of reference as long as it is used consistently).
@@ -180,14 +186,20 @@ __global__ __launch_bounds__(512, 4) void hv_attention40_kernel(hv_attention_par
     };
 
     f32x4 oacc[2][3];  // O^T accumulators [16-query tile][16-row channel fragment]: lane = query r16, channels 16 dt + 4 quad + 0..3
+    __syncthreads();  // LDS initialisation complete before the first tile store
+    // pass 0: optimistic (the first tile's maximum is the reference throughout); pass 1, only after an overflow: careful
+    for (int pass = 0; pass < 2; ++pass) {
+    const bool careful = pass == 1;
+    if (careful) {  // start over: the query operand's augmented element back to -m = 0
+        mneg = 0.f;
+        if (half) qf[2][0] = (short)0;
+    }
 #pragma unroll
     for (int qt = 0; qt < 2; ++qt)
 #pragma unroll
         for (int dt = 0; dt < 3; ++dt) oacc[qt][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
-
     set_source(false);
     load_tile(0);
-    __syncthreads();  // LDS initialisation complete before the first tile store
     for (int ti = 0; ti < ntiles; ++ti) {
         const int buf = ti & 1;
         store_tile(buf);
@@ -238,25 +250,19 @@ __global__ __launch_bounds__(512, 4) void hv_attention40_kernel(hv_attention_par
 #pragma unroll
             for (int j = 0; j < 8; ++j)
                 w[kbk][j] = hv_pack2(__builtin_amdgcn_exp2f(sacc[kbk][2 * j]), __builtin_amdgcn_exp2f(sacc[kbk][2 * j + 1]));
-        // some probability of the wave above 2^THR (bf16 256.0 = 0x4380; +inf = 0x7F80 is above as well)?  Positive bf16
-        // order like 16-bit unsigned integers: the maximum runs on the packed pairs.
-#ifdef HV_ATTN40_PROBE_NOTEST
-        unsigned pm = 0;
-#else
-        unsigned pm = hv_pk_max_u16(w[0][0], w[0][1]);
+        // careful pass only: some probability of the wave above 2^THR (bf16 256.0 = 0x4380; +inf = 0x7F80 is above as well)?
+        // Positive bf16 order like 16-bit unsigned integers: the maximum runs on the packed pairs.
+        bool over = false;
+        if (careful) {  // (wave-uniform)
+            unsigned pm = hv_pk_max_u16(w[0][0], w[0][1]);
 #pragma unroll
-        for (int j = 2; j < 8; ++j) pm = hv_pk_max_u16(pm, w[0][j]);
+            for (int j = 2; j < 8; ++j) pm = hv_pk_max_u16(pm, w[0][j]);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) pm = hv_pk_max_u16(pm, w[1][j]);
-#endif
-#ifdef HV_ATTN40_PROBE_NOTEST  // timing probe (tools/r04_s3.sh): what the threshold test costs -- wrong on spiky inputs, never shipped
-        const bool over = false;
-        asm volatile("" ::"v"(pm));
-#else
-        const bool over = (pm & 0xffffu) > 0x4380u || (pm >> 16) > 0x4380u;
-#endif
+            for (int j = 0; j < 8; ++j) pm = hv_pk_max_u16(pm, w[1][j]);
+            over = __any((pm & 0xffffu) > 0x4380u || (pm >> 16) > 0x4380u);
+        }
         const bool first = ti == 0;  // the first tile fixes the reference maximum (it starts at 0, not at a score)
-        if (first || __any(over)) {
+        if (first || over) {
             // rare: raise the reference maximum by the query's tile maximum, redo the exponentials against it and scale what
             // is still at the old reference (O^T with its denominator row) exactly once.  The scores are recomputed from LDS.
 #ifndef HV_EMU
@@ -322,6 +328,23 @@ __global__ __launch_bounds__(512, 4) void hv_attention40_kernel(hv_attention_par
 #ifndef HV_EMU
         __builtin_amdgcn_s_setprio(0);
 #endif
+    }
+    if (careful) break;
+    // ---- did anything overflow?  (inf / NaN anywhere in this lane's O^T columns, denominator row included: 0 x inf = NaN)
+    float chk = 0.f;
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+        for (int dt = 0; dt < 3; ++dt) chk += (oacc[qt][dt][0] + oacc[qt][dt][1] + oacc[qt][dt][2] + oacc[qt][dt][3]) * 0.f;
+    const int wave_bad = __any(chk != chk);
+    __syncthreads();  // every wave is done with the tile buffers: the first bytes of the K buffer take the votes
+    if (lane == 0) reinterpret_cast<int*>(smem)[wave] = wave_bad;
+    __syncthreads();
+    int any_bad = 0;
+#pragma unroll
+    for (int i = 0; i < G::NW; ++i) any_bad |= reinterpret_cast<const int*>(smem)[i];
+    if (!any_bad) break;
+    __syncthreads();  // the votes are read before pass 1 stores its first tile over them
     }
 
     // ---- normalise and store: lane owns query 16 qt + r16, channels 16 dt + 4 quad + 0..3; the denominator is O^T row 40

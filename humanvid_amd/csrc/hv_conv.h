@@ -426,7 +426,7 @@ __global__ __launch_bounds__(2 * 64 * (NPIX / WPX), (WPX == 128 ? 2 : 1)) void h
 static int g_hv_conv_glds = 1;  // tuning knob (hv_set_tuning): LDS-DMA weight tiles
 
 static int g_hv_conv_big = 1;  // tuning knob: 256-pixel tiles (8 waves) on images that fill them
-static int g_hv_conv_raster = 0;  // tuning knob (hv_set_tuning key 9): 0 / 1 always that raster, 2 = raster 1 where the weights exceed the XCD's L2 (Cin x Cout >= 640 x 640)
+static int g_hv_conv_raster = 2;  // tuning knob (hv_set_tuning key 9): 0 / 1 always that raster, 2 = raster 1 where the weights exceed the XCD's L2 (Cin x Cout >= 640 x 640)
 
 template <int TW, int MODE, int NPIX, int WPX = 64, int CK = 32>
 static inline void hv_conv3x3_launch_t(const hv_conv3x3_params& p, hipStream_t stream) {

@@ -513,10 +513,14 @@ def case_attention(cx: Ctx, D=40, n_img=4, Lq=72, Lb=40, seed=6, check=None, q_s
     q, k, v = rnd(g, n_img, Lq, Cc), rnd(g, n_img, Lq, Cc), rnd(g, n_img, Lq, Cc)
     kb, vb = rnd(g, 2, Lb, Cc), rnd(g, 2, Lb, Cc)
     if spike:
+        # spike = True: scores 30-45 (exp2 domain) above the rest -- past the deferred-rescale threshold 2^8, inside fp32 range;
+        # spike = 8.0 (a factor): 200-360 above -- exp2 overflows against the first tile's reference, which is what sends
+        # the optimistic head-dim-40 kernel (hv_attention40.h) into its careful second pass
+        amp = 1.0 if spike is True else float(spike)
         for i in range(n_img):
             for j, ks in enumerate(range(min(Lq - 1, 70), Lq, 97)):
-                k[i, ks] = (3.0 + j % 3) * q[i, (5 + 11 * j) % Lq]
-        kb[1, min(3, Lb - 1)] = 4.0 * q[n_img - 1, 9 % Lq]
+                k[i, ks] = amp * (3.0 + j % 3) * q[i, (5 + 11 * j) % Lq]
+        kb[1, min(3, Lb - 1)] = amp * 4.0 * q[n_img - 1, 9 % Lq]
     sel = torch.tensor([-1] * (n_img // 2) + [1] * (n_img - n_img // 2), dtype=torch.int32)
 
     def heads(t):

@@ -330,6 +330,8 @@ def test_attention40_variants(cx):
     finally:
         cx.lib.call("hv_set_tuning", 0, 0)
     kc.case_attention(cx, D=40, n_img=2, Lq=520, Lb=8, seed=20)
+    kc.case_attention(cx, D=40, n_img=2, Lq=200, Lb=72, spike=8.0, seed=71)   # exp2 overflow against the first tile's reference: second, careful pass
+    kc.case_attention(cx, D=40, n_img=2, Lq=192, Lb=64, spike=8.0, seed=72)   # (unmasked instance)
 
 
 def test_attention_unmasked_instances(cx):

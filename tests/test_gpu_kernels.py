@@ -158,6 +158,9 @@ def test_attention_variants(cx):
 def test_attention_forced_rescale(cx, D, L):
     kc.case_attention(cx, D=D, n_img=4, Lq=L, Lb=L, spike=True, seed=73, check=(0, 3), q_stride=4)
     kc.case_attention(cx, D=D, n_img=4, Lq=L + 40, Lb=L - 24, spike=True, seed=74, check=(1, 2), q_stride=4)
+    if D == 40:  # exp2 overflow against the first tile's reference: the optimistic kernel's careful second pass
+        kc.case_attention(cx, D=D, n_img=4, Lq=L, Lb=L, spike=8.0, seed=75, check=(0, 3), q_stride=4)
+        kc.case_attention(cx, D=D, n_img=4, Lq=L + 40, Lb=L - 24, spike=8.0, seed=76, check=(1, 2), q_stride=4)
 
 
 @pytest.mark.parametrize("D,Fr,P", [(40, 24, 384), (80, 16, 96), (160, 24, 24), (40, 8, 64), (80, 32, 40), (40, 18, 50), (80, 24, 768),

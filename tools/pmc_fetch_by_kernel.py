@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""FETCH_SIZE per kernel instantiation and launch from one rocprofv3 pass (`--pmc FETCH_SIZE --kernel-trace`), x 2 for gfx950's
-half-counted wide reads (MI355X_MICROARCH.md, section HBM): python tools/pmc_fetch_by_kernel.py <pass_dir> [name filter]"""
+"""FETCH_SIZE per kernel instantiation and launch from one rocprofv3 pass (`--pmc FETCH_SIZE --kernel-trace`): KiB x 1024, x 2 for
+gfx950's half-counted wide reads (MI355X_MICROARCH.md, section HBM; the corrections of tools/pmc_by_shape.py): python tools/pmc_fetch_by_kernel.py <pass_dir> [name filter]"""
 import collections
 import csv
 import glob
@@ -22,4 +22,4 @@ for r in csv.DictReader(open(files[0])):
     n[key] += 1
 for key, v in sorted(acc.items(), key=lambda kv: -kv[1]):
     if flt in key:
-        print(f"{n[key]:>5} launches  {2.0 * v / n[key] / 1e6:>10.1f} MB fetched per launch  {key}")
+        print(f"{n[key]:>5} launches  {2.0 * 1024.0 * v / n[key] / 1e6:>10.1f} MB fetched per launch  {key}")

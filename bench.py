@@ -194,7 +194,7 @@ def roofline_from_profile(kernels, traffic_file):
         t = json.load(open(traffic_file))
         if t.get("csrc_digest") != csrc_digest():
             roof["traffic_note"] = (f"refused {os.path.basename(traffic_file)}: collected with kernel sources "
-                                    f"{t.get('csrc_digest')}, this build is {csrc_digest()} (re-run tools/final_r03.sh)")
+                                    f"{t.get('csrc_digest')}, this build is {csrc_digest()} (re-run tools/final_r04.sh)")
         else:
             k = t.get("kernels", {}).get(name)
             if k is not None:
@@ -492,7 +492,7 @@ def main():
         if exchange is not None:
             out["exchange"] = exchange
         if "kernels" in prof:
-            roof, table = roofline_from_profile(prof["kernels"], os.path.join(REPO, "profiles", "r03_pmc_traffic.json"))
+            roof, table = roofline_from_profile(prof["kernels"], os.path.join(REPO, "profiles", "r04_pmc_traffic.json"))
             out["roofline"] = roof
             out["kernels"] = table
         if world == 1 and not args.no_cpu_baseline:

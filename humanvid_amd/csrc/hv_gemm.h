@@ -883,7 +883,7 @@ __global__ __launch_bounds__(256, 2) void hv_gemm_kernel(HvGemmParams p) {
 //   PERM: the permuted channel assignment of a wave's 64-channel block (hv_perm_row) for the plain-output forms.
 //   STATS (with PERM): the plain / residual epilogue also leaves GroupNorm (1, p.gn_part) or LayerNorm (2, p.ln_part) partial
 //   statistics of its tile.
-template <int BN, int NW, int BM, int PH, bool PERM = false, int STATS = 0>
+template <int BN, int NW, int BM, int PH, bool PERM = false, int STATS = 0, bool PP = false>
 __global__ __launch_bounds__(NW * 64, 2) void hv_gemm_glds_kernel(HvGemmParams p, int gm, int form) {
     constexpr int BK = 64, NS = 2;
     constexpr int WAVES_N = BN / 64, WAVES_M = NW / WAVES_N;
@@ -1028,6 +1028,156 @@ __global__ __launch_bounds__(NW * 64, 2) void hv_gemm_glds_kernel(HvGemmParams p
 #ifdef HV_GEMM_TRACE
     int hv_ti = 0;
 #endif
+    if constexpr (PP) {
+        // ---- PING-PONG k-loop (round 4; 256 x 256 x 64 on 8 waves only).  The loop below keeps the two waves of a SIMD in
+        // lockstep: both read fragments, then both multiply -- the matrix pipe idles while they read and the LDS idles while
+        // they multiply (profiles/r03_gemm_trace.txt: 43 % MFMA-busy inside the k-loop).  Here a k-step is FOUR phases
+        //     R0: W fragments + X fragments of the first row half (16 ds_read_b128)    M0: their 32 MFMAs
+        //     R1: X fragments of the second row half (8 reads)                         M1: their 32 MFMAs
+        // separated by raw barriers, and waves 4-7 (the second wave of every SIMD) run ONE PHASE BEHIND waves 0-3: while one
+        // wave of a SIMD multiplies, the other reads (and issues its LDS-DMA).  Global phase t = 4 s + phi: group A executes
+        // phase t of its program, group B what A executed at t - 1 (B passes one extra barrier at the start, A one at the end).
+        // LDS-DMA (inline-asm form: hipcc does not see it, every wait below is by hand): a wave issues G0(s+1) = {W q0-3,
+        // X q0, X q2} in its R0(s) and G1(s+1) = {X q1, X q3} in its R1(s), in that order.  Hazards, by global phase:
+        //   readers  W / Xa of tile s: A at 4s, B at 4s+1;  Xb of tile s: A at 4s+2, B at 4s+3
+        //   writers  G0(s+1) -> W / Xa of slot (s+1)%2 (last read: tile s-1, B at 4s-3): issued A 4s, B 4s+1       (WAR ok)
+        //            G1(s+1) -> Xb of that slot (last read: B at 4s-1): issued A 4s+2, B 4s+3                      (WAR ok)
+        //   G0(s+1) must be visible at 4s+4: every wave waits for its own share before the barrier that ends phase 4s+3
+        //            = A's M1(s), B's R1(s): vmcnt(2) (the two G1(s+1) behind it stay in flight)
+        //   G1(s+1) must be visible at 4s+6: wait before the barrier that ends phase 4s+5 = A's M0(s+1), B's R0(s+1):
+        //            vmcnt(6) (the six G0(s+2) behind it stay in flight)
+        // After an epilogue (it waits for every load before its first store) whatever was issued before it has landed: the
+        // wait that would come next is skipped instead of waiting for the epilogue's stores to be acknowledged.
+        static_assert(NW == 8 && BM == 256 && BN == 256 && NMF == 8, "ping-pong k-loop: 256 x 256 x 64 on 8 waves");
+        const int grp = wave >> 2;  // 0: waves 0-3 (group A), 1: waves 4-7 (group B) -- one wave of each per SIMD
+        auto dma_x = [&](auto Q) __attribute__((always_inline)) {
+            constexpr int q = decltype(Q)::value;
+            unsigned& o = hv_pick4<q>(xo0, xo1, xo2, xo3);
+            hv_glds16_s(xbase, o, smem + i_slot * SLOT + (wave + NW * q) * 1024);
+            o += BK * 2;
+        };
+        auto dma_w = [&](auto Q) __attribute__((always_inline)) {
+            constexpr int q = decltype(Q)::value;
+            unsigned& o = hv_pick4<q>(wo0, wo1, wo2, wo3);
+            hv_glds16_s(wbase, o, smem + i_slot * SLOT + XT + (wave + NW * q) * 1024);
+            o += BK * 2;
+        };
+        auto issue_g0 = [&]() __attribute__((always_inline)) {
+            hv_static_for<WQ>([&](auto Q) __attribute__((always_inline)) { dma_w(Q); });
+            dma_x(HvInt<0>{});
+            dma_x(HvInt<2>{});
+        };
+        auto issue_g1 = [&]() __attribute__((always_inline)) {
+            dma_x(HvInt<1>{});
+            dma_x(HvInt<3>{});
+            issue_advance();
+        };
+        auto fence = [&]() __attribute__((always_inline)) {
+#ifndef HV_EMU
+            __builtin_amdgcn_sched_barrier(0);  // nothing moves across a phase boundary at compile time either
+#endif
+        };
+        auto phase_end = [&]() __attribute__((always_inline)) {
+            fence();
+            hv_barrier_raw();
+            fence();
+        };
+        issue_g0();
+        issue_g1();
+        hv_vm_wait<0>();
+        phase_end();               // k-tile 0 visible
+        if (grp == 1) phase_end();  // group B runs one phase behind
+        int c_tile = first, c_k = 0, c_slot = 0;
+        bool skip6 = false;  // an epilogue has run since the last G1 wait
+        constexpr int HMF = 4;
+        bf16x8 wf[2][4], xf[2][HMF];
+        for (int s = 0; s < nsteps; ++s) {
+            const bool more = s + 1 < nsteps;
+            const unsigned char* xs = smem + c_slot * SLOT;
+            const unsigned char* ws = xs + XT;
+            if (++c_slot == NS) c_slot = 0;
+            auto wait_g1 = [&]() __attribute__((always_inline)) {  // G1 of this step's own k-tile ... (see the table above)
+                if (skip6) skip6 = false;
+                else if (more) hv_vm_wait<6>();
+                else hv_vm_wait<0>();
+            };
+            auto wait_g0 = [&](bool landed) __attribute__((always_inline)) {  // G0 of the next k-tile
+                if (landed) return;
+                if (more) hv_vm_wait<2>();
+                else hv_vm_wait<0>();
+            };
+            // ---- R0
+            if (more) issue_g0();
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                for (int f = 0; f < 4; ++f) {
+                    const int wrow = !PERM ? 16 * f + r16 : (form == HV_FORM_LN_GEGLU ? hv_perm_row_geglu(f, r16) : hv_perm_row(f, r16));
+                    wf[kk][f] = hv_as_bf16x8(hv_ld16(ws + (PERM ? hv_swz_wperm(64 * wn + wrow, kk * 4 + quad)
+                                                                : hv_swz<BK>(64 * wn + wrow, kk * 4 + quad))));
+                }
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                for (int f = 0; f < HMF; ++f) xf[kk][f] = hv_as_bf16x8(hv_ld16(xs + hv_swz<BK>(WTM * wm + 16 * f + r16, kk * 4 + quad)));
+            if (grp == 1) wait_g1();
+            phase_end();
+            // ---- M0
+#ifndef HV_EMU
+            __builtin_amdgcn_s_setprio(1);
+#endif
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                for (int nf = 0; nf < 4; ++nf)
+#pragma unroll
+                    for (int mf = 0; mf < HMF; ++mf)
+                        acc[nf][mf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[kk][nf], xf[kk][mf], acc[nf][mf], 0, 0, 0);
+#ifndef HV_EMU
+            __builtin_amdgcn_s_setprio(0);
+#endif
+            if (grp == 0) wait_g1();
+            phase_end();
+            // ---- R1
+            if (more) issue_g1();
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                for (int f = 0; f < HMF; ++f)
+                    xf[kk][f] = hv_as_bf16x8(hv_ld16(xs + hv_swz<BK>(WTM * wm + 16 * HMF + 16 * f + r16, kk * 4 + quad)));
+            if (grp == 1) wait_g0(false);
+            phase_end();
+            // ---- M1 (+ the tile's epilogue after its last k-step)
+#ifndef HV_EMU
+            __builtin_amdgcn_s_setprio(1);
+#endif
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                for (int nf = 0; nf < 4; ++nf)
+#pragma unroll
+                    for (int mf = 0; mf < HMF; ++mf)
+                        acc[nf][HMF + mf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[kk][nf], xf[kk][mf], acc[nf][HMF + mf], 0, 0, 0);
+#ifndef HV_EMU
+            __builtin_amdgcn_s_setprio(0);
+#endif
+            bool epi = false;
+            if (++c_k == nk) {
+                c_k = 0;
+                int m0, n0;
+                tile_origin(c_tile, m0, n0);
+                hv_gemm_epilogue_form<NMF, PERM, STATS>(form, p, acc, m0 + WTM * wm, n0 + 64 * wn, r16, quad HV_TRACE_ARG);
+                c_tile += tstep;
+                clear_acc();
+                epi = true;
+                skip6 = true;
+            }
+            if (grp == 0) wait_g0(epi);
+            phase_end();
+        }
+        if (grp == 0) phase_end();
+        return;
+    }
     {  // prologue: k-tile 0 in readiness-group order (G0 = all of W + the X rows of the first fragment half, G1 = the rest)
         hv_static_for<WQ>([&](auto Q) __attribute__((always_inline)) { issue_w1(Q); });
         issue_x1(HvInt<0>{});
@@ -1385,6 +1535,7 @@ static int g_hv_gemm_max_grid = 512;  // tuning knob (hv_set_tuning): persistent
 //   0: the register-staged kernel for everything (A/Bs; also what problems outside the fast epilogue forms run on)
 //   6: as 1 without the wide tiles (the round-3 default; A/B)
 static int g_hv_gemm_glds = 1;
+static int g_hv_gemm_pp = 0;  // tuning knob (hv_set_tuning key 8): 1 = the ping-pong k-loop for the 256 x 256 x 64 tiles
 static int g_hv_gemm_perm = 1;  // tuning knob (hv_set_tuning key 6): 16-byte epilogue through the permuted channel assignment (A/B)
 
 // Which kernel hv_gemm_launch takes for a problem: 0 register-staged, 1 = 256x256x64, 2 = 128x128x64 (LDS-DMA); perm = the
@@ -1482,7 +1633,13 @@ static inline int hv_gemm_launch(const HvGemmParams& p, hipStream_t stream) {
         int grid = ((t256 + 7) / 8) * 8;
         if (grid > 256) grid = 256;
         if (grid > g_hv_gemm_max_grid) grid = g_hv_gemm_max_grid;
-        if (c.perm) {
+        if (g_hv_gemm_pp && c.perm) {
+            hv_note("hv_gemm_glds_kernel<256,8,256,1,perm,pp> | %s", shape);
+            hv_launch(hv_gemm_glds_kernel<256, 8, 256, 1, true, 0, true>, dim3(grid), dim3(512), stream, p, c.gm, c.form);
+        } else if (g_hv_gemm_pp) {
+            hv_note("hv_gemm_glds_kernel<256,8,256,1,pp> | %s", shape);
+            hv_launch(hv_gemm_glds_kernel<256, 8, 256, 1, false, 0, true>, dim3(grid), dim3(512), stream, p, c.gm, c.form);
+        } else if (c.perm) {
             hv_note("hv_gemm_glds_kernel<256,8,256,1,perm> | %s", shape);
             hv_launch(hv_gemm_glds_kernel<256, 8, 256, 1, true>, dim3(grid), dim3(512), stream, p, c.gm, c.form);
         } else {

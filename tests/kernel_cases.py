@@ -225,7 +225,7 @@ def case_gemm_lnfold(cx: Ctx, B=2, Fr=3, P=20, C=320, N=192, seed=2):
     return e
 
 
-def case_gemm_forms(cx: Ctx, M=520, C=128, N=192, P=128, form="ln", seed=30):
+def case_gemm_forms(cx: Ctx, M=520, C=128, N=192, P=128, form="ln", seed=30, return_output=False):
     """The epilogue forms of the denoising path as the engine launches them (hv_gemm_epilogue_fast on the LDS-DMA kernel
     when M >= 256 and the per-row table period P is a multiple of the wave sub-tile):
       ln        LayerNorm fold + bias + positional-encoding row (motion-module QKV)
@@ -291,6 +291,8 @@ def case_gemm_forms(cx: Ctx, M=520, C=128, N=192, P=128, form="ln", seed=30):
         e = nrmse(y, ref)
         tol = TOL
     assert e < tol, f"gemm form {form} nrmse {e}"
+    if return_output:  # (for bit-wise comparisons of kernel selections; the transposed tail of ln_yt rides along)
+        return torch.cat([y.float().cpu().reshape(-1), yt.float().cpu().reshape(-1)]) if form == "ln_yt" else y.float().cpu()
     return e
 
 
@@ -516,9 +518,14 @@ def case_attention(cx: Ctx, D=40, n_img=4, Lq=72, Lb=40, seed=6, check=None, q_s
         # spike = True: scores 30-45 (exp2 domain) above the rest -- past the deferred-rescale threshold 2^8, inside fp32 range;
         # spike = 8.0 (a factor): 200-360 above -- exp2 overflows against the first tile's reference, which is what sends
         # the optimistic head-dim-40 kernel (hv_attention40.h) into its careful second pass
+        # (with a factor only ONE own key per image is spiked: several keys with logits in the hundreds would compete through
+        #  cross-terms whose bf16 rounding -- 2^-9 of a logit of ~100 -- is no longer small against their gaps; that is a
+        #  property of bf16 logits, not of the branch under test)
         amp = 1.0 if spike is True else float(spike)
         for i in range(n_img):
             for j, ks in enumerate(range(min(Lq - 1, 70), Lq, 97)):
+                if amp != 1.0 and j > 0:
+                    break
                 k[i, ks] = amp * (3.0 + j % 3) * q[i, (5 + 11 * j) % Lq]
         kb[1, min(3, Lb - 1)] = amp * 4.0 * q[n_img - 1, 9 % Lq]
     sel = torch.tensor([-1] * (n_img // 2) + [1] * (n_img - n_img // 2), dtype=torch.int32)

@@ -1107,7 +1107,9 @@ __global__ __launch_bounds__(NW * 64, 2) void hv_gemm_glds_kernel(HvGemmParams p
                 else hv_vm_wait<0>();
             };
             // ---- R0
+            HV_TRACE(1);
             if (more) issue_g0();
+            HV_TRACE(2);
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
@@ -1121,7 +1123,9 @@ __global__ __launch_bounds__(NW * 64, 2) void hv_gemm_glds_kernel(HvGemmParams p
 #pragma unroll
                 for (int f = 0; f < HMF; ++f) xf[kk][f] = hv_as_bf16x8(hv_ld16(xs + hv_swz<BK>(WTM * wm + 16 * f + r16, kk * 4 + quad)));
             if (grp == 1) wait_g1();
+            HV_TRACE(3);
             phase_end();
+            HV_TRACE(4);
             // ---- M0
 #ifndef HV_EMU
             __builtin_amdgcn_s_setprio(1);
@@ -1136,8 +1140,11 @@ __global__ __launch_bounds__(NW * 64, 2) void hv_gemm_glds_kernel(HvGemmParams p
 #ifndef HV_EMU
             __builtin_amdgcn_s_setprio(0);
 #endif
+            HV_TRACE(5);
             if (grp == 0) wait_g1();
+            HV_TRACE(8);
             phase_end();
+            HV_TRACE(9);
             // ---- R1
             if (more) issue_g1();
 #pragma unroll
@@ -1146,7 +1153,9 @@ __global__ __launch_bounds__(NW * 64, 2) void hv_gemm_glds_kernel(HvGemmParams p
                 for (int f = 0; f < HMF; ++f)
                     xf[kk][f] = hv_as_bf16x8(hv_ld16(xs + hv_swz<BK>(WTM * wm + 16 * HMF + 16 * f + r16, kk * 4 + quad)));
             if (grp == 1) wait_g0(false);
+            HV_TRACE(10);
             phase_end();
+            HV_TRACE(14);
             // ---- M1 (+ the tile's epilogue after its last k-step)
 #ifndef HV_EMU
             __builtin_amdgcn_s_setprio(1);
@@ -1161,6 +1170,7 @@ __global__ __launch_bounds__(NW * 64, 2) void hv_gemm_glds_kernel(HvGemmParams p
 #ifndef HV_EMU
             __builtin_amdgcn_s_setprio(0);
 #endif
+            HV_TRACE(15);
             bool epi = false;
             if (++c_k == nk) {
                 c_k = 0;
@@ -1171,6 +1181,7 @@ __global__ __launch_bounds__(NW * 64, 2) void hv_gemm_glds_kernel(HvGemmParams p
                 clear_acc();
                 epi = true;
                 skip6 = true;
+                HV_TRACE(6);
             }
             if (grp == 0) wait_g0(epi);
             phase_end();

@@ -565,9 +565,11 @@ HV_DEV void hv_gemm_epilogue_fast_perm(const HvGemmParams& p, f32x4 (&acc)[4][NM
 
 // LayerNorm fold + GEGLU under hv_perm_row_geglu: fragments (0, 1) = h, g of output channels n_base / 2 + 8 quad + 0..3,
 // fragments (2, 3) = h, g of the next four.  N % 32 == 0 (checked by hv_gemm_launch for every GEGLU problem).
-template <int NMF>
+// KEEP (round 4, the 256 x 256 x 64 kernel on interior tiles): the packed results are handed back in `keep` instead of being
+// stored -- the kernel issues the eight stores of a lane one per half k-step of the NEXT tile (see hv_gemm_glds_kernel).
+template <int NMF, bool KEEP = false>
 HV_DEV void hv_gemm_epilogue_fast_perm_geglu(const HvGemmParams& p, f32x4 (&acc)[4][NMF], int m_base, int n_base, int r16, int quad,
-                                             const float* tab_row HV_TRACE_PARAM) {
+                                             const float* tab_row, u32x4 (*keep)[NMF] HV_TRACE_PARAM) {
     constexpr int G = NMF < HV_GEMM_EPI_G ? NMF : HV_GEMM_EPI_G;
     f32x4 add4[4], cs4[4];
     auto ld4 = [&](const float* base, unsigned byte_ofs) __attribute__((always_inline)) {
@@ -626,6 +628,11 @@ HV_DEV void hv_gemm_epilogue_fast_perm_geglu(const HvGemmParams& p, f32x4 (&acc)
     for (int mf = 0; mf < NMF; ++mf) asm volatile("" : "+v"(outp[mf][0]), "+v"(outp[mf][1]), "+v"(outp[mf][2]), "+v"(outp[mf][3]));
     __builtin_amdgcn_s_waitcnt(0x0F70);
 #endif
+    if constexpr (KEEP) {
+#pragma unroll
+        for (int mf = 0; mf < NMF; ++mf) (*keep)[mf] = outp[mf];
+        return;
+    }
     char* const yb = reinterpret_cast<char*>(p.Y);
     const int no = (n_base >> 1) + 8 * quad;  // output channel of the lane's first result
 #pragma unroll
@@ -681,7 +688,7 @@ HV_DEV void hv_gemm_epilogue_form(int form, const HvGemmParams& p, f32x4 (&acc)[
     else if (p.rowvec != nullptr) tab = p.rowvec + (long)(m_first / p.rowvec_period) * p.N;
     if constexpr (PERM) {  // the launcher sends only the plain-output forms here
         switch (form) {
-            case HV_FORM_LN_GEGLU: hv_gemm_epilogue_fast_perm_geglu<NMF>(p, acc, m_base, n_base, r16, quad, tab HV_TRACE_ARG); break;
+            case HV_FORM_LN_GEGLU: hv_gemm_epilogue_fast_perm_geglu<NMF>(p, acc, m_base, n_base, r16, quad, tab, nullptr HV_TRACE_ARG); break;
             case HV_FORM_LN: hv_gemm_epilogue_fast_perm<NMF, true, false>(p, acc, m_base, n_base, r16, quad, tab HV_TRACE_ARG); break;
             case HV_FORM_RES: hv_gemm_epilogue_fast_perm<NMF, false, true, STATS>(p, acc, m_base, n_base, r16, quad, tab HV_TRACE_ARG); break;
             default: hv_gemm_epilogue_fast_perm<NMF, false, false, STATS>(p, acc, m_base, n_base, r16, quad, tab HV_TRACE_ARG); break;
@@ -895,7 +902,9 @@ __global__ __launch_bounds__(NW * 64, 2) void hv_gemm_glds_kernel(HvGemmParams p
     static_assert(PH == 1 || PH == 2, "issue cadence");
     static_assert(XQ == 4 && WQ == 4 && WAVES_M == 2 && NMF % 2 == 0,
                   "the two-group k-loop is written for the 256 x 256 x 64 tile on 8 waves and the 128 x 128 x 64 tile on 4");
-    __shared__ __attribute__((aligned(16))) unsigned char smem[NS * SLOT];
+    // (+ 32 KiB behind the ring for the 256 x 256 x 64 kernel: staging area of the deferred output stores, see DEFER below)
+    constexpr int STAGE = (PERM && STATS == 0 && BM == 256 && NW == 8 && !PP) ? 32768 : 0;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[NS * SLOT + STAGE];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -1199,6 +1208,41 @@ __global__ __launch_bounds__(NW * 64, 2) void hv_gemm_glds_kernel(HvGemmParams p
     }
     int c_tile = first, c_k = 0, c_slot = 0;  // consumer state
     int landed = 0;  // k-steps that need no vmcnt wait (see below)
+    // Deferred output stores (round 4; GEGLU tiles of the 256 x 256 x 64 kernel).  The phase timeline shows 5200-5600 of a tile's
+    // cycles as "store issue" (profiles/r04_s6_pingpong_trace.txt): a CU's store path takes ~12 B/clk (the chip's ~6 TB/s over
+    // 256 CUs), so the 64 KB a workgroup stores per tile block its eight waves for that long while nothing is multiplied --
+    // 17 % of a K = 320 tile.  Interior GEGLU tiles therefore store only HALF of their packed results at once; the other half
+    // (four 16-byte pieces per lane, 32 KiB per workgroup) is parked in the LDS behind the ring -- lane-private slots, no
+    // barrier -- and goes out one piece per half k-step of the NEXT tile, under its MFMAs.  (Keeping the pieces in registers
+    // instead spilled: the k-loop has 256.  The counted vmcnt waits of the k-loop only become more conservative: a store
+    // issued behind a DMA instruction raises the number of younger operations, never lowers it.)
+    constexpr bool DEFER = STAGE != 0;
+    int pend_mw = 0, pend_nw = 0;  // origin of the wave's sub-tile whose pieces are parked (scalars: nothing per-lane stays live)
+    bool pend_live = false;
+    auto stage_of = [&](int slot) __attribute__((always_inline)) {  // this lane's staging slots, 1 KiB apart
+        return smem + NS * SLOT + (wave * 4 + slot) * 1024 + lane * 16;
+    };
+    auto y_off = [&](int mw, int nw, int mf) __attribute__((always_inline)) {  // byte offset in Y of the lane's piece of fragment mf
+        return (unsigned)(mw + 16 * mf + r16) * (unsigned)p.ldy * 2u + 2u * (unsigned)((nw >> 1) + 8 * quad);
+    };
+    auto pend_store = [&](auto MF) __attribute__((always_inline)) {  // piece mf (4 .. 7): LDS slot mf - 4 -> global
+        constexpr int mf = decltype(MF)::value;
+        if constexpr (DEFER) hv_st16(reinterpret_cast<char*>(p.Y) + y_off(pend_mw, pend_nw, mf), hv_ld16(stage_of(mf - 4)));
+    };
+    auto pend_drain = [&](int half) __attribute__((always_inline)) {  // one piece per half k-step: pieces 4 .. 7 over k-steps 0, 1
+        if constexpr (DEFER) {
+            if (pend_live) {
+                if (c_k == 0) { if (half == 0) pend_store(HvInt<4>{}); else pend_store(HvInt<5>{}); }
+                else if (c_k == 1) {
+                    if (half == 0) pend_store(HvInt<6>{});
+                    else {
+                        pend_store(HvInt<7>{});
+                        pend_live = false;
+                    }
+                }
+            }
+        }
+    };
     constexpr int HMF = NMF / 2;  // fragment rows per half: X DMA instruction q covers rows [BM / 4 * q, +BM / 4) = half q % 2 of wm = q / 2
     for (int s = 0; s < nsteps; ++s) {
         // Two readiness groups per k-tile, counted vmcnt, no drain.  A wave multiplies the X rows [WTM wm, +WTM) with the
@@ -1221,6 +1265,7 @@ __global__ __launch_bounds__(NW * 64, 2) void hv_gemm_glds_kernel(HvGemmParams p
         HV_TRACE(2);
         hv_barrier_raw();
         HV_TRACE(3);
+        pend_drain(0);
         const unsigned char* xs = smem + c_slot * SLOT;
         const unsigned char* ws = xs + XT;
         if (++c_slot == NS) c_slot = 0;
@@ -1269,6 +1314,7 @@ __global__ __launch_bounds__(NW * 64, 2) void hv_gemm_glds_kernel(HvGemmParams p
             else hv_vm_wait<6>();
         }
         hv_barrier_raw();
+        pend_drain(1);
         if (PH == 1 && more) issue_x1(HvInt<1>{});
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
@@ -1302,7 +1348,26 @@ __global__ __launch_bounds__(NW * 64, 2) void hv_gemm_glds_kernel(HvGemmParams p
             {
                 int m0, n0;
                 tile_origin(c_tile, m0, n0);
-                hv_gemm_epilogue_form<NMF, PERM, STATS>(form, p, acc, m0 + WTM * wm, n0 + 64 * wn, r16, quad HV_TRACE_ARG);
+                bool kept = false;
+                if constexpr (DEFER) {
+                    // interior GEGLU tile with at least two k-steps behind it in this workgroup's walk: defer half of the stores
+                    if (form == HV_FORM_LN_GEGLU && nk >= 2 && s + 1 < nsteps && m0 + BM <= p.M && n0 + BN <= p.N) {
+                        const int mw = m0 + WTM * wm, nw = n0 + 64 * wn;
+                        const float* tab = nullptr;
+                        if (p.pe != nullptr) tab = p.pe + (long)((mw / p.pe_period) % p.pe_frames) * p.N;
+                        else if (p.rowvec != nullptr) tab = p.rowvec + (long)(mw / p.rowvec_period) * p.N;
+                        u32x4 pend[NMF];
+                        hv_gemm_epilogue_fast_perm_geglu<NMF, true>(p, acc, mw, nw, r16, quad, tab, &pend HV_TRACE_ARG);
+                        pend_mw = mw, pend_nw = nw;
+#pragma unroll
+                        for (int mf = 0; mf < 4; ++mf) hv_st16(reinterpret_cast<char*>(p.Y) + y_off(mw, nw, mf), pend[mf]);
+#pragma unroll
+                        for (int mf = 4; mf < NMF; ++mf) hv_st16(stage_of(mf - 4), pend[mf]);
+                        pend_live = true;
+                        kept = true;
+                    }
+                }
+                if (!kept) hv_gemm_epilogue_form<NMF, PERM, STATS>(form, p, acc, m0 + WTM * wm, n0 + 64 * wn, r16, quad HV_TRACE_ARG);
                 landed = 1;
             }
             c_tile += tstep;

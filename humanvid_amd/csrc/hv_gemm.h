@@ -565,11 +565,9 @@ HV_DEV void hv_gemm_epilogue_fast_perm(const HvGemmParams& p, f32x4 (&acc)[4][NM
 
 // LayerNorm fold + GEGLU under hv_perm_row_geglu: fragments (0, 1) = h, g of output channels n_base / 2 + 8 quad + 0..3,
 // fragments (2, 3) = h, g of the next four.  N % 32 == 0 (checked by hv_gemm_launch for every GEGLU problem).
-// KEEP (round 4, the 256 x 256 x 64 kernel on interior tiles): the packed results are handed back in `keep` instead of being
-// stored -- the kernel issues the eight stores of a lane one per half k-step of the NEXT tile (see hv_gemm_glds_kernel).
-template <int NMF, bool KEEP = false>
+template <int NMF>
 HV_DEV void hv_gemm_epilogue_fast_perm_geglu(const HvGemmParams& p, f32x4 (&acc)[4][NMF], int m_base, int n_base, int r16, int quad,
-                                             const float* tab_row, u32x4 (*keep)[NMF] HV_TRACE_PARAM) {
+                                             const float* tab_row HV_TRACE_PARAM) {
     constexpr int G = NMF < HV_GEMM_EPI_G ? NMF : HV_GEMM_EPI_G;
     f32x4 add4[4], cs4[4];
     auto ld4 = [&](const float* base, unsigned byte_ofs) __attribute__((always_inline)) {
@@ -628,11 +626,7 @@ HV_DEV void hv_gemm_epilogue_fast_perm_geglu(const HvGemmParams& p, f32x4 (&acc)
     for (int mf = 0; mf < NMF; ++mf) asm volatile("" : "+v"(outp[mf][0]), "+v"(outp[mf][1]), "+v"(outp[mf][2]), "+v"(outp[mf][3]));
     __builtin_amdgcn_s_waitcnt(0x0F70);
 #endif
-    if constexpr (KEEP) {
-#pragma unroll
-        for (int mf = 0; mf < NMF; ++mf) (*keep)[mf] = outp[mf];
-        return;
-    }
+    HV_TRACE(9);  // (a trace build's own mark stores are outstanding here: this interval is their write-acknowledge latency)
     char* const yb = reinterpret_cast<char*>(p.Y);
     const int no = (n_base >> 1) + 8 * quad;  // output channel of the lane's first result
 #pragma unroll
@@ -640,6 +634,8 @@ HV_DEV void hv_gemm_epilogue_fast_perm_geglu(const HvGemmParams& p, f32x4 (&acc)
         const int m = m_base + 16 * mf + r16;
         if (m >= p.M || 2 * no >= p.N) continue;
         hv_st16(yb + ((unsigned)m * (unsigned)p.ldy * 2u + 2u * (unsigned)no), outp[mf]);
+        if (mf == 0) HV_TRACE(8);
+        if (mf == 3) HV_TRACE(10);
     }
     HV_TRACE(13);
     HV_TRACE(11);
@@ -688,7 +684,7 @@ HV_DEV void hv_gemm_epilogue_form(int form, const HvGemmParams& p, f32x4 (&acc)[
     else if (p.rowvec != nullptr) tab = p.rowvec + (long)(m_first / p.rowvec_period) * p.N;
     if constexpr (PERM) {  // the launcher sends only the plain-output forms here
         switch (form) {
-            case HV_FORM_LN_GEGLU: hv_gemm_epilogue_fast_perm_geglu<NMF>(p, acc, m_base, n_base, r16, quad, tab, nullptr HV_TRACE_ARG); break;
+            case HV_FORM_LN_GEGLU: hv_gemm_epilogue_fast_perm_geglu<NMF>(p, acc, m_base, n_base, r16, quad, tab HV_TRACE_ARG); break;
             case HV_FORM_LN: hv_gemm_epilogue_fast_perm<NMF, true, false>(p, acc, m_base, n_base, r16, quad, tab HV_TRACE_ARG); break;
             case HV_FORM_RES: hv_gemm_epilogue_fast_perm<NMF, false, true, STATS>(p, acc, m_base, n_base, r16, quad, tab HV_TRACE_ARG); break;
             default: hv_gemm_epilogue_fast_perm<NMF, false, false, STATS>(p, acc, m_base, n_base, r16, quad, tab HV_TRACE_ARG); break;
@@ -890,7 +886,7 @@ __global__ __launch_bounds__(256, 2) void hv_gemm_kernel(HvGemmParams p) {
 //   PERM: the permuted channel assignment of a wave's 64-channel block (hv_perm_row) for the plain-output forms.
 //   STATS (with PERM): the plain / residual epilogue also leaves GroupNorm (1, p.gn_part) or LayerNorm (2, p.ln_part) partial
 //   statistics of its tile.
-template <int BN, int NW, int BM, int PH, bool PERM = false, int STATS = 0, bool PP = false>
+template <int BN, int NW, int BM, int PH, bool PERM = false, int STATS = 0>
 __global__ __launch_bounds__(NW * 64, 2) void hv_gemm_glds_kernel(HvGemmParams p, int gm, int form) {
     constexpr int BK = 64, NS = 2;
     constexpr int WAVES_N = BN / 64, WAVES_M = NW / WAVES_N;
@@ -902,9 +898,7 @@ __global__ __launch_bounds__(NW * 64, 2) void hv_gemm_glds_kernel(HvGemmParams p
     static_assert(PH == 1 || PH == 2, "issue cadence");
     static_assert(XQ == 4 && WQ == 4 && WAVES_M == 2 && NMF % 2 == 0,
                   "the two-group k-loop is written for the 256 x 256 x 64 tile on 8 waves and the 128 x 128 x 64 tile on 4");
-    // (+ 32 KiB behind the ring for the 256 x 256 x 64 kernel: staging area of the deferred output stores, see DEFER below)
-    constexpr int STAGE = (PERM && STATS == 0 && BM == 256 && NW == 8 && !PP) ? 32768 : 0;
-    __shared__ __attribute__((aligned(16))) unsigned char smem[NS * SLOT + STAGE];
+    __shared__ __attribute__((aligned(16))) unsigned char smem[NS * SLOT];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -1037,167 +1031,6 @@ __global__ __launch_bounds__(NW * 64, 2) void hv_gemm_glds_kernel(HvGemmParams p
 #ifdef HV_GEMM_TRACE
     int hv_ti = 0;
 #endif
-    if constexpr (PP) {
-        // ---- PING-PONG k-loop (round 4; 256 x 256 x 64 on 8 waves only).  The loop below keeps the two waves of a SIMD in
-        // lockstep: both read fragments, then both multiply -- the matrix pipe idles while they read and the LDS idles while
-        // they multiply (profiles/r03_gemm_trace.txt: 43 % MFMA-busy inside the k-loop).  Here a k-step is FOUR phases
-        //     R0: W fragments + X fragments of the first row half (16 ds_read_b128)    M0: their 32 MFMAs
-        //     R1: X fragments of the second row half (8 reads)                         M1: their 32 MFMAs
-        // separated by raw barriers, and waves 4-7 (the second wave of every SIMD) run ONE PHASE BEHIND waves 0-3: while one
-        // wave of a SIMD multiplies, the other reads (and issues its LDS-DMA).  Global phase t = 4 s + phi: group A executes
-        // phase t of its program, group B what A executed at t - 1 (B passes one extra barrier at the start, A one at the end).
-        // LDS-DMA (inline-asm form: hipcc does not see it, every wait below is by hand): a wave issues G0(s+1) = {W q0-3,
-        // X q0, X q2} in its R0(s) and G1(s+1) = {X q1, X q3} in its R1(s), in that order.  Hazards, by global phase:
-        //   readers  W / Xa of tile s: A at 4s, B at 4s+1;  Xb of tile s: A at 4s+2, B at 4s+3
-        //   writers  G0(s+1) -> W / Xa of slot (s+1)%2 (last read: tile s-1, B at 4s-3): issued A 4s, B 4s+1       (WAR ok)
-        //            G1(s+1) -> Xb of that slot (last read: B at 4s-1): issued A 4s+2, B 4s+3                      (WAR ok)
-        //   G0(s+1) must be visible at 4s+4: every wave waits for its own share before the barrier that ends phase 4s+3
-        //            = A's M1(s), B's R1(s): vmcnt(2) (the two G1(s+1) behind it stay in flight)
-        //   G1(s+1) must be visible at 4s+6: wait before the barrier that ends phase 4s+5 = A's M0(s+1), B's R0(s+1):
-        //            vmcnt(6) (the six G0(s+2) behind it stay in flight)
-        // After an epilogue (it waits for every load before its first store) whatever was issued before it has landed: the
-        // wait that would come next is skipped instead of waiting for the epilogue's stores to be acknowledged.
-        static_assert(NW == 8 && BM == 256 && BN == 256 && NMF == 8, "ping-pong k-loop: 256 x 256 x 64 on 8 waves");
-        const int grp = wave >> 2;  // 0: waves 0-3 (group A), 1: waves 4-7 (group B) -- one wave of each per SIMD
-        auto dma_x = [&](auto Q) __attribute__((always_inline)) {
-            constexpr int q = decltype(Q)::value;
-            unsigned& o = hv_pick4<q>(xo0, xo1, xo2, xo3);
-            hv_glds16_s(xbase, o, smem + i_slot * SLOT + (wave + NW * q) * 1024);
-            o += BK * 2;
-        };
-        auto dma_w = [&](auto Q) __attribute__((always_inline)) {
-            constexpr int q = decltype(Q)::value;
-            unsigned& o = hv_pick4<q>(wo0, wo1, wo2, wo3);
-            hv_glds16_s(wbase, o, smem + i_slot * SLOT + XT + (wave + NW * q) * 1024);
-            o += BK * 2;
-        };
-        auto issue_g0 = [&]() __attribute__((always_inline)) {
-            hv_static_for<WQ>([&](auto Q) __attribute__((always_inline)) { dma_w(Q); });
-            dma_x(HvInt<0>{});
-            dma_x(HvInt<2>{});
-        };
-        auto issue_g1 = [&]() __attribute__((always_inline)) {
-            dma_x(HvInt<1>{});
-            dma_x(HvInt<3>{});
-            issue_advance();
-        };
-        auto fence = [&]() __attribute__((always_inline)) {
-#ifndef HV_EMU
-            __builtin_amdgcn_sched_barrier(0);  // nothing moves across a phase boundary at compile time either
-#endif
-        };
-        auto phase_end = [&]() __attribute__((always_inline)) {
-            fence();
-            hv_barrier_raw();
-            fence();
-        };
-        issue_g0();
-        issue_g1();
-        hv_vm_wait<0>();
-        phase_end();               // k-tile 0 visible
-        if (grp == 1) phase_end();  // group B runs one phase behind
-        int c_tile = first, c_k = 0, c_slot = 0;
-        bool skip6 = false;  // an epilogue has run since the last G1 wait
-        constexpr int HMF = 4;
-        bf16x8 wf[2][4], xf[2][HMF];
-        for (int s = 0; s < nsteps; ++s) {
-            const bool more = s + 1 < nsteps;
-            const unsigned char* xs = smem + c_slot * SLOT;
-            const unsigned char* ws = xs + XT;
-            if (++c_slot == NS) c_slot = 0;
-            auto wait_g1 = [&]() __attribute__((always_inline)) {  // G1 of this step's own k-tile ... (see the table above)
-                if (skip6) skip6 = false;
-                else if (more) hv_vm_wait<6>();
-                else hv_vm_wait<0>();
-            };
-            auto wait_g0 = [&](bool landed) __attribute__((always_inline)) {  // G0 of the next k-tile
-                if (landed) return;
-                if (more) hv_vm_wait<2>();
-                else hv_vm_wait<0>();
-            };
-            // ---- R0
-            HV_TRACE(1);
-            if (more) issue_g0();
-            HV_TRACE(2);
-#pragma unroll
-            for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-                for (int f = 0; f < 4; ++f) {
-                    const int wrow = !PERM ? 16 * f + r16 : (form == HV_FORM_LN_GEGLU ? hv_perm_row_geglu(f, r16) : hv_perm_row(f, r16));
-                    wf[kk][f] = hv_as_bf16x8(hv_ld16(ws + (PERM ? hv_swz_wperm(64 * wn + wrow, kk * 4 + quad)
-                                                                : hv_swz<BK>(64 * wn + wrow, kk * 4 + quad))));
-                }
-#pragma unroll
-            for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-                for (int f = 0; f < HMF; ++f) xf[kk][f] = hv_as_bf16x8(hv_ld16(xs + hv_swz<BK>(WTM * wm + 16 * f + r16, kk * 4 + quad)));
-            if (grp == 1) wait_g1();
-            HV_TRACE(3);
-            phase_end();
-            HV_TRACE(4);
-            // ---- M0
-#ifndef HV_EMU
-            __builtin_amdgcn_s_setprio(1);
-#endif
-#pragma unroll
-            for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-                for (int nf = 0; nf < 4; ++nf)
-#pragma unroll
-                    for (int mf = 0; mf < HMF; ++mf)
-                        acc[nf][mf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[kk][nf], xf[kk][mf], acc[nf][mf], 0, 0, 0);
-#ifndef HV_EMU
-            __builtin_amdgcn_s_setprio(0);
-#endif
-            HV_TRACE(5);
-            if (grp == 0) wait_g1();
-            HV_TRACE(8);
-            phase_end();
-            HV_TRACE(9);
-            // ---- R1
-            if (more) issue_g1();
-#pragma unroll
-            for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-                for (int f = 0; f < HMF; ++f)
-                    xf[kk][f] = hv_as_bf16x8(hv_ld16(xs + hv_swz<BK>(WTM * wm + 16 * HMF + 16 * f + r16, kk * 4 + quad)));
-            if (grp == 1) wait_g0(false);
-            HV_TRACE(10);
-            phase_end();
-            HV_TRACE(14);
-            // ---- M1 (+ the tile's epilogue after its last k-step)
-#ifndef HV_EMU
-            __builtin_amdgcn_s_setprio(1);
-#endif
-#pragma unroll
-            for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-                for (int nf = 0; nf < 4; ++nf)
-#pragma unroll
-                    for (int mf = 0; mf < HMF; ++mf)
-                        acc[nf][HMF + mf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[kk][nf], xf[kk][mf], acc[nf][HMF + mf], 0, 0, 0);
-#ifndef HV_EMU
-            __builtin_amdgcn_s_setprio(0);
-#endif
-            HV_TRACE(15);
-            bool epi = false;
-            if (++c_k == nk) {
-                c_k = 0;
-                int m0, n0;
-                tile_origin(c_tile, m0, n0);
-                hv_gemm_epilogue_form<NMF, PERM, STATS>(form, p, acc, m0 + WTM * wm, n0 + 64 * wn, r16, quad HV_TRACE_ARG);
-                c_tile += tstep;
-                clear_acc();
-                epi = true;
-                skip6 = true;
-                HV_TRACE(6);
-            }
-            if (grp == 0) wait_g0(epi);
-            phase_end();
-        }
-        if (grp == 0) phase_end();
-        return;
-    }
     {  // prologue: k-tile 0 in readiness-group order (G0 = all of W + the X rows of the first fragment half, G1 = the rest)
         hv_static_for<WQ>([&](auto Q) __attribute__((always_inline)) { issue_w1(Q); });
         issue_x1(HvInt<0>{});
@@ -1208,41 +1041,6 @@ __global__ __launch_bounds__(NW * 64, 2) void hv_gemm_glds_kernel(HvGemmParams p
     }
     int c_tile = first, c_k = 0, c_slot = 0;  // consumer state
     int landed = 0;  // k-steps that need no vmcnt wait (see below)
-    // Deferred output stores (round 4; GEGLU tiles of the 256 x 256 x 64 kernel).  The phase timeline shows 5200-5600 of a tile's
-    // cycles as "store issue" (profiles/r04_s6_pingpong_trace.txt): a CU's store path takes ~12 B/clk (the chip's ~6 TB/s over
-    // 256 CUs), so the 64 KB a workgroup stores per tile block its eight waves for that long while nothing is multiplied --
-    // 17 % of a K = 320 tile.  Interior GEGLU tiles therefore store only HALF of their packed results at once; the other half
-    // (four 16-byte pieces per lane, 32 KiB per workgroup) is parked in the LDS behind the ring -- lane-private slots, no
-    // barrier -- and goes out one piece per half k-step of the NEXT tile, under its MFMAs.  (Keeping the pieces in registers
-    // instead spilled: the k-loop has 256.  The counted vmcnt waits of the k-loop only become more conservative: a store
-    // issued behind a DMA instruction raises the number of younger operations, never lowers it.)
-    constexpr bool DEFER = STAGE != 0;
-    int pend_mw = 0, pend_nw = 0;  // origin of the wave's sub-tile whose pieces are parked (scalars: nothing per-lane stays live)
-    bool pend_live = false;
-    auto stage_of = [&](int slot) __attribute__((always_inline)) {  // this lane's staging slots, 1 KiB apart
-        return smem + NS * SLOT + (wave * 4 + slot) * 1024 + lane * 16;
-    };
-    auto y_off = [&](int mw, int nw, int mf) __attribute__((always_inline)) {  // byte offset in Y of the lane's piece of fragment mf
-        return (unsigned)(mw + 16 * mf + r16) * (unsigned)p.ldy * 2u + 2u * (unsigned)((nw >> 1) + 8 * quad);
-    };
-    auto pend_store = [&](auto MF) __attribute__((always_inline)) {  // piece mf (4 .. 7): LDS slot mf - 4 -> global
-        constexpr int mf = decltype(MF)::value;
-        if constexpr (DEFER) hv_st16(reinterpret_cast<char*>(p.Y) + y_off(pend_mw, pend_nw, mf), hv_ld16(stage_of(mf - 4)));
-    };
-    auto pend_drain = [&](int half) __attribute__((always_inline)) {  // one piece per half k-step: pieces 4 .. 7 over k-steps 0, 1
-        if constexpr (DEFER) {
-            if (pend_live) {
-                if (c_k == 0) { if (half == 0) pend_store(HvInt<4>{}); else pend_store(HvInt<5>{}); }
-                else if (c_k == 1) {
-                    if (half == 0) pend_store(HvInt<6>{});
-                    else {
-                        pend_store(HvInt<7>{});
-                        pend_live = false;
-                    }
-                }
-            }
-        }
-    };
     constexpr int HMF = NMF / 2;  // fragment rows per half: X DMA instruction q covers rows [BM / 4 * q, +BM / 4) = half q % 2 of wm = q / 2
     for (int s = 0; s < nsteps; ++s) {
         // Two readiness groups per k-tile, counted vmcnt, no drain.  A wave multiplies the X rows [WTM wm, +WTM) with the
@@ -1265,7 +1063,6 @@ __global__ __launch_bounds__(NW * 64, 2) void hv_gemm_glds_kernel(HvGemmParams p
         HV_TRACE(2);
         hv_barrier_raw();
         HV_TRACE(3);
-        pend_drain(0);
         const unsigned char* xs = smem + c_slot * SLOT;
         const unsigned char* ws = xs + XT;
         if (++c_slot == NS) c_slot = 0;
@@ -1314,7 +1111,6 @@ __global__ __launch_bounds__(NW * 64, 2) void hv_gemm_glds_kernel(HvGemmParams p
             else hv_vm_wait<6>();
         }
         hv_barrier_raw();
-        pend_drain(1);
         if (PH == 1 && more) issue_x1(HvInt<1>{});
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
@@ -1348,26 +1144,7 @@ __global__ __launch_bounds__(NW * 64, 2) void hv_gemm_glds_kernel(HvGemmParams p
             {
                 int m0, n0;
                 tile_origin(c_tile, m0, n0);
-                bool kept = false;
-                if constexpr (DEFER) {
-                    // interior GEGLU tile with at least two k-steps behind it in this workgroup's walk: defer half of the stores
-                    if (form == HV_FORM_LN_GEGLU && nk >= 2 && s + 1 < nsteps && m0 + BM <= p.M && n0 + BN <= p.N) {
-                        const int mw = m0 + WTM * wm, nw = n0 + 64 * wn;
-                        const float* tab = nullptr;
-                        if (p.pe != nullptr) tab = p.pe + (long)((mw / p.pe_period) % p.pe_frames) * p.N;
-                        else if (p.rowvec != nullptr) tab = p.rowvec + (long)(mw / p.rowvec_period) * p.N;
-                        u32x4 pend[NMF];
-                        hv_gemm_epilogue_fast_perm_geglu<NMF, true>(p, acc, mw, nw, r16, quad, tab, &pend HV_TRACE_ARG);
-                        pend_mw = mw, pend_nw = nw;
-#pragma unroll
-                        for (int mf = 0; mf < 4; ++mf) hv_st16(reinterpret_cast<char*>(p.Y) + y_off(mw, nw, mf), pend[mf]);
-#pragma unroll
-                        for (int mf = 4; mf < NMF; ++mf) hv_st16(stage_of(mf - 4), pend[mf]);
-                        pend_live = true;
-                        kept = true;
-                    }
-                }
-                if (!kept) hv_gemm_epilogue_form<NMF, PERM, STATS>(form, p, acc, m0 + WTM * wm, n0 + 64 * wn, r16, quad HV_TRACE_ARG);
+                hv_gemm_epilogue_form<NMF, PERM, STATS>(form, p, acc, m0 + WTM * wm, n0 + 64 * wn, r16, quad HV_TRACE_ARG);
                 landed = 1;
             }
             c_tile += tstep;
@@ -1611,7 +1388,6 @@ static int g_hv_gemm_max_grid = 512;  // tuning knob (hv_set_tuning): persistent
 //   0: the register-staged kernel for everything (A/Bs; also what problems outside the fast epilogue forms run on)
 //   6: as 1 without the wide tiles (the round-3 default; A/B)
 static int g_hv_gemm_glds = 1;
-static int g_hv_gemm_pp = 0;  // tuning knob (hv_set_tuning key 8): 1 = the ping-pong k-loop for the 256 x 256 x 64 tiles
 static int g_hv_gemm_perm = 1;  // tuning knob (hv_set_tuning key 6): 16-byte epilogue through the permuted channel assignment (A/B)
 
 // Which kernel hv_gemm_launch takes for a problem: 0 register-staged, 1 = 256x256x64, 2 = 128x128x64 (LDS-DMA); perm = the
@@ -1709,13 +1485,7 @@ static inline int hv_gemm_launch(const HvGemmParams& p, hipStream_t stream) {
         int grid = ((t256 + 7) / 8) * 8;
         if (grid > 256) grid = 256;
         if (grid > g_hv_gemm_max_grid) grid = g_hv_gemm_max_grid;
-        if (g_hv_gemm_pp && c.perm) {
-            hv_note("hv_gemm_glds_kernel<256,8,256,1,perm,pp> | %s", shape);
-            hv_launch(hv_gemm_glds_kernel<256, 8, 256, 1, true, 0, true>, dim3(grid), dim3(512), stream, p, c.gm, c.form);
-        } else if (g_hv_gemm_pp) {
-            hv_note("hv_gemm_glds_kernel<256,8,256,1,pp> | %s", shape);
-            hv_launch(hv_gemm_glds_kernel<256, 8, 256, 1, false, 0, true>, dim3(grid), dim3(512), stream, p, c.gm, c.form);
-        } else if (c.perm) {
+        if (c.perm) {
             hv_note("hv_gemm_glds_kernel<256,8,256,1,perm> | %s", shape);
             hv_launch(hv_gemm_glds_kernel<256, 8, 256, 1, true>, dim3(grid), dim3(512), stream, p, c.gm, c.form);
         } else {

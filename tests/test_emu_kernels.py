@@ -83,31 +83,6 @@ def test_gemm_fast_epilogue_forms(cx):
         cx.lib.call("hv_set_tuning", 2, 512)
 
 
-def test_gemm_ping_pong_k_loop(cx):
-    """256 x 256 x 64 tiles with the ping-pong k-loop (tuning key 8: the two waves of a SIMD one phase apart) give the same
-    results as the lockstep loop, bit for bit: every output form, one and several k-steps per tile, several tiles per
-    persistent workgroup (the epilogue / skipped-wait paths), ragged edges, two-source K, the grouped raster"""
-    cx.lib.call("hv_set_tuning", 2, 8)
-    cx.lib.call("hv_set_tuning", 3, 2)
-    try:
-        outs = {}
-        for pp in (0, 1):
-            cx.lib.call("hv_set_tuning", 8, pp)
-            res = []
-            for form in ("ln", "ln_yt", "ln_geglu", "res", "plain"):
-                res.append(kc.case_gemm_forms(cx, M=900, C=192, N=320, P=128, form=form, seed=34, return_output=True))
-            res.append(kc.case_gemm_forms(cx, M=2304, C=64, N=512, P=256, form="res", seed=35, return_output=True))   # one k-step per tile
-            res.append(kc.case_gemm_forms(cx, M=1024, C=320, N=2560, P=256, form="ln_geglu", seed=36, return_output=True))  # wide N: grouped raster
-            kc.case_gemm(cx, M=520, N=320, K=192, seed=22, two_source=True)
-            outs[pp] = res
-        for a_, b_ in zip(outs[0], outs[1]):
-            assert torch.equal(a_, b_)
-    finally:
-        cx.lib.call("hv_set_tuning", 8, 0)
-        cx.lib.call("hv_set_tuning", 3, 1)
-        cx.lib.call("hv_set_tuning", 2, 512)
-
-
 def test_gemm_wide_tile_kernel(cx):
     """hv_gemm_wide_kernel (256 x 320 x 64 tiles: the default for N = 320, K >= 640, M % 256 == 0, plain-output forms with a
     bias): its three output forms, several tiles per persistent workgroup, a table row per 32-row wave block; problems it does not take (ragged M, K < 640, statistics wanted) run on the

@@ -48,26 +48,6 @@ def test_gemm_wide_tile_kernel(cx):
     kc.case_ln_parts_gemm(cx, M=36864, C=320, K=640, seed=84)
 
 
-def test_gemm_ping_pong_k_loop(cx):
-    """the ping-pong k-loop of the 256 x 256 x 64 tiles (tuning key 8: the two waves of a SIMD one phase apart) against the
-    lockstep loop at the step's shapes: bit-identical outputs, and bit-identical again on repeated launches (a hand-placed
-    wait or barrier that is one phase off shows up as a difference that comes and goes)"""
-    shapes = [dict(M=73728, C=320, N=1280, P=6144, form="ln_geglu", seed=91),     # level-0 ff1 (a quarter of the rows)
-              dict(M=73728, C=320, N=960, P=6144, form="ln_yt", seed=92),         # level-0 QKV with the transposed V tail
-              dict(M=73728, C=640, N=1920, P=1536, form="ln", seed=93),           # level-1 temporal QKV
-              dict(M=18432, C=1280, N=5120, P=384, form="ln_geglu", seed=94)]     # level-2 ff1: 20 k-steps per tile
-    try:
-        for kw in shapes:
-            cx.lib.call("hv_set_tuning", 8, 0)
-            want = kc.case_gemm_forms(cx, return_output=True, **kw)
-            cx.lib.call("hv_set_tuning", 8, 1)
-            for rep in range(3):
-                got = kc.case_gemm_forms(cx, return_output=True, **kw)
-                assert torch.equal(got, want), (kw, rep, float((got - want).abs().max()))
-    finally:
-        cx.lib.call("hv_set_tuning", 8, 0)
-
-
 def test_gemm_epilogue_forms(cx):
     """the epilogue forms the engine launches (hv_gemm_epilogue_fast on the LDS-DMA kernel), every LDS-DMA tile shape"""
     for form in ("ln", "ln_yt", "ln_geglu", "res", "plain"):

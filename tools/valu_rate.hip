@@ -1,0 +1,158 @@
+// Issue cost of the softmax instructions of the attention kernels on one SIMD, alone and beside MFMAs (gfx950):
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/valu_rate.hip -o tools/bin/valu_rate && tools/bin/valu_rate
+// One workgroup of W waves on one CU (W = 4: one wave per SIMD, 8: two, 16: four); every wave runs REP iterations of an
+// unrolled block of N independent instructions of one kind between two s_memtime reads; prints shader cycles per
+// wave-instruction per SIMD (= cycles x SIMDs / instructions issued on the CU).
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <vector>
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+
+template <int KIND>
+__global__ void rate_kernel(unsigned long long* out, int rep, float seed) {
+    float v[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) v[i] = seed + threadIdx.x * 1e-3f + i;
+    unsigned u[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) u[i] = threadIdx.x * 16 + i;
+    f32x16 acc, acc2;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = acc2[i] = 0.f;
+    bf16x8 a, b;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) a[i] = b[i] = (short)(0x3c00 + threadIdx.x);
+    __syncthreads();
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    for (int r = 0; r < rep; ++r) {
+        if (KIND == 0) {  // 16 x v_exp_f32
+#pragma unroll
+            for (int i = 0; i < 16; ++i) asm volatile("v_exp_f32 %0, %0" : "+v"(v[i]));
+        } else if (KIND == 1) {  // 16 x v_mul_f32
+#pragma unroll
+            for (int i = 0; i < 16; ++i) asm volatile("v_mul_f32 %0, %0, %0" : "+v"(v[i]));
+        } else if (KIND == 2) {  // 8 x v_cvt_pk_bf16_f32
+#pragma unroll
+            for (int i = 0; i < 8; ++i) asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(u[i]) : "v"(v[2 * i]), "v"(v[2 * i + 1]));
+        } else if (KIND == 3) {  // 8 x v_permlane16_swap
+#pragma unroll
+            for (int i = 0; i < 8; ++i) asm volatile("v_permlane16_swap_b32 %0, %1" : "+v"(u[2 * i]), "+v"(u[2 * i + 1]));
+        } else if (KIND == 4) {  // 8 x v_pk_mul_f32
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                asm volatile("v_pk_mul_f32 %0, %0, %0" : "+v"(*reinterpret_cast<double*>(&v[2 * i])));
+        } else if (KIND == 5) {  // 2 x mfma 32x32x16 alone
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
+            acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc2, 0, 0, 0);
+        } else if (KIND >= 10 && KIND < 20) {  // 2 x mfma 32x32x16 with (KIND - 10) v_exp_f32 behind each
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < KIND - 10; ++i) asm volatile("v_exp_f32 %0, %0" : "+v"(v[i]));
+            acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc2, 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < KIND - 10; ++i) asm volatile("v_exp_f32 %0, %0" : "+v"(v[8 + i]));
+        } else if (KIND >= 20 && KIND < 30) {  // 2 x mfma with (KIND - 20) v_mul_f32 behind each
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < KIND - 20; ++i) asm volatile("v_mul_f32 %0, %0, %0" : "+v"(v[i]));
+            acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc2, 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < KIND - 20; ++i) asm volatile("v_mul_f32 %0, %0, %0" : "+v"(v[8 + i]));
+        }
+    }
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) s += v[i] + acc[i] + acc2[i] + (float)u[i];
+    if (threadIdx.x % 64 == 0) out[threadIdx.x / 64] = t1 - t0;
+    if (s == 12345.678f) out[63] = 1;
+}
+
+// waves of a SIMD in different phases: even waves (of the SIMD) run MFMAs while odd waves run exps -- the cross-wave overlap
+// the 4-waves-per-SIMD attention kernel relies on.  A wave's SIMD is (wave id % 4) on gfx950's cyclic dispatch, so waves
+// w and w + 4 share one: w < 4 -> MFMA role, w >= 4 -> exp role.
+__global__ void mix_kernel(unsigned long long* out, int rep, int n_mfma, int n_exp) {
+    float v[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) v[i] = threadIdx.x * 1e-3f + i;
+    f32x16 acc, acc2;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = acc2[i] = 0.f;
+    bf16x8 a, b;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) a[i] = b[i] = (short)(0x3c00 + threadIdx.x);
+    const int wave = threadIdx.x / 64;
+    __syncthreads();
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    if (wave < 4) {
+        for (int r = 0; r < rep * n_mfma; ++r) {
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
+            acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc2, 0, 0, 0);
+        }
+    } else {
+        for (int r = 0; r < rep * n_exp; ++r) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) asm volatile("v_exp_f32 %0, %0" : "+v"(v[i]));
+        }
+    }
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) s += v[i] + acc[i] + acc2[i];
+    if (threadIdx.x % 64 == 0) out[wave] = t1 - t0;
+    if (s == 12345.678f) out[63] = 1;
+}
+
+template <int KIND>
+static void run(const char* what, int per_iter, int waves) {
+    unsigned long long* d;
+    hipMalloc(&d, 64 * 8);
+    const int rep = 4096;
+    rate_kernel<KIND><<<1, waves * 64>>>(d, rep, 0.5f);
+    rate_kernel<KIND><<<1, waves * 64>>>(d, rep, 0.5f);
+    hipDeviceSynchronize();
+    std::vector<unsigned long long> h(64);
+    hipMemcpy(h.data(), d, 64 * 8, hipMemcpyDeviceToHost);
+    unsigned long long mx = 0;
+    for (int w = 0; w < waves; ++w) mx = h[w] > mx ? h[w] : mx;
+    const double per_simd = (double)waves / 4 * rep * per_iter;
+    printf("%-44s %2d waves/CU: %6.2f cycles per wave-instruction per SIMD (block of %d: %.1f)\n", what, waves, mx / per_simd, per_iter,
+           mx / per_simd * per_iter);
+    hipFree(d);
+}
+
+int main() {
+    for (int waves : {4, 8, 16}) {
+        run<0>("v_exp_f32", 16, waves);
+        run<1>("v_mul_f32", 16, waves);
+        run<2>("v_cvt_pk_bf16_f32", 8, waves);
+        run<3>("v_permlane16_swap_b32", 8, waves);
+        run<4>("v_pk_mul_f32", 8, waves);
+        run<5>("v_mfma_f32_32x32x16_bf16", 2, waves);
+    }
+    for (int waves : {4, 8}) {
+        run<12>("mfma + 2 v_exp_f32 (cycles per MFMA)", 2, waves);
+        run<14>("mfma + 4 v_exp_f32 (cycles per MFMA)", 2, waves);
+        run<16>("mfma + 6 v_exp_f32 (cycles per MFMA)", 2, waves);
+        run<18>("mfma + 8 v_exp_f32 (cycles per MFMA)", 2, waves);
+        run<24>("mfma + 4 v_mul_f32 (cycles per MFMA)", 2, waves);
+        run<26>("mfma + 6 v_mul_f32 (cycles per MFMA)", 2, waves);
+        run<28>("mfma + 8 v_mul_f32 (cycles per MFMA)", 2, waves);
+    }
+    // cross-wave: waves 0-3 run 2 n MFMAs per round, waves 4-7 (same SIMDs) 16 m exps per round
+    for (int m : {0, 2, 4, 8}) {
+        unsigned long long* d;
+        hipMalloc(&d, 64 * 8);
+        const int rep = 1024, n = 4;
+        mix_kernel<<<1, 512>>>(d, rep, n, m);
+        mix_kernel<<<1, 512>>>(d, rep, n, m);
+        hipDeviceSynchronize();
+        std::vector<unsigned long long> h(64);
+        hipMemcpy(h.data(), d, 64 * 8, hipMemcpyDeviceToHost);
+        printf("cross-wave: wave A %d MFMAs, wave B %d v_exp_f32 per round: A %.0f cycles per round (alone %d), B %.0f\n", 2 * n, 16 * m,
+               (double)h[0] / rep, 64 * n, (double)h[4] / rep);
+        hipFree(d);
+    }
+    return 0;
+}

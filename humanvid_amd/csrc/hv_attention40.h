@@ -36,6 +36,12 @@
 //   wave-instruction (10.6-11.4 beside another wave's MFMA stream, which is not slowed), v_cvt_pk_bf16_f32 4.8,
 //   v_permlane16_swap 8.6, plain VALU 2.5; per 64-key tile and wave that is ~410-540 VALU cycles against 384 matrix-pipe
 //   cycles -- this kernel is bound by its softmax VALU work, and 778 cycles per wave-tile and SIMD are what it takes now.)
+//  (What bounds it, profiles/r04_s14_attn40_stream_model.txt: a synthetic wave with exactly this kernel's per-tile instruction
+//   stream and no memory side -- 6 + 12 MFMAs, 32 v_exp_f32, 16 packs, 8 lane-row swaps, dependent as here -- runs at 603-609
+//   cycles per wave-tile and SIMD with four waves per SIMD (its VALU part alone: 530; its MFMAs alone: 384), this kernel at
+//   ~780: 78 % of what the arithmetic alone allows, the rest is the tile barrier, LDS latency and staging.  One workgroup per CU
+//   instead of two: 4.91 instead of 3.85 ms.  Truncating instead of rounding the probabilities (v_perm_b32, half the issue
+//   time of the pack): no change, reverted.)
 //  (Wave priority: raising the MFMA sections (s_setprio 1, the generic kernel's -1.7 %), flat, raising the softmax section:
 //   3.845 / 3.802 / 3.910 ms on one box, profiles/r04_s13_attn40_prio.txt -- flat it is.)
 // The reference maximum therefore lives in bf16 (it is an element of the Q operand); the rescale factors are computed from

@@ -23,6 +23,10 @@ __global__ void rate_kernel(unsigned long long* out, int rep, float seed) {
     bf16x8 a, b;
 #pragma unroll
     for (int i = 0; i < 8; ++i) a[i] = b[i] = (short)(0x3c00 + threadIdx.x);
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    f32x4 o4[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) o4[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     __syncthreads();
     const unsigned long long t0 = __builtin_amdgcn_s_memtime();
     for (int r = 0; r < rep; ++r) {
@@ -45,6 +49,13 @@ __global__ void rate_kernel(unsigned long long* out, int rep, float seed) {
         } else if (KIND == 5) {  // 2 x mfma 32x32x16 alone
             acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
             acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc2, 0, 0, 0);
+        } else if (KIND == 6) {  // 2 x mfma 32x32x16, ONE accumulation chain
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
+        } else if (KIND == 7 || KIND == 8 || KIND == 9) {  // 6 x mfma 16x16x32 over 1 / 2 / 6 accumulation chains
+            constexpr int NC = KIND == 7 ? 1 : (KIND == 8 ? 2 : 6);
+#pragma unroll
+            for (int i = 0; i < 6; ++i) o4[i % NC] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, o4[i % NC], 0, 0, 0);
         } else if (KIND >= 10 && KIND < 20) {  // 2 x mfma 32x32x16 with (KIND - 10) v_exp_f32 behind each
             acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
 #pragma unroll
@@ -65,6 +76,8 @@ __global__ void rate_kernel(unsigned long long* out, int rep, float seed) {
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < 16; ++i) s += v[i] + acc[i] + acc2[i] + (float)u[i];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) s += o4[i][0] + o4[i][1] + o4[i][2] + o4[i][3];
     if (threadIdx.x % 64 == 0) out[threadIdx.x / 64] = t1 - t0;
     if (s == 12345.678f) out[63] = 1;
 }
@@ -104,6 +117,99 @@ __global__ void mix_kernel(unsigned long long* out, int rep, int n_mfma, int n_e
     if (s == 12345.678f) out[63] = 1;
 }
 
+
+// The instruction stream of one hv_attention40 wave-tile without its memory side: 6 MFMA 32x32x16 (two chains of 3), 32 v_exp_f32
+// on their results, 16 packs, 8 lane-row swaps, 12 MFMA 16x16x32 on the swapped pairs.  One workgroup of 8 or 16 waves per CU
+// (two or four such waves per SIMD), optionally a workgroup barrier per iteration.  Pipe work per wave-iteration:
+// 384 matrix cycles, ~410 VALU cycles.
+template <int BAR, int PART>
+__global__ __launch_bounds__(1024, 4) void attn_like_kernel(unsigned long long* out, int rep) {
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    bf16x8 a, b;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) a[i] = b[i] = (short)(0x3c00 + threadIdx.x);
+    f32x4 o4[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) o4[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x16 z;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) z[i] = 0.f;
+    __syncthreads();
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    for (int r = 0; r < rep; ++r) {
+        f32x16 s0 = z, s1 = z;
+        if (PART & 1) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, s0, 0, 0, 0);
+#pragma unroll
+            for (int k = 0; k < 3; ++k) s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, s1, 0, 0, 0);
+        }
+        unsigned w[2][8];
+        if (PART & 2) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                asm volatile("v_exp_f32 %0, %0" : "+v"(s0[i]));
+                asm volatile("v_exp_f32 %0, %0" : "+v"(s1[i]));
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(w[0][j]) : "v"(s0[2 * j]), "v"(s0[2 * j + 1]));
+                asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(w[1][j]) : "v"(s1[2 * j]), "v"(s1[2 * j + 1]));
+            }
+#pragma unroll
+            for (int k = 0; k < 2; ++k)
+#pragma unroll
+                for (int d = 0; d < 4; ++d) asm volatile("v_permlane16_swap_b32 %0, %1" : "+v"(w[k][d]), "+v"(w[k][d + 4]));
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) w[0][j] = __builtin_bit_cast(unsigned, s0[j]), w[1][j] = __builtin_bit_cast(unsigned, s1[j]);
+        }
+        if (PART & 4) {
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const bf16x8 p0 = __builtin_bit_cast(bf16x8, u32x4{w[k][0], w[k][1], w[k][2], w[k][3]});
+                const bf16x8 p1 = __builtin_bit_cast(bf16x8, u32x4{w[k][4], w[k][5], w[k][6], w[k][7]});
+#pragma unroll
+                for (int dt = 0; dt < 3; ++dt) {
+                    o4[2 * dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, p0, o4[2 * dt], 0, 0, 0);
+                    o4[2 * dt + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, p1, o4[2 * dt + 1], 0, 0, 0);
+                }
+            }
+        } else {
+            o4[0][0] += __builtin_bit_cast(float, w[0][0] ^ w[1][7] ^ w[0][4] ^ w[1][3]);
+        }
+        if (BAR) __syncthreads();
+    }
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) sum += o4[i][0] + o4[i][1] + o4[i][2] + o4[i][3];
+    if (threadIdx.x % 64 == 0 && blockIdx.x == 0) out[threadIdx.x / 64] = t1 - t0;
+    if (sum == 12345.678f) out[63] = 1;
+}
+
+template <int BAR, int PART>
+static void run_attn_like(const char* what, int blocks_per_cu) {
+    unsigned long long* d;
+    hipMalloc(&d, 64 * 8);
+    hipMemset(d, 0, 64 * 8);
+    const int rep = 2048;
+    hipDeviceProp_t prop;
+    hipGetDeviceProperties(&prop, 0);
+    const int grid = prop.multiProcessorCount;
+    attn_like_kernel<BAR, PART><<<grid, 512 * blocks_per_cu>>>(d, rep);
+    attn_like_kernel<BAR, PART><<<grid, 512 * blocks_per_cu>>>(d, rep);
+    hipDeviceSynchronize();
+    std::vector<unsigned long long> h(64);
+    hipMemcpy(h.data(), d, 64 * 8, hipMemcpyDeviceToHost);
+    unsigned long long mx = 0;
+    for (int w = 0; w < 8 * blocks_per_cu; ++w) mx = h[w] > mx ? h[w] : mx;
+    printf("%-58s %d x 8 waves per CU: %7.1f cycles per iteration = %6.1f per wave-iteration and SIMD\n", what, blocks_per_cu,
+           (double)mx / rep, (double)mx / rep / (2.0 * blocks_per_cu));
+    hipFree(d);
+}
+
 template <int KIND>
 static void run(const char* what, int per_iter, int waves) {
     unsigned long long* d;
@@ -129,7 +235,11 @@ int main() {
         run<2>("v_cvt_pk_bf16_f32", 8, waves);
         run<3>("v_permlane16_swap_b32", 8, waves);
         run<4>("v_pk_mul_f32", 8, waves);
-        run<5>("v_mfma_f32_32x32x16_bf16", 2, waves);
+        run<5>("v_mfma_f32_32x32x16_bf16, two chains", 2, waves);
+        run<6>("v_mfma_f32_32x32x16_bf16, one chain", 2, waves);
+        run<7>("v_mfma_f32_16x16x32_bf16, one chain", 6, waves);
+        run<8>("v_mfma_f32_16x16x32_bf16, two chains", 6, waves);
+        run<9>("v_mfma_f32_16x16x32_bf16, six chains", 6, waves);
     }
     for (int waves : {4, 8}) {
         run<12>("mfma + 2 v_exp_f32 (cycles per MFMA)", 2, waves);
@@ -139,6 +249,18 @@ int main() {
         run<24>("mfma + 4 v_mul_f32 (cycles per MFMA)", 2, waves);
         run<26>("mfma + 6 v_mul_f32 (cycles per MFMA)", 2, waves);
         run<28>("mfma + 8 v_mul_f32 (cycles per MFMA)", 2, waves);
+    }
+    for (int bpc : {1, 2}) {
+        if (bpc == 1) {
+            run_attn_like<0, 2>("attention-like wave: softmax VALU only", 1);
+            run_attn_like<0, 4>("attention-like wave: PV MFMAs only", 1);
+            run_attn_like<0, 7>("attention-like wave: all", 1);
+            run_attn_like<1, 7>("attention-like wave: all + barrier per iteration", 1);
+        } else {
+            run_attn_like<0, 2>("attention-like wave: softmax VALU only", 2);
+            run_attn_like<0, 7>("attention-like wave: all", 2);
+            run_attn_like<1, 7>("attention-like wave: all + barrier per iteration", 2);
+        }
     }
     // cross-wave: waves 0-3 run 2 n MFMAs per round, waves 4-7 (same SIMDs) 16 m exps per round
     for (int m : {0, 2, 4, 8}) {

@@ -16,7 +16,13 @@
 //    v_permlane16_swap per 32-key block -- the K rows are staged in the order that makes the swapped dwords line up with
 //    the natural key order of V^T (below), so nothing else moves;
 //  * 256 queries per workgroup (8 waves x 32): a staged K / V^T tile serves twice the queries of the generic kernel's 128
-//    -- half the staging loads, LDS stores and barriers per query; 30 KB of LDS, two workgroups per CU;
+//    -- half the staging and barriers per query; two workgroups per CU;
+//  * tiles staged by LDS-DMA (ten global_load_lds_dwordx4 wave-instructions per 64-key tile, inline asm so that hipcc's
+//    wait-count tracker does not drain them in front of every fragment read): no staging registers, no LDS stores, no LDS
+//    initialisation, 20 KB of LDS.  The constants the MFMAs want beside the data -- the augmented K column, the ones / zero
+//    rows of V^T -- are three 16-byte chunks behind each buffer that the lanes concerned address instead of tile data
+//    (HvAttn40Geom).  The register-staged form it replaces (ds_write_b128 of a chunk per thread, padded pitches) measured
+//    1 % slower (profiles/r04_s17_attn40_dma.txt): staging is not what this kernel waits for either;
 //  * softmax VALU work per score: the query's reference maximum rides in the MFMA (K is augmented by a column of ones at
 //    head-dim index 40, Q by -m there: the MFMA delivers s - m with C = 0 -- no accumulator initialisation moves, no
 //    subtraction), the "some probability exceeds 2^THR" test runs on the PACKED bf16 pairs (v_pk_max_u16: positive bf16
@@ -49,7 +55,8 @@
 // (the softmax is invariant to the choice of reference as long as it is used consistently).
 //
 // Key order.  S^T block (32 keys x 32 queries), C/D layout of the 32x32 MFMA: lane l, register i <-> row (i & 3) + 8 (i >> 2)
-// + 4 (l >> 5).  K tile rows are staged so that LDS row 8 a + 4 b + c of a 32-key block holds key 16 b + 4 a + c: register i
+// + 4 (l >> 5).  K tile rows are staged (source-side, by the DMA's per-lane addresses) so that LDS row 8 a + 4 b + c of a
+// 32-key block holds key 16 b + 4 a + c: register i
 // of half b then IS key 16 b + i, the packed pair j (registers 2 j, 2 j + 1) keys 16 b + 2 j (+1), and after
 // v_permlane16_swap(pair d, pair d + 4) quad q of the result holds keys 8 q + 2 d (+1) for the queries r16 (first result:
 // queries 0-15 of the wave's 32, second: 16-31) -- dword d of the PV B operand with V^T in natural key order.
@@ -84,23 +91,29 @@ HV_DEV unsigned hv_pk_max_u16(unsigned a, unsigned b) {
 
 struct HvAttn40Geom {
     static constexpr int D = 40, NW = 8, BQ = 32 * NW;
-    static constexpr int KRS = 112;  // K row pitch: 80 data bytes + the augmented column (bf16 1.0 at byte 80) + padding; 28 dwords:
-                                     // the 16 rows of a ds_read_b128 lane group (equal column offset in the 32x32 A-operand read)
-                                     // fall on 16 different 4-dword bank windows (28 r mod 64 is a permutation of the multiples of 4)
-    static constexpr int VRS = 160;  // V^T row pitch (64 keys = 128 data bytes): conflict-free for the 16x16x32 A-operand read
-    static constexpr int DV = 48;    // V^T rows: 40 channels, the row of ones (denominator), 7 zero rows
-    static constexpr int KBYTES = 64 * KRS, VBYTES = DV * VRS;
-    static constexpr int KCH = 64 * 5, VCH = 40 * 8;  // 16-byte chunks of a K / V^T tile: 320 each
-    static constexpr int VT0 = 512 - VCH;              // first thread of the V^T loaders (threads 192 .. 511; K: threads 0 .. 319)
+    // Tiles are staged by LDS-DMA (global_load_lds_dwordx4: 64 lanes x 16 bytes land contiguously), so a tile in LDS is a dense
+    // array of 16-byte chunks and every constant the MFMAs need beside the data sits in a few chunks BEHIND the tile that the
+    // lanes concerned address instead of tile data:
+    //   K tile: 64 rows x 80 bytes (5 chunks: 320 chunks = five wave-instructions).  20 dwords per row: the 16 rows of a
+    //     ds_read_b128 lane group fall on 16 different 4-dword bank windows (20 r mod 64 over the group's rows is a permutation
+    //     of the multiples of 4).  The augmented column (bf16 1.0 at head-dim index 40, zeros up to 47) is one constant chunk:
+    //     the upper-half lanes of the third k-step read it for every key row (a broadcast).
+    //   V^T tile: 40 rows x 128 bytes (8 chunks of 8 keys: 320 chunks), chunk position XOR-swizzled by the row (position c of
+    //     row r holds keys 8 (c ^ (r & 7)) .. + 7, applied on the source side of the DMA): conflict-free for the 16x16x32
+    //     A-operand read.  Row 40 (all ones: the denominator) and rows 41 - 47 (zeros) are two constant chunks.
+    static constexpr int KRS = 80, VRS = 128;
+    static constexpr int KBYTES = 64 * KRS, VBYTES = D * VRS;     // 5120 each
+    static constexpr int KSTRIDE = KBYTES + 16, VSTRIDE = VBYTES + 32;  // buffer strides: tile + its constant chunks
+    static constexpr int LDS_BYTES = 2 * KSTRIDE + 2 * VSTRIDE;
 };
 
 template <bool MASK>
 __global__ __launch_bounds__(512, 4) void hv_attention40_kernel(hv_attention_params p) {
     using G = HvAttn40Geom;
     constexpr int D = G::D;
-    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * (G::KBYTES + G::VBYTES)];
-    unsigned char* Ks = smem;
-    unsigned char* Vs = smem + 2 * G::KBYTES;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[G::LDS_BYTES];
+    unsigned char* Ks = smem;                   // buffer b: Ks + b * KSTRIDE  (tile, then the augmented-column chunk)
+    unsigned char* Vs = smem + 2 * G::KSTRIDE;  // buffer b: Vs + b * VSTRIDE  (tile, then the ones chunk, then the zeros chunk)
 
     const int tid = threadIdx.x, lane = tid & 63;
 #ifndef HV_EMU
@@ -129,14 +142,10 @@ __global__ __launch_bounds__(512, 4) void hv_attention40_kernel(hv_attention_par
     const int T2 = sel >= 0 ? (p.L2 + 63) / 64 : 0;
     const int ntiles = T1 + T2;
 
-    // LDS: zero everything once (the padding is never overwritten by the tile stores), then the augmented K column (bf16 1.0
-    // at head-dim index 40 of every key row) and the V^T row of ones (row 40: the P.V MFMA accumulates the denominator)
-    for (int i = tid; i < 2 * (G::KBYTES + G::VBYTES) / 16; i += 512) hv_st16(smem + i * 16, u32x4{0u, 0u, 0u, 0u});
-    __syncthreads();
-    if (tid < 128) *reinterpret_cast<unsigned*>(Ks + (tid >> 6) * G::KBYTES + (tid & 63) * G::KRS + 2 * D) = 0x00003F80u;
-    if (tid >= 128 && tid < 144)
-        hv_st16(Vs + ((tid - 128) >> 3) * G::VBYTES + D * G::VRS + ((tid - 128) & 7) * 16,
-                u32x4{0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u});
+    // LDS constants (every tile byte is written by the DMA; the first tile barrier orders these stores before their readers)
+    if (tid < 2) hv_st16(Ks + tid * G::KSTRIDE + G::KBYTES, u32x4{0x00003F80u, 0u, 0u, 0u});
+    if (tid >= 64 && tid < 66) hv_st16(Vs + (tid - 64) * G::VSTRIDE + G::VBYTES, u32x4{0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u});
+    if (tid >= 128 && tid < 130) hv_st16(Vs + (tid - 128) * G::VSTRIDE + G::VBYTES + 16, u32x4{0u, 0u, 0u, 0u});
 
     // ---- query fragments: B operand of S^T = K.Q^T (32x32x16): lane = query l32, elements = head-dim 16 s + 8 half + 0..7;
     //      pre-multiplied by scale * log2(e) (scores come out of the MFMA in the exp2 domain); step 2 of the upper half is the
@@ -159,48 +168,62 @@ __global__ __launch_bounds__(512, 4) void hv_attention40_kernel(hv_attention_par
     }
     float mneg = 0.f;  // -m of this lane's query: always exactly representable in bf16 (it is what qf[2][0] of the upper half holds)
 
-    // ---- tile staging: one 16-byte chunk of the K tile (threads 0 .. 319: waves 0-4) and / or one of the V^T tile (threads
-    //      192 .. 511: waves 3-7) per thread, through registers (the loads of tile t + 1 fly during the arithmetic of tile t)
+    // ---- tile staging by LDS-DMA: waves 0-4 issue one instruction of the K tile each, waves 3-7 one of the V^T tile (source =
+    //      wave-uniform tile base + a per-lane byte offset that does not change from tile to tile), into the buffer the
+    //      previous tile was read from two barriers ago.  No staging registers, no LDS stores, no LDS initialisation.
     const bool k_loader = wave < 5, v_loader = wave >= 3;  // (wave-uniform)
-    const int krow = tid / 5, kcol = (tid - 5 * krow) * 16;  // key row within the tile, byte within its 80-byte head slice
-    const int vid = tid - G::VT0, vrow = vid >> 3, vcol = (vid & 7) * 16;  // V^T channel row, byte within its 128 bytes (8 keys per chunk)
-    // key 16 b + 4 a + c of a 32-key block is staged at row 8 a + 4 b + c (see the header)
-    const int klds = ((krow & 32) | (((krow >> 2) & 3) << 3) | (((krow >> 4) & 1) << 2) | (krow & 3)) * G::KRS + kcol;
-    const int vlds = vrow * G::VRS + vcol;
-    u32x4 kreg = {0u, 0u, 0u, 0u}, vreg = {0u, 0u, 0u, 0u};
-    const char* kbase = nullptr;
-    const char* vbase = nullptr;
-    unsigned kstep = 0, koff = 0, voff = 0;
+    // K: chunk 64 wave + lane of the tile = row (chunk / 5), 16-byte piece (chunk % 5) of its 80-byte head slice; LDS row
+    //    8 a + 4 b + c of a 32-key block holds key 16 b + 4 a + c (see the header)
+    const int kch = 64 * (k_loader ? wave : 0) + lane, klrow = kch / 5, kpc = kch - 5 * klrow;
+    const int kkey = (klrow & 32) | (((klrow >> 2) & 1) << 4) | (((klrow >> 3) & 3) << 2) | (klrow & 3);
+    // V^T: chunk 64 (wave - 3) + lane = channel row (chunk / 8), position (chunk % 8) <- keys 8 (position ^ (row & 7)) .. + 7
+    const int vch = 64 * (v_loader ? wave - 3 : 0) + lane, vrow = vch >> 3, vkc = (vch & 7) ^ (vrow & 7);
+    unsigned koff = 0, voff = 0;      // per-lane source byte offsets within a tile (set_source)
+    const char* kbase = nullptr;      // wave-uniform: first key row of the next tile to request, at this head's columns
+    const char* vbase = nullptr;      //               first key column of the next tile, at this head's first channel row
+    unsigned kstep = 0, ldk_b = 0, ldv_b = 0;
     int src_kv0 = 0, src_L = 0;
     auto set_source = [&](bool bank) {
         const unsigned rowbase = bank ? (unsigned)sel * (unsigned)p.L2 : (unsigned)img * (unsigned)p.L1;
-        const unsigned ldk2 = (unsigned)(bank ? p.ldk2 : p.ldk) * 2u, ldv2 = (unsigned)(bank ? p.ldvt2 : p.ldvt) * 2u;  // bytes
-        kbase = reinterpret_cast<const char*>(bank ? p.K2 : p.K) + ((size_t)rowbase * ldk2 + (size_t)(head * D) * 2u);
-        vbase = reinterpret_cast<const char*>(bank ? p.Vt2 : p.Vt) + ((size_t)(head * D) * ldv2 + (size_t)rowbase * 2u);
-        kstep = 64u * ldk2;
+        ldk_b = (unsigned)(bank ? p.ldk2 : p.ldk) * 2u, ldv_b = (unsigned)(bank ? p.ldvt2 : p.ldvt) * 2u;  // bytes
+        kbase = reinterpret_cast<const char*>(bank ? p.K2 : p.K) + ((size_t)rowbase * ldk_b + (size_t)(head * D) * 2u);
+        vbase = reinterpret_cast<const char*>(bank ? p.Vt2 : p.Vt) + ((size_t)(head * D) * ldv_b + (size_t)rowbase * 2u);
+        kstep = 64u * ldk_b;
         src_kv0 = 0;
         src_L = bank ? p.L2 : p.L1;
-        koff = hv_umul24((unsigned)krow, ldk2) + (unsigned)kcol;
-        voff = hv_umul24((unsigned)(vrow & 63), ldv2) + (unsigned)vcol;  // (& 63: non-loader threads stay inside the 24-bit multiply)
+        koff = hv_umul24((unsigned)kkey, ldk_b) + (unsigned)kpc * 16u;
+        voff = hv_umul24((unsigned)vrow, ldv_b) + (unsigned)vkc * 16u;
     };
-    auto load_tile = [&](int ti) {
+    auto request_tile = [&](int ti, int buf) {  // tiles are requested in order
         if (ti == T1) set_source(true);  // (rare, wave-uniform) the bank follows the own keys
-        if (k_loader) {
-            kreg = u32x4{0u, 0u, 0u, 0u};
-            if (!MASK || src_kv0 + krow < src_L) kreg = hv_ld16(kbase + koff);
+        unsigned ko = koff, vo = voff;
+        if (MASK && src_kv0 + 64 > src_L) {
+            // ragged last tile: rows / key chunks beyond the end re-read the last valid one (in bounds; their scores are
+            // masked to -inf and their probabilities are zero, so the values never count)
+            const int last = src_L - 1 - src_kv0;  // last valid key of the tile (>= 0: L % 8 == 0, L > kv0)
+            ko = hv_umul24((unsigned)min(kkey, last), ldk_b) + (unsigned)kpc * 16u;
+            vo = hv_umul24((unsigned)vrow, ldv_b) + (unsigned)min(vkc, last >> 3) * 16u;
         }
-        if (v_loader) {
-            vreg = u32x4{0u, 0u, 0u, 0u};
-            if (!MASK || src_kv0 + (vcol >> 1) < src_L) vreg = hv_ld16(vbase + voff);  // (L % 8 == 0: a chunk never straddles the end)
-        }
+        if (k_loader) hv_glds16_s(kbase, ko, Ks + buf * G::KSTRIDE + wave * 1024);
+        if (v_loader) hv_glds16_s(vbase, vo, Vs + buf * G::VSTRIDE + (wave - 3) * 1024);
         kbase += kstep;
         vbase += 128;
         src_kv0 += 64;
     };
-    auto store_tile = [&](int buf) {
-        if (k_loader) hv_st16(Ks + buf * G::KBYTES + klds, kreg);
-        if (v_loader) hv_st16(Vs + buf * G::VBYTES + vlds, vreg);
-    };
+    // fragment read offsets (loop-invariant, relative to the buffer):
+    //  K, A operand of the 32x32x16 MFMA: lane = key row l32 of the 32-key block, bytes 32 s + 16 half of its slice; the third
+    //  step's upper half is the augmented column = the constant chunk behind the tile
+    const int krd = l32 * G::KRS + half * 16;
+    const int krd2_0 = half ? G::KBYTES : krd + 64, krd2_1 = half ? G::KBYTES : krd + 32 * G::KRS + 64;
+    //  V^T, A operand of the 16x16x32 MFMA: lane = channel row 16 dt + r16, keys 32 kbk + 8 quad .. + 7
+    int vrd[3][2];
+#pragma unroll
+    for (int dt = 0; dt < 3; ++dt)
+#pragma unroll
+        for (int kbk = 0; kbk < 2; ++kbk) {
+            const int row = 16 * dt + r16;
+            vrd[dt][kbk] = row < D ? row * G::VRS + (((quad + 4 * kbk) ^ (row & 7)) << 4) : (row == D ? G::VBYTES : G::VBYTES + 16);
+        }
 
     f32x4 oacc[2][3];  // O^T accumulators [16-query tile][16-row channel fragment]: lane = query r16, channels 16 dt + 4 quad + 0..3
     __syncthreads();  // LDS initialisation complete before the first tile store
@@ -216,14 +239,14 @@ __global__ __launch_bounds__(512, 4) void hv_attention40_kernel(hv_attention_par
 #pragma unroll
         for (int dt = 0; dt < 3; ++dt) oacc[qt][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
     set_source(false);
-    load_tile(0);
+    request_tile(0, 0);
     for (int ti = 0; ti < ntiles; ++ti) {
         const int buf = ti & 1;
-        store_tile(buf);
-        __syncthreads();
-        if (ti + 1 < ntiles) load_tile(ti + 1);
-        const unsigned char* kb = Ks + buf * G::KBYTES + l32 * G::KRS + half * 16;
-        const unsigned char* vb = Vs + buf * G::VBYTES + r16 * G::VRS + quad * 16;
+        hv_vm_wait<0>();   // this wave's pieces of tile ti have landed (requested a whole tile ago) ...
+        __syncthreads();   // ... and everybody's; every wave is done reading the other buffer
+        if (ti + 1 < ntiles) request_tile(ti + 1, buf ^ 1);
+        const unsigned char* kb = Ks + buf * G::KSTRIDE;
+        const unsigned char* vb = Vs + buf * G::VSTRIDE;
         const int tile_kv0 = MASK ? ((ti >= T1 ? ti - T1 : ti) * 64) : 0;
         const int tile_L = MASK ? (ti >= T1 ? p.L2 : p.L1) : 0;
         auto mask_tail = [&](f32x16 (&sc)[2]) __attribute__((always_inline)) {
@@ -244,7 +267,8 @@ __global__ __launch_bounds__(512, 4) void hv_attention40_kernel(hv_attention_par
                 for (int i = 0; i < 16; ++i) a[i] = 0.f;
 #pragma unroll
                 for (int s = 0; s < 3; ++s) {
-                    const bf16x8 kf = hv_as_bf16x8(hv_ld16(kb + (32 * kbk) * G::KRS + s * 32));
+                    const int ofs = s < 2 ? krd + (32 * kbk) * G::KRS + s * 32 : (kbk ? krd2_1 : krd2_0);
+                    const bf16x8 kf = hv_as_bf16x8(hv_ld16(kb + ofs));
                     a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], a, 0, 0, 0);
                 }
                 sc[kbk] = a;
@@ -328,7 +352,7 @@ __global__ __launch_bounds__(512, 4) void hv_attention40_kernel(hv_attention_par
         for (int dt = 0; dt < 3; ++dt)
 #pragma unroll
             for (int kbk = 0; kbk < 2; ++kbk) {
-                const bf16x8 vf = hv_as_bf16x8(hv_ld16(vb + (16 * dt) * G::VRS + kbk * 64));
+                const bf16x8 vf = hv_as_bf16x8(hv_ld16(vb + vrd[dt][kbk]));
 #pragma unroll
                 for (int qt = 0; qt < 2; ++qt)
                     oacc[qt][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[qt][kbk], oacc[qt][dt], 0, 0, 0);

@@ -152,18 +152,22 @@ __global__ __launch_bounds__(1024, 4) void attn_like_kernel(unsigned long long* 
                 asm volatile("v_exp_f32 %0, %0" : "+v"(s0[i]));
                 asm volatile("v_exp_f32 %0, %0" : "+v"(s1[i]));
             }
+        }
+        if (PART & 8) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(w[0][j]) : "v"(s0[2 * j]), "v"(s0[2 * j + 1]));
                 asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(w[1][j]) : "v"(s1[2 * j]), "v"(s1[2 * j + 1]));
             }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) w[0][j] = __builtin_bit_cast(unsigned, s0[j]), w[1][j] = __builtin_bit_cast(unsigned, s1[j]);
+        }
+        if (PART & 16) {
 #pragma unroll
             for (int k = 0; k < 2; ++k)
 #pragma unroll
                 for (int d = 0; d < 4; ++d) asm volatile("v_permlane16_swap_b32 %0, %1" : "+v"(w[k][d]), "+v"(w[k][d + 4]));
-        } else {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) w[0][j] = __builtin_bit_cast(unsigned, s0[j]), w[1][j] = __builtin_bit_cast(unsigned, s1[j]);
         }
         if (PART & 4) {
 #pragma unroll
@@ -252,14 +256,20 @@ int main() {
     }
     for (int bpc : {1, 2}) {
         if (bpc == 1) {
-            run_attn_like<0, 2>("attention-like wave: softmax VALU only", 1);
+            run_attn_like<0, 26>("attention-like wave: softmax VALU only", 1);
             run_attn_like<0, 4>("attention-like wave: PV MFMAs only", 1);
-            run_attn_like<0, 7>("attention-like wave: all", 1);
-            run_attn_like<1, 7>("attention-like wave: all + barrier per iteration", 1);
+            run_attn_like<0, 31>("attention-like wave: all", 1);
+            run_attn_like<1, 31>("attention-like wave: all + barrier per iteration", 1);
         } else {
-            run_attn_like<0, 2>("attention-like wave: softmax VALU only", 2);
-            run_attn_like<0, 7>("attention-like wave: all", 2);
-            run_attn_like<1, 7>("attention-like wave: all + barrier per iteration", 2);
+            run_attn_like<0, 26>("attention-like wave: softmax VALU only", 2);
+            run_attn_like<0, 2>("attention-like wave: 32 v_exp_f32 only", 2);
+            run_attn_like<0, 8>("attention-like wave: 16 v_cvt_pk_bf16_f32 only", 2);
+            run_attn_like<0, 16>("attention-like wave: 8 v_permlane16_swap only", 2);
+            run_attn_like<0, 5>("attention-like wave: MFMAs only (18)", 2);
+            run_attn_like<0, 7>("attention-like wave: MFMAs + exps", 2);
+            run_attn_like<0, 15>("attention-like wave: MFMAs + exps + packs", 2);
+            run_attn_like<0, 31>("attention-like wave: all", 2);
+            run_attn_like<1, 31>("attention-like wave: all + barrier per iteration", 2);
         }
     }
     // cross-wave: waves 0-3 run 2 n MFMAs per round, waves 4-7 (same SIMDs) 16 m exps per round

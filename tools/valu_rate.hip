@@ -214,6 +214,57 @@ static void run_attn_like(const char* what, int blocks_per_cu) {
     hipFree(d);
 }
 
+
+// Do transcendentals and plain VALU of two waves of one SIMD overlap?  Waves 0-3 run v_exp_f32, waves 4-7 (same SIMDs) ROLE_B:
+// 0 nothing, 1 v_mul_f32, 2 v_pk_fma_f32, 3 v_exp_f32.
+template <int ROLE_B>
+__global__ void trans_mix_kernel(unsigned long long* out, int rep) {
+    float v[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) v[i] = 0.001f * threadIdx.x + i * 0.01f;
+    const int wave = threadIdx.x / 64;
+    __syncthreads();
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    if (wave < 4 || ROLE_B == 3) {
+        for (int r = 0; r < rep; ++r) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) asm volatile("v_exp_f32 %0, %1" : "=v"(v[i]) : "v"(v[(i + 1) & 15]));
+        }
+    } else if (ROLE_B == 1) {
+        for (int r = 0; r < rep * 3; ++r) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) asm volatile("v_mul_f32 %0, %0, %0" : "+v"(v[i]));
+        }
+    } else if (ROLE_B == 2) {
+        for (int r = 0; r < rep * 2; ++r) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                asm volatile("v_pk_fma_f32 %0, %0, %0, %0" : "+v"(*reinterpret_cast<double*>(&v[2 * i])));
+        }
+    }
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) sum += v[i];
+    if (threadIdx.x % 64 == 0) out[wave] = t1 - t0;
+    if (sum == 12345.678f) out[63] = 1;
+}
+template <int ROLE_B>
+static void run_trans_mix(const char* what, int per_b) {
+    unsigned long long* d;
+    hipMalloc(&d, 64 * 8);
+    const int rep = 2048;
+    trans_mix_kernel<ROLE_B><<<1, 512>>>(d, rep);
+    trans_mix_kernel<ROLE_B><<<1, 512>>>(d, rep);
+    hipDeviceSynchronize();
+    std::vector<unsigned long long> h(64);
+    hipMemcpy(h.data(), d, 64 * 8, hipMemcpyDeviceToHost);
+    printf("wave A v_exp_f32 beside wave B %-14s: A %.2f cycles per v_exp_f32", what, (double)h[0] / rep / 16);
+    if (per_b) printf(", B %.2f cycles per instruction", (double)h[4] / rep / per_b);
+    printf("\n");
+    hipFree(d);
+}
+
 template <int KIND>
 static void run(const char* what, int per_iter, int waves) {
     unsigned long long* d;
@@ -272,6 +323,10 @@ int main() {
             run_attn_like<1, 31>("attention-like wave: all + barrier per iteration", 2);
         }
     }
+    run_trans_mix<0>("(idle)", 0);
+    run_trans_mix<1>("v_mul_f32", 48);
+    run_trans_mix<2>("v_pk_fma_f32", 16);
+    run_trans_mix<3>("v_exp_f32", 16);
     // cross-wave: waves 0-3 run 2 n MFMAs per round, waves 4-7 (same SIMDs) 16 m exps per round
     for (int m : {0, 2, 4, 8}) {
         unsigned long long* d;

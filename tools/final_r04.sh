@@ -1,6 +1,6 @@
 #!/bin/bash
 # The round's closing measurement, all at the built tree that is shipped (run LAST, with >= 12 GPU-minutes left):
-#   gpurun --timeout 1500 -- 'bash tools/final_r04.sh'
+#   gpurun --timeout 2700 -- 'bash tools/final_r04.sh'
 #  1. the -m gpu suite, serially          -> gpurun_out/r04_final_pytest.txt
 #  2. the bench line (+ step profile)     -> gpurun_out/r04_bench_line_final.json, r04_step_profile_final.tsv
 #  3. rocprofv3 --kernel-trace --stats    -> gpurun_out/r04_final_kernel_stats.csv
@@ -10,7 +10,7 @@
 mkdir -p gpurun_out
 export TMPDIR=/tmp
 if [ "$1" != "--no-tests" ] && [ "$1" != "--measure-only" ]; then
-  timeout 900 python -m pytest tests -m gpu -q -x > gpurun_out/r04_final_pytest.txt 2>&1
+  timeout 1500 python -m pytest tests -m gpu -q -x > gpurun_out/r04_final_pytest.txt 2>&1
   tail -3 gpurun_out/r04_final_pytest.txt
 fi
 MEASURE_ONLY=0; if [ "$1" == "--measure-only" ]; then MEASURE_ONLY=1; fi   # bench line + the three traffic passes only
@@ -22,6 +22,7 @@ if [ $MEASURE_ONLY == 0 ]; then
   timeout 400 python bench.py --config 5 --fp8-attention 1 --steps 3 --warmup 1 --no-cpu-baseline --no-profile 2>/dev/null | grep '^{'
 } > gpurun_out/r04_bench_configs.jsonl; cut -c1-200 gpurun_out/r04_bench_configs.jsonl
 bash tools/prof_bench.sh r04_final --no-profile | head -12
+timeout 300 python tools/microbench.py 2>&1 | grep -v amdgpu.ids > gpurun_out/r04_microbench_final.txt
 fi
 REPO=$(pwd)
 cd /tmp

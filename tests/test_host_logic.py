@@ -331,3 +331,46 @@ def test_loop_body_goldens_counters_and_callback_contract():
             assert np.array_equal(z[f"counter{i}"], cover), (case, z[f"counter{i}"], cover)
     assert ts[0] == 999 and ts[-1] == 32
     assert len(windows) == 1  # (the last case is a single 24-frame window)
+
+
+def test_interleaved_replay_order_and_streams(monkeypatch):
+    """StepRecorder.replay_interleaved (exchange / compute overlap of the two CFG halves): item i of
+    every half is issued before item i + 1 of any, each half on its own stream -- so the collectives reach the communicator
+    in the order A1 B1 A2 B2 ... on every rank (the property that keeps the ranks' collective sequences identical) -- and a
+    recording whose item kinds differ from the other half's is refused."""
+    import contextlib
+
+    from humanvid_amd.pipeline import StepRecorder
+
+    log, cur = [], [None]
+
+    class FakeStream:
+        def __init__(self, name):
+            self.name, self.cuda_stream = name, name
+
+    class FakeLib:
+        def call(self, fn, handle, stream):
+            assert fn == "hv_cmdlist_run" and stream == cur[0].name  # launched on the stream it is issued under
+            log.append(("k", handle, stream))
+
+    @contextlib.contextmanager
+    def fake_stream_ctx(s):
+        prev, cur[0] = cur[0], s
+        try:
+            yield
+        finally:
+            cur[0] = prev
+
+    monkeypatch.setattr(torch.cuda, "stream", fake_stream_ctx)
+    recs = []
+    for half in ("A", "B"):
+        r = StepRecorder(FakeLib())
+        r.items = [("k", half + "0"), ("c", lambda h=half: log.append(("c", h + "1", cur[0].name))), ("k", half + "2"),
+                   ("c", lambda h=half: log.append(("c", h + "3", cur[0].name)))]
+        recs.append(r)
+    StepRecorder.replay_interleaved(recs, [FakeStream("sA"), FakeStream("sB")])
+    assert log == [("k", "A0", "sA"), ("k", "B0", "sB"), ("c", "A1", "sA"), ("c", "B1", "sB"),
+                   ("k", "A2", "sA"), ("k", "B2", "sB"), ("c", "A3", "sA"), ("c", "B3", "sB")]
+    recs[1].items = recs[1].items[:3] + [("k", "B3")]
+    with pytest.raises(AssertionError):
+        StepRecorder.replay_interleaved(recs, [FakeStream("sA"), FakeStream("sB")])

@@ -298,6 +298,10 @@ def main():
                     help="N > 1 GPUs: the two CFG halves of a step on two streams, replayed interleaved, so that one half's temporal "
                          "exchange runs under the other half's kernels (DESIGN.md section 5).  auto: on, after a three-step probe "
                          "run outside the timed region; if the probe raises, the serial path is timed and the line says so")
+    ap.add_argument("--single-rank-sharded", action="store_true",
+                    help="diagnostic (N = 1 only): run the SHARDED code path -- exchange layouts, graph-replayed command-list "
+                         "segments, CFG halves on two streams, every collective through RCCL -- with a process group of one rank: "
+                         "what the sharded schedule costs before any byte crosses xGMI (DESIGN.md section 5)")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline", default="quarter", choices=["quarter", "full"],
@@ -320,7 +324,14 @@ def main():
     dev = torch.device("cuda", local)
     import torch.distributed as dist
 
-    if world > 1:
+    sharded = world > 1 or args.single_rank_sharded
+    if args.single_rank_sharded:
+        if world != 1:
+            raise SystemExit("--single-rank-sharded is an N = 1 diagnostic")
+        os.environ["HUMANVID_SINGLE_RANK_SHARDED"] = "1"  # read by FrameShard
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.update(RANK="0", WORLD_SIZE="1")
+    if sharded:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
 
@@ -348,7 +359,7 @@ def main():
     sched = DDIMScheduler(beta_start=0.00085, beta_end=0.012, beta_schedule="linear", clip_sample=False, steps_offset=1,
                           prediction_type="v_prediction", rescale_betas_zero_snr=True, timestep_spacing="trailing")
     pipe = Pose2VideoPipeline(None, None, None, unet, pg, cam, sched)
-    if world > 1:
+    if sharded:
         pipe.enable_frame_sharding(window_groups=args.window_groups)
 
     g = torch.Generator().manual_seed(42)
@@ -358,7 +369,7 @@ def main():
     clip = torch.randn(1, 768, generator=torch.Generator().manual_seed(2))
     from humanvid_amd.unet3d import transformer_locations
 
-    eng = unet.engine() if world == 1 else None
+    eng = unet.engine() if not sharded else None
     if eng is None:
         from humanvid_amd.engine import UNet3DEngine
 
@@ -383,7 +394,7 @@ def main():
 
     def sync_barrier():
         torch.cuda.synchronize()
-        if world > 1:
+        if sharded:
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -396,9 +407,9 @@ def main():
             times["t1"] = time.perf_counter()
 
     def after_loop(one_step):
-        if world == 1 and not args.no_profile:
+        if not sharded and not args.no_profile:
             prof["kernels"] = profile_step(one_step)
-        if world > 1:
+        if sharded:
             # one more, eagerly launched step outside the timed region with every collective counted and bracketed by
             # events: collectives per step, bytes this rank sends, and the exchange time the step is exposed to
             # (a diagnostic: whatever goes wrong in it must not take the bench line down -- every rank still reaches the
@@ -421,7 +432,7 @@ def main():
                 sh.measure = False
 
     cfg_streams = None
-    if world > 1:
+    if sharded:
         sh = pipe.shard
         sh.overlap_cfg = args.cfg_streams != "0" and not args.no_graph
         cfg_streams = "on" if sh.overlap_cfg else "off"
@@ -446,13 +457,13 @@ def main():
     pipe.denoise(latents, pose, plucker, clip, n_inf, 3.5, use_graph=not args.no_graph, max_steps=SETUP + Wm + K, step_hook=hook,
                  after_loop=after_loop)
     elapsed = times["t1"] - times["t0"]
-    if world > 1:
+    if sharded:
         tmax = torch.tensor([elapsed], device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax)
 
     exchange = None
-    if world > 1 and "exchange" in prof:
+    if sharded and "exchange" in prof:
         ex = prof["exchange"]
         t = torch.tensor([ex["exposed_exchange_ms"], ex["eager_step_ms"], -ex["ok"]], device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -468,10 +479,10 @@ def main():
         windows = list(get_context_scheduler("uniform")(0, n_inf, F, 24, 1, 4))
         fl_total = sum(unet3d_flops(cfg, 2, len(c), h, w, False)["total"] for c in windows)
         ms_step = elapsed / K * 1e3
-        exch = pipe.shard.exchange if world > 1 else None
-        par = "single GPU" if world == 1 else (
+        exch = pipe.shard.exchange if sharded else None
+        par = "single GPU" if not sharded else ("ONE rank on the sharded code path (diagnostic: --single-rank-sharded)" if world == 1 else (
             f"frame-sharded x{world}: frames<->pixels all-to-all around every temporal attention (RCCL over xGMI)"
-            if exch == "alltoall" else f"frame-sharded x{world}: RCCL all-gather of temporal K/V")
+            if exch == "alltoall" else f"frame-sharded x{world}: RCCL all-gather of temporal K/V"))
         out = {
             "metric": f"denoising steps/sec, {F}f x {H}x{W} Pose2Video", "value": K / elapsed, "unit": "steps/s",
             "n_gpus": world, "steps": K, "warmup": Wm, "ms_per_step": ms_step, "higher_is_better": True,
@@ -495,7 +506,7 @@ def main():
             roof, table = roofline_from_profile(prof["kernels"], os.path.join(REPO, "profiles", "r04_pmc_traffic.json"))
             out["roofline"] = roof
             out["kernels"] = table
-        if world == 1 and not args.no_cpu_baseline:
+        if not sharded and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline((96, 64) if args.cpu_baseline == "full" else (48, 32))
             ref = os.path.join(REPO, "tests", "golden", f"cpu_reference_config{args.config}.json")
             if os.path.exists(ref):  # the reference SOURCE timed in the build container (oracle/gen_fullsize_golden.py)
@@ -506,7 +517,7 @@ def main():
                                                   f"{r['cores']} vCPU build container), committed measurement: "
                                                   f"tests/golden/cpu_reference_config{args.config}.json"}
         print(json.dumps(out))
-    if world > 1:
+    if sharded:
         dist.destroy_process_group()
 
 

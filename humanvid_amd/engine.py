@@ -357,7 +357,7 @@ class UNet3DEngine:
         self.run.gn_parts.clear()
         self.run.ln_parts.clear()
         conv = self.run.conv_with_stats
-        sharded = self.shard is not None and self.shard.world > 1
+        sharded = self.shard is not None and self.shard.active
 
         def resnet(prefix, x, skip, out_name):
             """ResnetBlock3D.forward, resnet.py:215-245 (skip = second concat source or None)."""

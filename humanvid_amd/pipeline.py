@@ -354,7 +354,8 @@ class Pose2VideoPipeline:
         # ---- exchange / compute overlap for frame-sharded guided steps (FrameShard.overlap_cfg): the two CFG halves never
         # interact before hv_cfg_ddim_step, so each runs as its own B = 1 forward on its own stream (own workspace), recorded
         # once as command-list segments cut at its collectives and replayed INTERLEAVED with the other half
-        overlap = (self.shard is not None and world > 1 and do_cfg and use_graph and getattr(self.shard, "overlap_cfg", False))
+        sharded = self.shard is not None and self.shard.active
+        overlap = sharded and do_cfg and use_graph and getattr(self.shard, "overlap_cfg", False)
         if overlap:
             halves = [eng.clone_for_half(hf) for hf in (0, 1)]
             streams = [torch.cuda.Stream(), torch.cuda.Stream()]
@@ -394,7 +395,7 @@ class Pose2VideoPipeline:
                 ops.pack_ncfhw(L, st, latents, xi, rep=rep, frames=frames)
                 y = eng.forward_nhwc(xi, t_dev, cond, B=rep, F=fl)
                 ops.accumulate_window(L, st, y, rep, C, frames, acc, counter)
-            if self.shard is not None and (world > 1 or self.shard.window_groups > 1):
+            if sharded or (self.shard is not None and self.shard.window_groups > 1):
                 self.shard.all_reduce(acc_cnt)
             ops.cfg_ddim_step(L, st, latents, acc, counter, rep, coeffs)
 
@@ -406,7 +407,7 @@ class Pose2VideoPipeline:
         for i in range(first_step, n_steps):
             t_dev.copy_(t_table[i].expand(rep))
             coeffs.copy_(c_table[i])
-            multi = self.shard is not None and (world > 1 or self.shard.window_groups > 1)
+            multi = sharded or (self.shard is not None and self.shard.window_groups > 1)
             if use_graph and not multi and i >= first_step + 1:
                 if graph is None:
                     # step 0 ran eagerly (allocates every workspace buffer); capture step 1 and replay it

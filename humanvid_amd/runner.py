@@ -100,6 +100,16 @@ class FrameShard:
         # it, so the event distance is the exchange time the step is EXPOSED to (nothing overlaps it yet)
         self.measure = False
         self.stats = dict(collectives=0, bytes_sent=0, events=[])
+        # Diagnostic: run the SHARDED code path (exchange layouts, command-list segments cut at the collectives, CFG halves on
+        # two streams) with a group of ONE rank -- every collective then is a local copy through the real backend.  This is how
+        # the RCCL choreography (collectives issued under two streams next to graph-replayed segments) is exercised on a
+        # one-GPU box, where RCCL refuses a second rank per device (tests/test_gpu_sharded.py).  Never set by the product.
+        self.single_rank_sharded = os.environ.get("HUMANVID_SINGLE_RANK_SHARDED") == "1"
+
+    @property
+    def active(self) -> bool:
+        """does this job take the sharded path?  (more than one rank in the frame group, or the one-rank diagnostic)"""
+        return self.world > 1 or self.single_rank_sharded
 
     def _timed(self, nbytes: int, fn):
         if not self.measure:

@@ -421,6 +421,33 @@ HV_DEV void hv_gemm_epilogue_fast_perm(const HvGemmParams& p, f32x4 (&acc)[4][NM
 #pragma unroll
         for (int nf = 0; nf < 4; ++nf) add4[nf] += t4[nf];
     }
+    // Row permutation of the output (p.perm_p > 0, hv_gemm_params: row (x perm_y + y) perm_p + pp is stored -- and the residual
+    // read -- at (y perm_x + x) perm_p + pp: the frame-sharded motion module writes its all-to-all send layout directly).
+    // The lane's rows are m_base + r16 + 16 mf: two divisions for the first, steps of 16 for the rest (perm_p >= 16: host).
+    // Everything on the INPUT side (LayerNorm row statistics, per-row tables, the bounds test) keeps the logical row m;
+    // everything on the output side (Y, residual, the LayerNorm partial statistics of the output) uses mo[mf].
+    // (128 x 128 kernel only -- the 256 x 256 one has no registers for it: hv_gemm_choose sends row-permuted problems here)
+    constexpr bool ROWPERM = NMF <= 4;
+    int mo[NMF];
+    {
+        const int m0r = m_base + r16;
+        if (ROWPERM && p.perm_p > 0) {
+            int blk = m0r / p.perm_p, pp = m0r - blk * p.perm_p;
+            int px = blk / p.perm_y, py = blk - px * p.perm_y;
+#pragma unroll
+            for (int mf = 0; mf < NMF; ++mf) {
+                mo[mf] = (py * p.perm_x + px) * p.perm_p + pp;
+                pp += 16;
+                if (pp >= p.perm_p) {
+                    pp -= p.perm_p;
+                    if (++py == p.perm_y) py = 0, ++px;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int mf = 0; mf < NMF; ++mf) mo[mf] = m0r + 16 * mf;
+        }
+    }
     u32x4 outp[NMF][2];
     f32x4 gs[4], gq[4];  // STATS = 1: per-channel partial sums of this lane ([2 h + k]: channels nc[h] + 4 k .. + 3)
 #pragma unroll
@@ -456,7 +483,8 @@ HV_DEV void hv_gemm_epilogue_fast_perm(const HvGemmParams& p, f32x4 (&acc)[4][NM
                 }
             }
             if (RES) {
-                const unsigned ro = (unsigned)mc * (unsigned)p.ldr * 2u;
+                // (rows beyond M: any valid row -- the clamped logical one -- their results are not stored)
+                const unsigned ro = (unsigned)(m_base + 16 * (g + j) + r16 < p.M ? mo[g + j] : mc) * (unsigned)p.ldr * 2u;
 #pragma unroll
                 for (int h = 0; h < 2; ++h)
                     res4[j][h] = hv_ld16(reinterpret_cast<const char*>(p.residual) + (ro + 2u * (unsigned)nc[h]));
@@ -517,7 +545,7 @@ HV_DEV void hv_gemm_epilogue_fast_perm(const HvGemmParams& p, f32x4 (&acc)[4][NM
     for (int mf = 0; mf < NMF; ++mf) {
         const int m = m_base + 16 * mf + r16;
         if (m >= p.M) continue;
-        const unsigned yo = (unsigned)m * (unsigned)p.ldy * 2u;
+        const unsigned yo = (unsigned)mo[mf] * (unsigned)p.ldy * 2u;
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             const int n = n_base + 32 * h + 8 * quad;
@@ -535,7 +563,7 @@ HV_DEV void hv_gemm_epilogue_fast_perm(const HvGemmParams& p, f32x4 (&acc)[4][NM
             a += __shfl_xor(a, 32);
             b += __shfl_xor(b, 32);
             const int m = m_base + 16 * mf + r16;
-            if (quad == 0 && m < p.M) *reinterpret_cast<u32x2*>(p.ln_part + ((long)m * parts + blk) * 2) =
+            if (quad == 0 && m < p.M) *reinterpret_cast<u32x2*>(p.ln_part + ((long)mo[mf] * parts + blk) * 2) =
                 u32x2{__builtin_bit_cast(unsigned, a), __builtin_bit_cast(unsigned, b)};
         }
     }
@@ -659,7 +687,10 @@ HV_DEV void hv_gemm_epilogue(const HvGemmParams& p, f32x4 (&acc)[4][NMF], int m_
 enum { HV_FORM_NONE = -1, HV_FORM_LN = 0, HV_FORM_LN_YT = 1, HV_FORM_LN_GEGLU = 2, HV_FORM_RES = 3, HV_FORM_PLAIN = 4 };
 
 static inline int hv_gemm_fast_form(const HvGemmParams& p, int rows_per_wave) {
-    if (p.out_act != HV_ACT_NONE || p.out_f32 || p.perm_p != 0) return HV_FORM_NONE;
+    if (p.out_act != HV_ACT_NONE || p.out_f32) return HV_FORM_NONE;
+    // a row permutation of the output: only the permuted-channel epilogue of the plain-output forms knows it
+    // (hv_gemm_epilogue_fast_perm; hv_gemm_choose checks that this epilogue is the one that runs), in steps of 16 rows
+    if (p.perm_p != 0 && (p.perm_p < 16 || p.geglu || p.Yt != nullptr || p.gn_part != nullptr)) return HV_FORM_NONE;
     if (p.pe != nullptr && p.rowvec != nullptr) return HV_FORM_NONE;
     // one table row per wave sub-tile: sub-tiles start at multiples of rows_per_wave
     if (p.pe != nullptr && (p.pe_period <= 0 || p.pe_period % rows_per_wave != 0)) return HV_FORM_NONE;
@@ -1402,6 +1433,7 @@ static inline HvGemmChoice hv_gemm_choose(const HvGemmParams& p, bool want_stats
 static inline int hv_gemm_gn_parts_of(const HvGemmParams& p) {
     const HvGemmChoice c = hv_gemm_choose(p, true);
     if (c.kernel != 2 || !c.perm || (c.form != HV_FORM_RES && c.form != HV_FORM_PLAIN)) return 0;
+    if (p.perm_p != 0) return 0;  // (a wave's rows are not one image's after the row permutation)
     const int rows = 64;  // rows of a wave's sub-tile = rows per partial sum
     if (p.gn_rows_per_image <= 0 || p.gn_rows_per_image % rows != 0 || p.M % p.gn_rows_per_image != 0) return 0;
     return p.gn_rows_per_image / rows;
@@ -1428,7 +1460,7 @@ static inline HvGemmChoice hv_gemm_choose(const HvGemmParams& p, bool want_stats
     // 0.086 -> 0.097 ms, ff2 0.303 -> 0.296).  Tuning value 6 = never (A/B).  The kernel leaves no normalisation statistics: a
     // problem that asks for them stays on the square tiles.
     if (g_hv_gemm_glds != 6 && g_hv_gemm_glds != 2 && g_hv_gemm_glds != 3 && p.N == 320 && p.K >= 640 && g_hv_gemm_perm &&
-        p.X2 == nullptr && p.M % 256 == 0 && p.Yt == nullptr && !p.geglu && p.bias != nullptr && !want_stats) {
+        p.perm_p == 0 && p.X2 == nullptr && p.M % 256 == 0 && p.Yt == nullptr && !p.geglu && p.bias != nullptr && !want_stats) {
         const int form32 = hv_gemm_fast_form(p, 32);
         if (form32 == HV_FORM_RES || form32 == HV_FORM_PLAIN || form32 == HV_FORM_LN) {
             c.kernel = 3;
@@ -1447,12 +1479,14 @@ static inline HvGemmChoice hv_gemm_choose(const HvGemmParams& p, bool want_stats
     const int t256 = tm * (n256 / 256), rounds256 = (t256 + 255) / 256;
     const bool fills256 = t256 * 10 >= rounds256 * 256 * 9;
     const bool shape256 = ok128 && p.N >= 960 && (n256 - p.N) * 8 <= p.N;
-    const bool big = g_hv_gemm_glds != 3 && shape256 && (fills256 || g_hv_gemm_glds == 2);  // (value 6 selects like 1 here)
+    const bool big = g_hv_gemm_glds != 3 && shape256 && (fills256 || g_hv_gemm_glds == 2) &&
+                     p.perm_p == 0;  // (value 6 selects like 1 here; a row-permuted output: the 128 x 128 kernel's epilogue)
     c.kernel = big ? 1 : 2;
     c.form = big ? form128 : form64;
     // plain bf16 outputs (plain / residual / LayerNorm fold) and GEGLU with N % 8 == 0: permuted channel assignment, 16-byte epilogue
     c.perm = g_hv_gemm_perm && p.N % 8 == 0 &&
              (c.form == HV_FORM_RES || c.form == HV_FORM_PLAIN || c.form == HV_FORM_LN || c.form == HV_FORM_LN_GEGLU);
+    if (p.perm_p != 0 && !c.perm) return HvGemmChoice{0, HV_FORM_NONE, 1, false};  // row-permuted output: that epilogue only
     return c;
 }
 

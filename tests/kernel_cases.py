@@ -80,8 +80,11 @@ def case_gemm(cx: Ctx, M=200, N=320, K=320, seed=0, residual=True, out_f32=False
     return e
 
 
-def case_gemm_row_perm(cx: Ctx, X=6, Y=4, P=24, N=320, K=320, seed=20):
-    """row-permuted output (+ residual read): row (x*Y + y)*P + p lands at (y*X + x)*P + p, with the LN fold and a bias"""
+def case_gemm_row_perm(cx: Ctx, X=6, Y=4, P=24, N=320, K=320, seed=20, form="res"):
+    """row-permuted output (+ residual read): row (x*Y + y)*P + p lands at (y*X + x)*P + p.
+    form "res": bias + residual read at the DESTINATION row (the frame-sharded motion module's output projection);
+    "ln": the LayerNorm fold (row statistics of the LOGICAL input row) + bias, no residual (its QKV projection);
+    "res_stats": "res" + the LayerNorm partial statistics of the output (ln_part), which belong to the DESTINATION row."""
     g = torch.Generator().manual_seed(seed)
     M = X * Y * P
     x, w = rnd(g, M, K), rnd(g, N, K, scale=K**-0.5)
@@ -90,13 +93,33 @@ def case_gemm_row_perm(cx: Ctx, X=6, Y=4, P=24, N=320, K=320, seed=20):
     blk, pp = idx // P, idx % P
     dst = ((blk % Y) * X + blk // Y) * P + pp
     ref = torch.zeros(M, N)
-    ref[dst] = r(x) @ r(w).t() + bias
-    ref = ref + r(res)  # the residual is read at the DESTINATION row
     y = torch.zeros(M, N, dtype=BF16, device=cx.device)
-    ops.gemm(cx.lib, cx.stream, cx.bf(x), cx.bf(w), y, bias=cx.dev(bias), residual=cx.bf(res), row_perm=(X, Y, P))
+    kw = dict(bias=cx.dev(bias), row_perm=(X, Y, P))
+    if form == "ln":
+        mean, rstd = rnd(g, M, scale=0.3), 0.5 + torch.rand(M, generator=g)
+        colsum = r(w).sum(dim=1)
+        ref[dst] = rstd[:, None] * (r(x) @ r(w).t() - mean[:, None] * colsum[None, :]) + bias
+        kw.update(row_mean=cx.dev(mean), row_rstd=cx.dev(rstd), colsum=cx.dev(colsum))
+    else:
+        ref[dst] = r(x) @ r(w).t() + bias
+        ref = ref + r(res)  # the residual is read at the DESTINATION row
+        kw.update(residual=cx.bf(res))
+    part = None
+    if form == "res_stats":
+        np_ = ops.gemm(cx.lib, cx.stream, cx.bf(x), cx.bf(w), y, query_ln_parts=True, **kw)
+        if np_ > 0:  # (0: this problem runs on a kernel that leaves no statistics -- nothing to check beyond the output)
+            part = torch.full((M, np_, 2), float("nan"), dtype=torch.float32, device=cx.device)
+            kw["ln_part"] = part
+    ops.gemm(cx.lib, cx.stream, cx.bf(x), cx.bf(w), y, **kw)
     cx.sync()
     e = nrmse(y, ref)
-    assert e < TOL, f"gemm row_perm nrmse {e}"
+    assert e < TOL, f"gemm row_perm ({form}) nrmse {e}"
+    if part is not None:
+        got = part.cpu().double().sum(dim=1)  # per DESTINATION row: sum and sum of squares over all columns
+        want = torch.stack([ref.double().sum(dim=1), (ref.double() ** 2).sum(dim=1)], dim=1)
+        assert torch.isfinite(got).all()
+        es = float((got - want).norm() / want.norm())
+        assert es < 5e-3, f"gemm row_perm ln_part nrmse {es}"
     return e
 
 

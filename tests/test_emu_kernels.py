@@ -276,6 +276,11 @@ def test_conv_two_source_narrow(cx):
 def test_gemm_row_permutation(cx):
     kc.case_gemm_row_perm(cx)
     kc.case_gemm_row_perm(cx, X=3, Y=2, P=50, N=192, K=128, seed=21)  # ragged against the 128/256-row tiles
+    # the LDS-DMA kernels' permuted-channel epilogue knows the row permutation (P >= 16): M >= 256 puts these on it
+    kc.case_gemm_row_perm(cx, X=4, Y=3, P=32, N=128, K=64, seed=22)
+    kc.case_gemm_row_perm(cx, X=3, Y=4, P=24, N=128, K=64, seed=23, form="ln")            # steps of 16 rows across P = 24 blocks
+    kc.case_gemm_row_perm(cx, X=4, Y=3, P=32, N=128, K=64, seed=24, form="res_stats")
+    kc.case_gemm_row_perm(cx, X=5, Y=3, P=20, N=64, K=64, seed=25, form="res_stats")     # M = 300: ragged last tile
 
 
 def test_layernorm_stats(cx):

@@ -27,6 +27,10 @@ def test_gemm(cx):
 def test_gemm_row_permutation(cx):
     kc.case_gemm_row_perm(cx, X=48, Y=8, P=96, N=960, K=320)   # frame-sharded QKV -> all-to-all send layout
     kc.case_gemm_row_perm(cx, X=8, Y=48, P=96, N=320, K=320)   # output projection folding the way back
+    kc.case_gemm_row_perm(cx, X=48, Y=8, P=768, N=960, K=320, form="ln")        # config #4 per-rank level 0: QKV, LayerNorm fold
+    kc.case_gemm_row_perm(cx, X=8, Y=6, P=768, N=320, K=320, form="res_stats")   # ... output projection + LayerNorm statistics
+    kc.case_gemm_row_perm(cx, X=6, Y=8, P=24, N=1280, K=1280, form="res_stats")  # level 2 at 8 ranks (P = 192 / 8)
+    kc.case_gemm_row_perm(cx, X=6, Y=8, P=12, N=1280, K=1280)                      # level 3 (P < 16): the register-staged kernel
 
 
 def test_gemm_fused(cx):

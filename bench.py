@@ -294,10 +294,12 @@ def main():
     ap.add_argument("--window-groups", type=int, default=1,
                     help="N > 1 GPUs: split the ranks into this many groups that take different context windows of a step "
                          "(window-parallel x frame-shard; clips with several windows per step, e.g. --config 5)")
-    ap.add_argument("--cfg-streams", default="auto", choices=["auto", "0", "1"],
+    ap.add_argument("--cfg-streams", default="0", choices=["auto", "0", "1"],
                     help="N > 1 GPUs: the two CFG halves of a step on two streams, replayed interleaved, so that one half's temporal "
-                         "exchange runs under the other half's kernels (DESIGN.md section 5).  auto: on, after a three-step probe "
-                         "run outside the timed region; if the probe raises, the serial path is timed and the line says so")
+                         "exchange runs under the other half's kernels (DESIGN.md section 5).  Default 0 = the serial replay (the "
+                         "overlapped one has never run with more than one rank on the real transport); 1: on; auto: on after a "
+                         "three-step probe run outside the timed region -- if the probe raises, the serial path is timed and the "
+                         "line says so (a rank that hangs inside a collective is NOT caught by the probe)")
     ap.add_argument("--single-rank-sharded", action="store_true",
                     help="diagnostic (N = 1 only): run the SHARDED code path -- exchange layouts, graph-replayed command-list "
                          "segments, CFG halves on two streams, every collective through RCCL -- with a process group of one rank: "

@@ -1185,6 +1185,8 @@ __global__ __launch_bounds__(NW * 64, 2) void hv_gemm_glds_kernel(HvGemmParams p
     }
 }
 
+#include "hv_gemm_p8.h"  // round 5: the 256 x 256 x 64 tile on deeper rings (hv_gemm_p8_kernel)
+
 // ---- epilogue of the wide-tile kernel (below): one wave's 32 rows x 320 columns = five 64-column blocks under the permuted
 // channel assignment (hv_perm_row: the fragment pair (2 j, 2 j + 1) of a lane is the 8 consecutive channels 64 b + 32 j + 8 quad).
 // Round 3 called hv_gemm_epilogue_fast_perm once per block: the five copies of the run-time form switch and of the pointer
@@ -1420,6 +1422,7 @@ static int g_hv_gemm_max_grid = 512;  // tuning knob (hv_set_tuning): persistent
 //   6: as 1 without the wide tiles (the round-3 default; A/B)
 static int g_hv_gemm_glds = 1;
 static int g_hv_gemm_perm = 1;  // tuning knob (hv_set_tuning key 6): 16-byte epilogue through the permuted channel assignment (A/B)
+static int g_hv_gemm_p8 = 1;    // tuning knob (hv_set_tuning key 8): 256 x 256 x 64 tiles on the 8-interval loop (hv_gemm_p8_kernel); 0: the two-group loop (A/B, bit-identical)
 
 // Which kernel hv_gemm_launch takes for a problem: 0 register-staged, 1 = 256x256x64, 2 = 128x128x64 (LDS-DMA); perm = the
 // permuted channel assignment.  Shared with hv_gemm_gn_parts so that the caller sizes gn_part for the kernel that will run.
@@ -1519,7 +1522,24 @@ static inline int hv_gemm_launch(const HvGemmParams& p, hipStream_t stream) {
         int grid = ((t256 + 7) / 8) * 8;
         if (grid > 256) grid = 256;
         if (grid > g_hv_gemm_max_grid) grid = g_hv_gemm_max_grid;
-        if (c.perm) {
+        // hv_gemm_p8_kernel: whole 64-row pieces only (scalar piece bases); GEGLU's fragment rows are a template parameter
+        if (g_hv_gemm_p8 && p.M % 64 == 0 && p.N % 64 == 0) {
+            const bool geglu = c.perm && c.form == HV_FORM_LN_GEGLU;
+            const bool free_run = g_hv_gemm_p8 == 2;
+            hv_note("hv_gemm_p8_kernel<%s%s%s> | %s", c.perm ? "perm" : "", geglu ? ",geglu" : "", free_run ? ",1" : ",0", shape);
+#define HV_P8_LAUNCH(PERM_, GEGLU_, SCHED_) \
+    hv_launch(hv_gemm_p8_kernel<PERM_, GEGLU_, SCHED_>, dim3(grid), dim3(512), stream, p, c.gm, c.form)
+            if (free_run) {
+                if (geglu) HV_P8_LAUNCH(true, true, 1);
+                else if (c.perm) HV_P8_LAUNCH(true, false, 1);
+                else HV_P8_LAUNCH(false, false, 1);
+            } else {
+                if (geglu) HV_P8_LAUNCH(true, true, 0);
+                else if (c.perm) HV_P8_LAUNCH(true, false, 0);
+                else HV_P8_LAUNCH(false, false, 0);
+            }
+#undef HV_P8_LAUNCH
+        } else if (c.perm) {
             hv_note("hv_gemm_glds_kernel<256,8,256,1,perm> | %s", shape);
             hv_launch(hv_gemm_glds_kernel<256, 8, 256, 1, true>, dim3(grid), dim3(512), stream, p, c.gm, c.form);
         } else {

@@ -82,14 +82,16 @@ class UNet3DEngine:
     def stream(self) -> int:
         return hvlib.current_stream()
 
-    def clone_for_half(self, half: int) -> "UNet3DEngine":
+    def clone_for_half(self, half: int, ws: "Workspace | None" = None) -> "UNet3DEngine":
         """An executor for ONE CFG half (batch entry `half` of [unconditional, conditional]) with its own workspace and
         statistics tables, sharing the packed weights, the projected reference banks and the folded cross-attention
-        constants of this one (read-only during a step).  Make the clones after the banks / embeddings are set."""
+        constants of this one (read-only during a step).  Make the clones after the banks / embeddings are set.
+        `ws`: a workspace kept by the caller across calls (the pipeline caches one per half and stream, so that repeated
+        denoise() calls do not re-allocate gigabytes on freshly drawn side streams)."""
         import copy
 
         e = copy.copy(self)
-        e.ws = Workspace(self.device)
+        e.ws = ws if ws is not None else Workspace(self.device)
         mmk = self.cfg.get("motion_module_kwargs") or {}
         e.run = Runner(self.device, self.w, e.ws, self.groups, self.shard, temporal_heads=mmk.get("num_attention_heads", 8))
         e._sel_cache = {}

@@ -357,8 +357,18 @@ class Pose2VideoPipeline:
         sharded = self.shard is not None and self.shard.active
         overlap = sharded and do_cfg and use_graph and getattr(self.shard, "overlap_cfg", False)
         if overlap:
-            halves = [eng.clone_for_half(hf) for hf in (0, 1)]
-            streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+            # the two half-engines' workspaces and their streams live on the pipeline: torch caches freed blocks per stream and
+            # torch.cuda.Stream() rotates through a pool, so per-call clones re-allocated every buffer; the
+            # clones themselves are re-linked per call (they share this call's banks / folded constants by reference)
+            cache = self.__dict__.setdefault("_half_state", {})
+            if cache.get("engine") is not eng:
+                from .engine import Workspace
+
+                cache.clear()
+                cache.update(engine=eng, ws=[Workspace(eng.device), Workspace(eng.device)],
+                             streams=[torch.cuda.Stream(), torch.cuda.Stream()])
+            halves = [eng.clone_for_half(hf, ws=cache["ws"][hf]) for hf in (0, 1)]
+            streams = cache["streams"]
             x_half = [[e.ws.get(f"pipe_x_in_{i}", (fl, h, w, 32)) for i, (_, fl, _) in enumerate(plans)] for e in halves]
             for xs in x_half:
                 for x in xs:

@@ -89,12 +89,13 @@ class FrameShard:
         # K/V of all frames on every rank (6.0 GB); SURVEY.md section 8(e)
         self.exchange = os.environ.get("HUMANVID_TEMPORAL_EXCHANGE", "alltoall")
         # exchange / compute overlap of a guided (CFG) step: the two halves on two streams, replayed interleaved
-        # (Pose2VideoPipeline.denoise, StepRecorder.replay_interleaved).  Default ON with RCCL (device collectives), where an
-        # exchange is asynchronous to the other half's kernels; the host-staged transport of the CPU / one-GPU tests
-        # synchronises in every collective and gains nothing, so it stays off there unless HUMANVID_CFG_STREAMS=1 asks for it
-        # (the tests do: same result, bit for bit).
-        env = os.environ.get("HUMANVID_CFG_STREAMS")
-        self.overlap_cfg = (not self.staged) if env is None else env == "1"
+        # (Pose2VideoPipeline.denoise, StepRecorder.replay_interleaved).  OPT-IN (HUMANVID_CFG_STREAMS=1, bench.py --cfg-streams 1):
+        # the choreography -- collectives issued from two streams next to graph-replayed segments -- is verified bit for bit
+        # on the host-staged transport and on a ONE-rank RCCL group (tests/test_gpu_sharded.py), but it has never run with more
+        # than one rank on the real transport, and a rank that fails inside a collective would hang its peers: until a
+        # multi-rank run has shown bit-identity against the serial replay, the serial replay is the default everywhere
+        # (ADVICE round 4).
+        self.overlap_cfg = os.environ.get("HUMANVID_CFG_STREAMS") == "1"
         # diagnostics for the scaling runs (bench.py --gpus N): with `measure` on, every collective is counted with the bytes
         # this rank sends and bracketed by two events on the compute stream -- the kernels behind a collective wait for
         # it, so the event distance is the exchange time the step is EXPOSED to (nothing overlaps it yet)

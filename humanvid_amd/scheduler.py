@@ -122,18 +122,30 @@ def fused_step_coefficients(sched, timestep: int, num_inference_steps: int):
     abar = getattr(sched, "alphas_cumprod", None)
     if abar is None:
         raise NotImplementedError("the scheduler has no alphas_cumprod: a DDIM-style scheduler is required")
-    # Only DDIM's update is fused.  Multistep / higher-order / ancestral samplers of diffusers (DPMSolver*, PNDM, UniPC,
-    # Euler*, Heun, LMS, KDPM2 ...) also carry alphas_cumprod and would pass the checks above while following a different
-    # update rule: recognised by what DDIM does not have (an order above 1, a sigma table, solver state) and refused.
-    if int(attr("order", 1) or 1) != 1 or hasattr(sched, "sigmas") or hasattr(sched, "model_outputs") or \
-            hasattr(sched, "ets") or attr("solver_order") is not None or attr("algorithm_type") is not None:
-        raise NotImplementedError(f"{type(sched).__name__} is not a DDIM-style scheduler: the fused CFG + DDIM step would sample "
-                                  "it with DDIM (eta = 0) coefficients")
+    # Only DDIM's update is fused, so the check is POSITIVE (ancestral / consistency samplers such as
+    # DDPMScheduler or LCMScheduler are first order, carry alphas_cumprod and no sigma table -- a blacklist lets them
+    # through and samples them with DDIM eta = 0 coefficients): the scheduler must be DDIM by name or by shape -- a
+    # `final_alpha_cumprod` AND a step() that takes `eta` -- and must not carry what DDIM does not have (an order above 1,
+    # a sigma table, multistep solver state).
+    import inspect
+
+    name = type(sched).__name__
+    step_fn = getattr(sched, "step", None)
+    try:
+        takes_eta = step_fn is not None and "eta" in inspect.signature(step_fn).parameters
+    except (TypeError, ValueError):
+        takes_eta = False
+    ddim_like = "DDIM" in name or (hasattr(sched, "final_alpha_cumprod") and takes_eta)
+    if not ddim_like or not hasattr(sched, "final_alpha_cumprod") or int(attr("order", 1) or 1) != 1 or \
+            hasattr(sched, "sigmas") or hasattr(sched, "model_outputs") or hasattr(sched, "ets") or \
+            attr("solver_order") is not None or attr("algorithm_type") is not None:
+        raise NotImplementedError(f"{name} is not a DDIM scheduler (needs final_alpha_cumprod and a DDIM step(..., eta)): the fused "
+                                  "CFG + DDIM step would sample it with DDIM (eta = 0) coefficients")
     T = int(attr("num_train_timesteps", len(abar)))
     t = int(timestep)
     prev = t - T // int(num_inference_steps)
     a = abar[t].float() if isinstance(abar, torch.Tensor) else torch.tensor(float(abar[t]))
-    final = getattr(sched, "final_alpha_cumprod", torch.tensor(1.0))
+    final = sched.final_alpha_cumprod
     ap = (abar[prev] if prev >= 0 else final)
     ap = ap.float() if isinstance(ap, torch.Tensor) else torch.tensor(float(ap))
     sa, s1a, sap, s1ap = float(a.sqrt()), float((1 - a).sqrt()), float(ap.sqrt()), float((1 - ap).sqrt())

@@ -175,7 +175,8 @@ def test_fused_step_coefficients_cover_v_and_epsilon_prediction():
         s.set_timesteps(25)
         like = types.SimpleNamespace(alphas_cumprod=s.alphas_cumprod, final_alpha_cumprod=s.final_alpha_cumprod,
                                      config=dict(prediction_type=kw["prediction_type"], num_train_timesteps=1000,
-                                                 clip_sample=False))
+                                                 clip_sample=False),
+                                     step=lambda model_output, timestep, sample, eta=0.0: None)  # diffusers' DDIM shape
         for t in s.timesteps.tolist()[:3] + s.timesteps.tolist()[-2:]:
             c = fused_step_coefficients(s, t, 25)
             assert c == fused_step_coefficients(like, t, 25)
@@ -197,6 +198,31 @@ def test_fused_step_coefficients_cover_v_and_epsilon_prediction():
                                                                                algorithm_type="dpmsolver++"))
     with pytest.raises(NotImplementedError):
         fused_step_coefficients(dpm, 10, 25)
+
+    # first-order schedulers WITHOUT a sigma table that are not DDIM (DDPM: ancestral; LCM: consistency): the check is positive
+    class DDPMScheduler:  # diffusers' shape: alphas_cumprod, order 1, step() without eta, no final_alpha_cumprod
+        order = 1
+
+        def __init__(self):
+            self.alphas_cumprod, self.config = s.alphas_cumprod, dict(prediction_type="epsilon")
+
+        def step(self, model_output, timestep, sample, generator=None):
+            raise AssertionError
+
+    class LCMScheduler(DDPMScheduler):  # carries final_alpha_cumprod, still no eta
+        def __init__(self):
+            super().__init__()
+            self.final_alpha_cumprod = torch.tensor(1.0)
+
+    for cls in (DDPMScheduler, LCMScheduler):
+        with pytest.raises(NotImplementedError):
+            fused_step_coefficients(cls(), 10, 25)
+
+    class MyScheduler(LCMScheduler):  # DDIM by shape (final_alpha_cumprod + step(..., eta)) under another name: accepted
+        def step(self, model_output, timestep, sample, eta=0.0):
+            raise AssertionError
+
+    assert len(fused_step_coefficients(MyScheduler(), 10, 25)) == 4
 
 
 def test_camera_front_end_matches_golden():

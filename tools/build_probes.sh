@@ -8,6 +8,7 @@ $H tools/fillbw.hip -o tools/bin/fillbw
 $H tools/storebw.hip -o tools/bin/storebw
 $H tools/valubw.hip -o tools/bin/valubw
 $H tools/valu_rate.hip -o tools/bin/valu_rate
+$H tools/dmabw.hip -o tools/bin/dmabw
 $H -Iinclude -Ihumanvid_amd/csrc -DHV_GEMM_TRACE=0 tools/gemm_trace.hip -o tools/bin/gemm_trace
 $H -Iinclude -Ihumanvid_amd/csrc -DHV_GEMM_TRACE=0 tools/attn_trace.hip -o tools/bin/attn_trace
 ls -la tools/bin

@@ -194,7 +194,7 @@ def roofline_from_profile(kernels, traffic_file):
         t = json.load(open(traffic_file))
         if t.get("csrc_digest") != csrc_digest():
             roof["traffic_note"] = (f"refused {os.path.basename(traffic_file)}: collected with kernel sources "
-                                    f"{t.get('csrc_digest')}, this build is {csrc_digest()} (re-run tools/final_r04.sh)")
+                                    f"{t.get('csrc_digest')}, this build is {csrc_digest()} (re-run tools/final_r05.sh)")
         else:
             k = t.get("kernels", {}).get(name)
             if k is not None:
@@ -212,10 +212,10 @@ def roofline_from_profile(kernels, traffic_file):
 
 
 def cpu_baseline(budget_hw=(48, 32), frames=24):
-    """Time the fp32 oracle (a port of the reference's forward) on THIS host's cores on a bounded sample: one CFG UNet forward +
-    DDIM update at F=24, full SD-1.5 widths, latent 48x32 = a QUARTER of the config-#3 pixels (round 3 sampled 1/16 and
-    scaled by 22.5), scaled to config #3 by the as-written FLOP ratio (~4.6: the spatial attention is
-    quadratic in the pixels).  --cpu-baseline full times the whole 96x64 step instead (several minutes on 128 cores)."""
+    """Time the fp32 oracle (a port of the reference's forward) on THIS host's cores: one CFG UNet forward + DDIM update at
+    F=24, full SD-1.5 widths.  Default since round 5: the WHOLE config-#3 step (latent 96x64: no
+    scaling, ~5.5 min on the bench host's 128 cores).  --cpu-baseline quarter: latent 48x32 = a quarter of the pixels, scaled
+    to config #3 by the as-written FLOP ratio (~5.2: the spatial attention is quadratic in the pixels)."""
     sys.path.insert(0, os.path.join(REPO, "oracle"))
     import oracle_torch as O  # test infrastructure: timed here as the reported CPU baseline only
 
@@ -306,9 +306,10 @@ def main():
                          "what the sharded schedule costs before any byte crosses xGMI (DESIGN.md section 5)")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-baseline", default="quarter", choices=["quarter", "full"],
-                    help="sample of the CPU baseline (fp32 oracle port on this host's cores): a quarter of the config-3 pixels "
-                         "(default, ~2 min on 128 cores) or the whole step (several minutes)")
+    ap.add_argument("--cpu-baseline", default="full", choices=["quarter", "full"],
+                    help="sample of the CPU baseline (fp32 oracle port on this host's cores): the WHOLE config-3 step (default: a "
+                         "timing, not an extrapolation; ~5.5 min on 128 cores, run after the timed GPU region) or a quarter of "
+                         "the config-3 pixels scaled by the as-written FLOP ratio (~1 min)")
     ap.add_argument("--no-profile", action="store_true", help="skip the profiled extra step (roofline block)")
     args = ap.parse_args()
 
@@ -505,7 +506,7 @@ def main():
         if exchange is not None:
             out["exchange"] = exchange
         if "kernels" in prof:
-            roof, table = roofline_from_profile(prof["kernels"], os.path.join(REPO, "profiles", "r04_pmc_traffic.json"))
+            roof, table = roofline_from_profile(prof["kernels"], os.path.join(REPO, "profiles", "r05_pmc_traffic.json"))
             out["roofline"] = roof
             out["kernels"] = table
         if not sharded and not args.no_cpu_baseline:

@@ -124,11 +124,8 @@ int hv_attention_fp8(const hv_attention_params* p, const float* kscale, const fl
 static int g_hv_cmdlist_graphs = 1;  // hv_set_tuning(HV_TUNE_CMDLIST_GRAPHS): 0 = hv_cmdlist_run re-issues the closures on every run (A/B)
 int hv_set_tuning(int key, int value) {
     if (key == HV_TUNE_ATTN_D40 && (value == 0 || value == 2)) hvk_attention_tune(40, value);
-    else if (key == HV_TUNE_ATTN_QT_D160 && (value == 1 || value == 2)) hvk_attention_tune(160, value);
     else if (key == HV_TUNE_GEMM_MAX_GRID && value >= 8 && value % 8 == 0) hvk_gemm_tune(value);
     else if (key == HV_TUNE_GEMM_GLDS && ((value >= 0 && value <= 3) || value == 6)) hvk_gemm_use_glds(value);
-    else if (key == HV_TUNE_GEMM_PERM && (value == 0 || value == 1)) hvk_gemm_perm(value);
-    else if (key == HV_TUNE_GEMM_P8 && (value >= 0 && value <= 2)) hvk_gemm_p8(value);
     else if (key == HV_TUNE_CONV_GLDS && (value == 0 || value == 1)) hvk_conv_use_glds(value);
     else if (key == HV_TUNE_CONV_BIG && (value >= 0 && value <= 3)) hvk_conv_use_big(value);
     else if (key == HV_TUNE_CONV_RASTER && (value >= 0 && value <= 2)) hvk_conv_raster(value);
@@ -229,33 +226,43 @@ int hv_cmdlist_end(void** list_out) {
     return HV_OK;
 }
 int hv_cmdlist_size(void* list) { return list ? (int)((HvCmdList*)list)->cmds.size() : 0; }
-#ifndef HV_EMU
-static hipStream_t g_hv_capture_stream = nullptr;
-#endif
 int hv_cmdlist_run(void* list, void* stream) {
     if (!list) return hv_fail(HV_EINVAL, "hv_cmdlist_run: null list");
     HvCmdList* cl = (HvCmdList*)list;
 #ifndef HV_EMU
-    if (g_hv_cmdlist_graphs && !cl->cmds.empty()) {
-        if (cl->exec == nullptr) {  // first run: capture the segment's launches into a graph instead of issuing them
-            if (!g_hv_capture_stream && hipStreamCreateWithFlags(&g_hv_capture_stream, hipStreamNonBlocking) != hipSuccess)
-                return hv_fail(HV_EHIP, "hv_cmdlist_run: capture stream");
-            hipError_t e = hipStreamBeginCapture(g_hv_capture_stream, hipStreamCaptureModeRelaxed);
-            if (e != hipSuccess) return hv_fail(HV_EHIP, hipGetErrorString(e));
-            for (auto& c : cl->cmds) c(g_hv_capture_stream);
+    if (g_hv_cmdlist_graphs && !cl->cmds.empty() && !cl->no_graph) {
+        if (cl->exec == nullptr) {
+            // First run: capture the segment's launches into a graph instead of issuing them.  The capture stream is created
+            // per capture on the CURRENT device and destroyed with it (a process-wide one is neither per-device nor
+            // thread-safe, and a failed hipStreamEndCapture would leave it in capture mode for every later segment --
+            // ADVICE round 4).  Any failure ends the capture, discards what was built and falls back to re-issuing the
+            // closures for this list from now on: the launches of a failed capture were never executed.
+            hipStream_t cs = nullptr;
             hipGraph_t g = nullptr;
-            e = hipStreamEndCapture(g_hv_capture_stream, &g);
-            if (e != hipSuccess) return hv_fail(HV_EHIP, hipGetErrorString(e));
-            e = hipGraphInstantiate(&cl->exec, g, nullptr, nullptr, 0);
-            (void)hipGraphDestroy(g);
-            if (e != hipSuccess) {
+            bool ok = hipStreamCreateWithFlags(&cs, hipStreamNonBlocking) == hipSuccess;
+            if (ok) {
+                ok = hipStreamBeginCapture(cs, hipStreamCaptureModeRelaxed) == hipSuccess;
+                if (ok) {
+                    for (auto& c : cl->cmds) c(cs);
+                    const bool launched = hipGetLastError() == hipSuccess;  // a launch error inside the capture
+                    ok = hipStreamEndCapture(cs, &g) == hipSuccess && g != nullptr && launched;
+                }
+                if (ok) ok = hipGraphInstantiate(&cl->exec, g, nullptr, nullptr, 0) == hipSuccess;
+                if (g) (void)hipGraphDestroy(g);
+                (void)hipStreamDestroy(cs);
+            }
+            if (!ok) {
+                (void)hipGetLastError();  // clear the sticky error of the failed capture
+                if (cl->exec) (void)hipGraphExecDestroy(cl->exec);
                 cl->exec = nullptr;
-                return hv_fail(HV_EHIP, hipGetErrorString(e));
+                cl->no_graph = true;
             }
         }
-        const hipError_t e = hipGraphLaunch(cl->exec, (hipStream_t)stream);
-        if (e != hipSuccess) return hv_fail(HV_EHIP, hipGetErrorString(e));
-        return HV_OK;
+        if (cl->exec != nullptr) {
+            const hipError_t e = hipGraphLaunch(cl->exec, (hipStream_t)stream);
+            if (e != hipSuccess) return hv_fail(HV_EHIP, hipGetErrorString(e));
+            return HV_OK;
+        }
     }
 #endif
     for (auto& c : cl->cmds) c((hipStream_t)stream);

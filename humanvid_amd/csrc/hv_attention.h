@@ -34,11 +34,6 @@
 #include "humanvid_hip.h"
 #include "hv_attention40.h"
 
-// phase timestamps for tools/attn_trace.hip (which includes hv_gemm.h first with HV_GEMM_TRACE defined)
-#ifndef HV_TRACE
-#define HV_TRACE(id)
-#endif
-
 #ifndef HV_ATTN_THR
 #define HV_ATTN_THR 8.0f  // log2 units: probabilities stay below 2^THR before the reference maximum is raised
 #endif
@@ -283,21 +278,14 @@ __global__ __launch_bounds__(256, (HvAttnOcc<D, QT>::value)) void hv_attention_k
         for (int dt = 0; dt < DT; ++dt) oacc[qt][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
 
-#ifdef HV_GEMM_TRACE
-    int hv_ti = 0;
-#endif
     if (INC) set_source(false);
     load_tile(0);
     __syncthreads();  // LDS initialisation complete before the first tile store
     for (int ti = 0; ti < ntiles; ++ti) {
         const int buf = ti & 1;
-        HV_TRACE(1);
         store_tile(buf);
-        HV_TRACE(2);
         __syncthreads();
-        HV_TRACE(3);
         if (ti + 1 < ntiles) load_tile(ti + 1);
-        HV_TRACE(4);
         const unsigned char* kb = Ks + buf * G::KBYTES + r16 * G::KRS;
         const unsigned char* vb = Vs + buf * G::VBYTES + r16 * G::VRS + quad * 16;
 
@@ -338,7 +326,6 @@ __global__ __launch_bounds__(256, (HvAttnOcc<D, QT>::value)) void hv_attention_k
 #ifndef HV_EMU
         if (D <= 80) __builtin_amdgcn_s_setprio(0);
 #endif
-        HV_TRACE(5);
         // ---- online softmax (exp2 domain) and P^T fragments
         bf16x8 pf[QT][2];
 #pragma unroll
@@ -419,7 +406,6 @@ __global__ __launch_bounds__(256, (HvAttnOcc<D, QT>::value)) void hv_attention_k
                 pf[qt][ks] = hv_as_bf16x8(w);
             }
         }
-        HV_TRACE(6);
         // ---- O^T += V^T . P^T   (row D of V^T is all ones when ONES: accumulates the denominator)
 #ifndef HV_EMU
         if (D <= 80) __builtin_amdgcn_s_setprio(1);  // MFMA clusters at raised priority: -1.7 % at d = 40 (four waves per SIMD)
@@ -436,7 +422,6 @@ __global__ __launch_bounds__(256, (HvAttnOcc<D, QT>::value)) void hv_attention_k
 #ifndef HV_EMU
         if (D <= 80) __builtin_amdgcn_s_setprio(0);
 #endif
-        HV_TRACE(7);
     }
 
     // ---- normalise and store: lane owns query r16, channels 16*dt + 4*quad + 0..3
@@ -481,9 +466,6 @@ static inline void hv_attention_launch_t(const hv_attention_params& p, hipStream
         hv_launch(hv_attention_kernel<D, QT, false>, dim3(grid), dim3(256), stream, p);
 }
 
-// tuning knob (hv_set_tuning): query fragments per wave at head dim 160
-static int g_hv_attn_qt160 = 2;
-
 static inline int hv_attention_launch(const hv_attention_params& p, hipStream_t stream) {
     if (p.L1 <= 0 || p.L1 % 8 != 0 || p.L2 % 8 != 0 || p.Lq <= 0) return -1;
     if (p.ldq % 8 || p.ldk % 8 || p.ldvt % 8 || p.ldo % 4) return -1;
@@ -505,10 +487,7 @@ static inline int hv_attention_launch(const hv_attention_params& p, hipStream_t 
             else hv_attention_launch_t<40, 2>(p, stream);
             break;
         case 80: hv_attention_launch_t<80, 2>(p, stream); break;
-        case 160:
-            if (g_hv_attn_qt160 == 1) hv_attention_launch_t<160, 1>(p, stream);
-            else hv_attention_launch_t<160, 2>(p, stream);
-            break;
+        case 160: hv_attention_launch_t<160, 2>(p, stream); break;  // (one query fragment per wave measured slower in round 2: removed)
         default: return -2;
     }
     return 0;

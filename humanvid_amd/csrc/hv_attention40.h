@@ -101,10 +101,17 @@ struct HvAttn40Geom {
     //   V^T tile: 40 rows x 128 bytes (8 chunks of 8 keys: 320 chunks), chunk position XOR-swizzled by the row (position c of
     //     row r holds keys 8 (c ^ (r & 7)) .. + 7, applied on the source side of the DMA): conflict-free for the 16x16x32
     //     A-operand read.  Row 40 (all ones: the denominator) and rows 41 - 47 (zeros) are two constant chunks.
+    //     Round 5: rows 40 - 47 are laid out like tile rows -- 128 bytes of ones (row 40) and two 128-byte rows of zeros (the
+    //     odd rows 41 .. 47 read row 41, the even rows 42 .. 46 row 42, each at its own swizzled chunk position) -- so that
+    //     the lanes of a ds_read_b128 group that read constants hit the 16-byte windows the design reserves for rows 40 - 47
+    //     instead of all landing on one chunk next to the data lanes': 8 extra LDS cycles per 24 group reads before, none now
+    //     (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE 0.14 in round 4, profiles/r04_lds_conflicts.txt).
     static constexpr int KRS = 80, VRS = 128;
     static constexpr int KBYTES = 64 * KRS, VBYTES = D * VRS;     // 5120 each
-    static constexpr int KSTRIDE = KBYTES + 16, VSTRIDE = VBYTES + 32;  // buffer strides: tile + its constant chunks
-    static constexpr int LDS_BYTES = 2 * KSTRIDE + 2 * VSTRIDE;
+    static constexpr int KSTRIDE = KBYTES + 16, VSTRIDE = VBYTES + 384;  // buffer strides: tile + its constant chunks / rows
+    static constexpr int NBUF = 2;  // (round 5, measured and not kept: four buffers and ONE barrier per two tiles -- 1-2 % slower on the
+                                    //  same box, profiles/r05_s5_attn40.txt: the barrier is not what the tile waits for)
+    static constexpr int LDS_BYTES = NBUF * KSTRIDE + NBUF * VSTRIDE;
 };
 
 template <bool MASK>
@@ -113,7 +120,7 @@ __global__ __launch_bounds__(512, 4) void hv_attention40_kernel(hv_attention_par
     constexpr int D = G::D;
     __shared__ __attribute__((aligned(16))) unsigned char smem[G::LDS_BYTES];
     unsigned char* Ks = smem;                   // buffer b: Ks + b * KSTRIDE  (tile, then the augmented-column chunk)
-    unsigned char* Vs = smem + 2 * G::KSTRIDE;  // buffer b: Vs + b * VSTRIDE  (tile, then the ones chunk, then the zeros chunk)
+    unsigned char* Vs = smem + G::NBUF * G::KSTRIDE;  // buffer b: Vs + b * VSTRIDE  (tile, then the ones row 40, then the zeros row)
 
     const int tid = threadIdx.x, lane = tid & 63;
 #ifndef HV_EMU
@@ -143,9 +150,12 @@ __global__ __launch_bounds__(512, 4) void hv_attention40_kernel(hv_attention_par
     const int ntiles = T1 + T2;
 
     // LDS constants (every tile byte is written by the DMA; the first tile barrier orders these stores before their readers)
-    if (tid < 2) hv_st16(Ks + tid * G::KSTRIDE + G::KBYTES, u32x4{0x00003F80u, 0u, 0u, 0u});
-    if (tid >= 64 && tid < 66) hv_st16(Vs + (tid - 64) * G::VSTRIDE + G::VBYTES, u32x4{0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u});
-    if (tid >= 128 && tid < 130) hv_st16(Vs + (tid - 128) * G::VSTRIDE + G::VBYTES + 16, u32x4{0u, 0u, 0u, 0u});
+    if (tid < G::NBUF) hv_st16(Ks + tid * G::KSTRIDE + G::KBYTES, u32x4{0x00003F80u, 0u, 0u, 0u});
+    if (tid >= 64 && tid < 64 + 24 * G::NBUF) {  // 8 chunks of ones + 16 chunks of zeros behind every V^T buffer
+        const int i = tid - 64, b = i / 24, c = i - 24 * b;
+        const unsigned one2 = c < 8 ? 0x3F803F80u : 0u;
+        hv_st16(Vs + b * G::VSTRIDE + G::VBYTES + 16 * c, u32x4{one2, one2, one2, one2});
+    }
 
     // ---- query fragments: B operand of S^T = K.Q^T (32x32x16): lane = query l32, elements = head-dim 16 s + 8 half + 0..7;
     //      pre-multiplied by scale * log2(e) (scores come out of the MFMA in the exp2 domain); step 2 of the upper half is the
@@ -222,7 +232,8 @@ __global__ __launch_bounds__(512, 4) void hv_attention40_kernel(hv_attention_par
 #pragma unroll
         for (int kbk = 0; kbk < 2; ++kbk) {
             const int row = 16 * dt + r16;
-            vrd[dt][kbk] = row < D ? row * G::VRS + (((quad + 4 * kbk) ^ (row & 7)) << 4) : (row == D ? G::VBYTES : G::VBYTES + 16);
+            // rows 41 - 47 read a zeros row of their own bank half (odd: row 41's place, even: row 42's) at their own position
+            vrd[dt][kbk] = (row <= D ? row : D + 2 - (row & 1)) * G::VRS + (((quad + 4 * kbk) ^ (row & 7)) << 4);
         }
 
     f32x4 oacc[2][3];  // O^T accumulators [16-query tile][16-row channel fragment]: lane = query r16, channels 16 dt + 4 quad + 0..3

@@ -233,6 +233,7 @@ struct HvCmdList {
     // ~700 launches cut into ~90 segments by its collectives: ~90 graph launches instead of ~700 std::function calls + kernel
     // launches from the host per step and rank
     hipGraphExec_t exec = nullptr;
+    bool no_graph = false;  // the capture of this list failed once: re-issue its closures instead
     ~HvCmdList() {
         if (exec) (void)hipGraphExecDestroy(exec);
     }

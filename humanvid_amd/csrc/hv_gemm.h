@@ -83,21 +83,6 @@ HV_DEV f32x4 hv_gelu_times(f32x4 x, f32x4 h) {
     return f32x4{a[0], a[1], b[0], b[1]};
 }
 
-// Optional phase timestamps (tools/gemm_trace.hip): wave 0 of workgroup HV_GEMM_TRACE logs (id, s_memtime).
-#ifdef HV_GEMM_TRACE
-__device__ unsigned long long g_hv_trace[8192];
-#define HV_TRACE_PARAM , int& hv_ti
-#define HV_TRACE_ARG , hv_ti
-#define HV_TRACE(id)                                                                                  \
-    do {                                                                                              \
-        if (blockIdx.x == HV_GEMM_TRACE && threadIdx.x == 0 && hv_ti < 8192)                          \
-            g_hv_trace[hv_ti++] = ((unsigned long long)(id) << 56) | (__builtin_amdgcn_s_memtime() & 0xffffffffffffffull); \
-    } while (0)
-#else
-#define HV_TRACE_PARAM
-#define HV_TRACE_ARG
-#define HV_TRACE(id)
-#endif
 constexpr int HV_GEMM_EPI_G = 2;  // row fragments per load group of the fast epilogues (the register budget of the 256 x 256 kernel)
 
 // ---- epilogue of one wave's (16*NMF) x 64 sub-tile: lane owns token m (column of the MFMA tile) and 4
@@ -110,7 +95,7 @@ constexpr int HV_GEMM_EPI_G = 2;  // row fragments per load group of the fast ep
 //   output).  The fully general body is ~100 KB of code per kernel and ran out of the instruction
 //   cache once per tile (measured: 0.29 of 0.61 ms of the level-0 QKV GEMM with the stores disabled).
 template <int NMF, int MODE>
-HV_DEV void hv_gemm_epilogue_t(const HvGemmParams& p, f32x4 (&acc)[4][NMF], int m_base, int n_base, int r16, int quad HV_TRACE_PARAM) {
+HV_DEV void hv_gemm_epilogue_t(const HvGemmParams& p, f32x4 (&acc)[4][NMF], int m_base, int n_base, int r16, int quad) {
     const bool geglu = MODE == 3 ? true : (MODE == 0 ? p.geglu != 0 : false);
     const bool has_t = MODE == 2 ? true : (MODE == 0 ? p.Yt != nullptr : false);
     const bool out_f32 = MODE == 0 ? p.out_f32 != 0 : false;
@@ -178,7 +163,6 @@ HV_DEV void hv_gemm_epilogue_t(const HvGemmParams& p, f32x4 (&acc)[4][NMF], int 
             for (int nf = 0; nf < 4; ++nf) row4[nf] += *reinterpret_cast<const f32x4*>(rv_row + nc[nf]);
         }
         // phase 2: arithmetic and stores
-        if (mf == 0) HV_TRACE(7);
         char* yrow = reinterpret_cast<char*>(p.Y) + (long)(MODE == 0 ? (m < p.M ? mo : m) : m) * p.ldy * (out_f32 ? 4 : 2);
 #pragma unroll
         for (int nf = 0; nf < 4; ++nf) {
@@ -197,12 +181,7 @@ HV_DEV void hv_gemm_epilogue_t(const HvGemmParams& p, f32x4 (&acc)[4][NMF], int 
                 v = hv_gelu_times(v, acc[nf - 1][mf]);
                 v += rres;
                 u32x2 o = {hv_pack2(v[0], v[1]), hv_pack2(v[2], v[3])};
-                if (mf == 2) HV_TRACE(12);
                 if (valid) hv_st8_stream(yrow + 2 * no, o);
-                if (mf == 2) HV_TRACE(13);
-                if (mf == 0 && nf == 1) HV_TRACE(8);
-                if (mf == 0 && nf == 3) HV_TRACE(9);
-                if (mf == 1 && nf == 3) HV_TRACE(10);
                 continue;
             }
             v += rres;
@@ -219,16 +198,10 @@ HV_DEV void hv_gemm_epilogue_t(const HvGemmParams& p, f32x4 (&acc)[4][NMF], int 
                 *reinterpret_cast<f32x4*>(yrow + 4 * n) = v;
             } else {
                 u32x2 o = {hv_pack2(v[0], v[1]), hv_pack2(v[2], v[3])};
-                if (mf == 2) HV_TRACE(12);
                 hv_st8_stream(yrow + 2 * n, o);
-                if (mf == 2) HV_TRACE(13);
-                if (mf == 0 && nf == 0) HV_TRACE(8);
-                if (mf == 0 && nf == 3) HV_TRACE(9);
-                if (mf == 1 && nf == 3) HV_TRACE(10);
             }
         }
     }
-    HV_TRACE(11);
 }
 
 // ---- fast epilogue for the hot output forms (round 2).  What was wrong with the one above, measured with gemm_trace and the
@@ -246,7 +219,7 @@ HV_DEV void hv_gemm_epilogue_t(const HvGemmParams& p, f32x4 (&acc)[4][NMF], int 
 // OUT: 0 = bf16 row-major, 1 = the same with the transposed tail (QKV projection), 2 = GEGLU.
 template <int NMF, bool LN, bool RES, int OUT>
 HV_DEV void hv_gemm_epilogue_fast(const HvGemmParams& p, f32x4 (&acc)[4][NMF], int m_base, int n_base, int r16, int quad,
-                                  const float* tab_row HV_TRACE_PARAM) {
+                                  const float* tab_row) {
     static_assert(!(RES && OUT != 0), "residual only with the plain output form");
     constexpr int G = NMF < HV_GEMM_EPI_G ? NMF : HV_GEMM_EPI_G;  // row fragments per load group
     constexpr int NO = OUT == 2 ? 2 : 4;  // packed 4-channel outputs per row fragment
@@ -302,7 +275,6 @@ HV_DEV void hv_gemm_epilogue_fast(const HvGemmParams& p, f32x4 (&acc)[4][NMF], i
 #if !defined(HV_EMU)
         __builtin_amdgcn_sched_barrier(0);  // the group's loads stay together, ahead of its arithmetic
 #endif
-        if (g == 0) HV_TRACE(7);
 #pragma unroll
         for (int j = 0; j < G; ++j) {
             const int mf = g + j;
@@ -333,7 +305,6 @@ HV_DEV void hv_gemm_epilogue_fast(const HvGemmParams& p, f32x4 (&acc)[4][NMF], i
         __builtin_amdgcn_sched_barrier(0);  // ... and the next group's loads are not hoisted over it (register budget)
 #endif
     }
-    HV_TRACE(12);
 #ifndef HV_EMU
     // Pin the packed results here.  Otherwise hipcc sinks the arithmetic of a fragment into its (edge-masked) store branch;
     // on the path that skips the store the fragment's loads are then never waited for, the register state that reaches the
@@ -377,8 +348,6 @@ HV_DEV void hv_gemm_epilogue_fast(const HvGemmParams& p, f32x4 (&acc)[4][NMF], i
             }
         }
     }
-    HV_TRACE(13);
-    HV_TRACE(11);
 }
 
 // The same epilogue for the permuted channel assignment (hv_perm_row): plain bf16 row-major output with optional LayerNorm
@@ -389,7 +358,7 @@ HV_DEV void hv_gemm_epilogue_fast(const HvGemmParams& p, f32x4 (&acc)[4][NMF], i
 // columns -- in-lane over the lane's 16 channels, then over the four quads that share a row.
 template <int NMF, bool LN, bool RES, int STATS = 0>
 HV_DEV void hv_gemm_epilogue_fast_perm(const HvGemmParams& p, f32x4 (&acc)[4][NMF], int m_base, int n_base, int r16, int quad,
-                                       const float* tab_row HV_TRACE_PARAM) {
+                                       const float* tab_row) {
     constexpr int G = NMF < HV_GEMM_EPI_G ? NMF : HV_GEMM_EPI_G;  // row fragments per load group
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
     int nc[2];
@@ -493,7 +462,6 @@ HV_DEV void hv_gemm_epilogue_fast_perm(const HvGemmParams& p, f32x4 (&acc)[4][NM
 #if !defined(HV_EMU)
         __builtin_amdgcn_sched_barrier(0);  // the group's loads stay together, ahead of its arithmetic
 #endif
-        if (g == 0) HV_TRACE(7);
 #pragma unroll
         for (int j = 0; j < G; ++j) {
             const int mf = g + j;
@@ -530,7 +498,6 @@ HV_DEV void hv_gemm_epilogue_fast_perm(const HvGemmParams& p, f32x4 (&acc)[4][NM
         __builtin_amdgcn_sched_barrier(0);  // ... and the next group's loads are not hoisted over it (register budget)
 #endif
     }
-    HV_TRACE(12);
 #ifndef HV_EMU
     // (pinned results + "no load outstanding": see hv_gemm_epilogue_fast)
 #pragma unroll
@@ -587,15 +554,13 @@ HV_DEV void hv_gemm_epilogue_fast_perm(const HvGemmParams& p, f32x4 (&acc)[4][NM
             }
         }
     }
-    HV_TRACE(13);
-    HV_TRACE(11);
 }
 
 // LayerNorm fold + GEGLU under hv_perm_row_geglu: fragments (0, 1) = h, g of output channels n_base / 2 + 8 quad + 0..3,
 // fragments (2, 3) = h, g of the next four.  N % 32 == 0 (checked by hv_gemm_launch for every GEGLU problem).
 template <int NMF>
 HV_DEV void hv_gemm_epilogue_fast_perm_geglu(const HvGemmParams& p, f32x4 (&acc)[4][NMF], int m_base, int n_base, int r16, int quad,
-                                             const float* tab_row HV_TRACE_PARAM) {
+                                             const float* tab_row) {
     constexpr int G = NMF < HV_GEMM_EPI_G ? NMF : HV_GEMM_EPI_G;
     f32x4 add4[4], cs4[4];
     auto ld4 = [&](const float* base, unsigned byte_ofs) __attribute__((always_inline)) {
@@ -629,7 +594,6 @@ HV_DEV void hv_gemm_epilogue_fast_perm_geglu(const HvGemmParams& p, f32x4 (&acc)
 #if !defined(HV_EMU)
         __builtin_amdgcn_sched_barrier(0);
 #endif
-        if (g == 0) HV_TRACE(7);
 #pragma unroll
         for (int j = 0; j < G; ++j) {
             const int mf = g + j;
@@ -648,13 +612,11 @@ HV_DEV void hv_gemm_epilogue_fast_perm_geglu(const HvGemmParams& p, f32x4 (&acc)
         __builtin_amdgcn_sched_barrier(0);
 #endif
     }
-    HV_TRACE(12);
 #ifndef HV_EMU
 #pragma unroll
     for (int mf = 0; mf < NMF; ++mf) asm volatile("" : "+v"(outp[mf][0]), "+v"(outp[mf][1]), "+v"(outp[mf][2]), "+v"(outp[mf][3]));
     __builtin_amdgcn_s_waitcnt(0x0F70);
 #endif
-    HV_TRACE(9);  // (a trace build's own mark stores are outstanding here: this interval is their write-acknowledge latency)
     char* const yb = reinterpret_cast<char*>(p.Y);
     const int no = (n_base >> 1) + 8 * quad;  // output channel of the lane's first result
 #pragma unroll
@@ -662,24 +624,20 @@ HV_DEV void hv_gemm_epilogue_fast_perm_geglu(const HvGemmParams& p, f32x4 (&acc)
         const int m = m_base + 16 * mf + r16;
         if (m >= p.M || 2 * no >= p.N) continue;
         hv_st16(yb + ((unsigned)m * (unsigned)p.ldy * 2u + 2u * (unsigned)no), outp[mf]);
-        if (mf == 0) HV_TRACE(8);
-        if (mf == 3) HV_TRACE(10);
     }
-    HV_TRACE(13);
-    HV_TRACE(11);
 }
 
 template <int NMF>
-HV_DEV void hv_gemm_epilogue(const HvGemmParams& p, f32x4 (&acc)[4][NMF], int m_base, int n_base, int r16, int quad HV_TRACE_PARAM) {
+HV_DEV void hv_gemm_epilogue(const HvGemmParams& p, f32x4 (&acc)[4][NMF], int m_base, int n_base, int r16, int quad) {
     const bool lean = p.out_act == HV_ACT_NONE && !p.out_f32 && p.perm_p == 0;
     if (lean && p.geglu)
-        hv_gemm_epilogue_t<NMF, 3>(p, acc, m_base, n_base, r16, quad HV_TRACE_ARG);
+        hv_gemm_epilogue_t<NMF, 3>(p, acc, m_base, n_base, r16, quad);
     else if (lean && p.Yt != nullptr)
-        hv_gemm_epilogue_t<NMF, 2>(p, acc, m_base, n_base, r16, quad HV_TRACE_ARG);
+        hv_gemm_epilogue_t<NMF, 2>(p, acc, m_base, n_base, r16, quad);
     else if (lean)
-        hv_gemm_epilogue_t<NMF, 1>(p, acc, m_base, n_base, r16, quad HV_TRACE_ARG);
+        hv_gemm_epilogue_t<NMF, 1>(p, acc, m_base, n_base, r16, quad);
     else
-        hv_gemm_epilogue_t<NMF, 0>(p, acc, m_base, n_base, r16, quad HV_TRACE_ARG);
+        hv_gemm_epilogue_t<NMF, 0>(p, acc, m_base, n_base, r16, quad);
 }
 
 // Output forms of hv_gemm_epilogue_fast that the LDS-DMA kernel instantiates; hv_gemm_fast_form() (host) classifies a
@@ -704,7 +662,7 @@ static inline int hv_gemm_fast_form(const HvGemmParams& p, int rows_per_wave) {
 
 template <int NMF, bool PERM = false, int STATS = 0>
 HV_DEV void hv_gemm_epilogue_form(int form, const HvGemmParams& p, f32x4 (&acc)[4][NMF], int m_base, int n_base, int r16,
-                                  int quad HV_TRACE_PARAM) {
+                                  int quad) {
 #ifndef HV_EMU
     const int m_first = __builtin_amdgcn_readfirstlane(min(m_base, p.M - 1));  // wave-uniform: the table row is a scalar base
 #else
@@ -715,19 +673,19 @@ HV_DEV void hv_gemm_epilogue_form(int form, const HvGemmParams& p, f32x4 (&acc)[
     else if (p.rowvec != nullptr) tab = p.rowvec + (long)(m_first / p.rowvec_period) * p.N;
     if constexpr (PERM) {  // the launcher sends only the plain-output forms here
         switch (form) {
-            case HV_FORM_LN_GEGLU: hv_gemm_epilogue_fast_perm_geglu<NMF>(p, acc, m_base, n_base, r16, quad, tab HV_TRACE_ARG); break;
-            case HV_FORM_LN: hv_gemm_epilogue_fast_perm<NMF, true, false>(p, acc, m_base, n_base, r16, quad, tab HV_TRACE_ARG); break;
-            case HV_FORM_RES: hv_gemm_epilogue_fast_perm<NMF, false, true, STATS>(p, acc, m_base, n_base, r16, quad, tab HV_TRACE_ARG); break;
-            default: hv_gemm_epilogue_fast_perm<NMF, false, false, STATS>(p, acc, m_base, n_base, r16, quad, tab HV_TRACE_ARG); break;
+            case HV_FORM_LN_GEGLU: hv_gemm_epilogue_fast_perm_geglu<NMF>(p, acc, m_base, n_base, r16, quad, tab); break;
+            case HV_FORM_LN: hv_gemm_epilogue_fast_perm<NMF, true, false>(p, acc, m_base, n_base, r16, quad, tab); break;
+            case HV_FORM_RES: hv_gemm_epilogue_fast_perm<NMF, false, true, STATS>(p, acc, m_base, n_base, r16, quad, tab); break;
+            default: hv_gemm_epilogue_fast_perm<NMF, false, false, STATS>(p, acc, m_base, n_base, r16, quad, tab); break;
         }
         return;
     }
     switch (form) {
-        case HV_FORM_LN: hv_gemm_epilogue_fast<NMF, true, false, 0>(p, acc, m_base, n_base, r16, quad, tab HV_TRACE_ARG); break;
-        case HV_FORM_LN_YT: hv_gemm_epilogue_fast<NMF, true, false, 1>(p, acc, m_base, n_base, r16, quad, tab HV_TRACE_ARG); break;
-        case HV_FORM_LN_GEGLU: hv_gemm_epilogue_fast<NMF, true, false, 2>(p, acc, m_base, n_base, r16, quad, tab HV_TRACE_ARG); break;
-        case HV_FORM_RES: hv_gemm_epilogue_fast<NMF, false, true, 0>(p, acc, m_base, n_base, r16, quad, tab HV_TRACE_ARG); break;
-        default: hv_gemm_epilogue_fast<NMF, false, false, 0>(p, acc, m_base, n_base, r16, quad, tab HV_TRACE_ARG); break;
+        case HV_FORM_LN: hv_gemm_epilogue_fast<NMF, true, false, 0>(p, acc, m_base, n_base, r16, quad, tab); break;
+        case HV_FORM_LN_YT: hv_gemm_epilogue_fast<NMF, true, false, 1>(p, acc, m_base, n_base, r16, quad, tab); break;
+        case HV_FORM_LN_GEGLU: hv_gemm_epilogue_fast<NMF, true, false, 2>(p, acc, m_base, n_base, r16, quad, tab); break;
+        case HV_FORM_RES: hv_gemm_epilogue_fast<NMF, false, true, 0>(p, acc, m_base, n_base, r16, quad, tab); break;
+        default: hv_gemm_epilogue_fast<NMF, false, false, 0>(p, acc, m_base, n_base, r16, quad, tab); break;
     }
 }
 
@@ -873,10 +831,7 @@ __global__ __launch_bounds__(256, 2) void hv_gemm_kernel(HvGemmParams p) {
     };
 
     auto epilogue = [&](int ti) __attribute__((always_inline)) {
-#ifdef HV_GEMM_TRACE
-        int hv_ti = 8192;
-#endif
-        hv_gemm_epilogue<4>(p, acc, (ti / tiles_n) * BM + 64 * wm, (ti % tiles_n) * BN + 64 * wn, r16, quad HV_TRACE_ARG);
+        hv_gemm_epilogue<4>(p, acc, (ti / tiles_n) * BM + 64 * wm, (ti % tiles_n) * BN + 64 * wn, r16, quad);
     };
 
     // one flattened step: park k-tile s in LDS, refill its registers with k-tile s+2, multiply,
@@ -1059,9 +1014,6 @@ __global__ __launch_bounds__(NW * 64, 2) void hv_gemm_glds_kernel(HvGemmParams p
     };
 
     clear_acc();
-#ifdef HV_GEMM_TRACE
-    int hv_ti = 0;
-#endif
     {  // prologue: k-tile 0 in readiness-group order (G0 = all of W + the X rows of the first fragment half, G1 = the rest)
         hv_static_for<WQ>([&](auto Q) __attribute__((always_inline)) { issue_w1(Q); });
         issue_x1(HvInt<0>{});
@@ -1086,14 +1038,11 @@ __global__ __launch_bounds__(NW * 64, 2) void hv_gemm_glds_kernel(HvGemmParams p
         // After an epilogue everything has landed (it waits for every load before its first store): both waits of the next
         // step are skipped, and the stores drain under it (they are older than that step's DMA, so the counted waits of the
         // step after it retire them first -- a full k-step later).
-        HV_TRACE(1);
         const bool more = s + 1 < nsteps;
         const bool skip = landed > 0;
         if (skip) --landed;
         else hv_vm_wait<2>();
-        HV_TRACE(2);
         hv_barrier_raw();
-        HV_TRACE(3);
         const unsigned char* xs = smem + c_slot * SLOT;
         const unsigned char* ws = xs + XT;
         if (++c_slot == NS) c_slot = 0;
@@ -1135,7 +1084,6 @@ __global__ __launch_bounds__(NW * 64, 2) void hv_gemm_glds_kernel(HvGemmParams p
                     acc[nf][mf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[kk][nf], xf[mf], acc[nf][mf], 0, 0, 0);
             }
         }
-        HV_TRACE(4);
         if (!skip) {
             if (!more) hv_vm_wait<0>();
             else if (PH == 2) hv_vm_wait<4>();
@@ -1169,23 +1117,19 @@ __global__ __launch_bounds__(NW * 64, 2) void hv_gemm_glds_kernel(HvGemmParams p
                     acc[nf][HMF + mf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[kk][nf], xf[mf], acc[nf][HMF + mf], 0, 0, 0);
             }
         }
-        HV_TRACE(5);
         if (++c_k == nk) {
             c_k = 0;
             {
                 int m0, n0;
                 tile_origin(c_tile, m0, n0);
-                hv_gemm_epilogue_form<NMF, PERM, STATS>(form, p, acc, m0 + WTM * wm, n0 + 64 * wn, r16, quad HV_TRACE_ARG);
+                hv_gemm_epilogue_form<NMF, PERM, STATS>(form, p, acc, m0 + WTM * wm, n0 + 64 * wn, r16, quad);
                 landed = 1;
             }
             c_tile += tstep;
             clear_acc();
-            HV_TRACE(6);
         }
     }
 }
-
-#include "hv_gemm_p8.h"  // round 5: the 256 x 256 x 64 tile on deeper rings (hv_gemm_p8_kernel)
 
 // ---- epilogue of the wide-tile kernel (below): one wave's 32 rows x 320 columns = five 64-column blocks under the permuted
 // channel assignment (hv_perm_row: the fragment pair (2 j, 2 j + 1) of a lane is the 8 consecutive channels 64 b + 32 j + 8 quad).
@@ -1353,9 +1297,6 @@ __global__ __launch_bounds__(512, 2) void hv_gemm_wide_kernel(HvGemmParams p, in
     clear_acc();
     issue();
     int c_tile = first, c_k = 0, c_slot = 0, landed = 0;
-#ifdef HV_GEMM_TRACE
-    int hv_ti = 0;
-#endif
     for (int s = 0; s < nsteps; ++s) {
         // (after an epilogue everything issued has landed: it waits for every load before its first store)
         if (landed > 0) --landed;
@@ -1421,8 +1362,6 @@ static int g_hv_gemm_max_grid = 512;  // tuning knob (hv_set_tuning): persistent
 //   0: the register-staged kernel for everything (A/Bs; also what problems outside the fast epilogue forms run on)
 //   6: as 1 without the wide tiles (the round-3 default; A/B)
 static int g_hv_gemm_glds = 1;
-static int g_hv_gemm_perm = 1;  // tuning knob (hv_set_tuning key 6): 16-byte epilogue through the permuted channel assignment (A/B)
-static int g_hv_gemm_p8 = 1;    // tuning knob (hv_set_tuning key 8): 256 x 256 x 64 tiles on the 8-interval loop (hv_gemm_p8_kernel); 0: the two-group loop (A/B, bit-identical)
 
 // Which kernel hv_gemm_launch takes for a problem: 0 register-staged, 1 = 256x256x64, 2 = 128x128x64 (LDS-DMA); perm = the
 // permuted channel assignment.  Shared with hv_gemm_gn_parts so that the caller sizes gn_part for the kernel that will run.
@@ -1454,7 +1393,7 @@ static inline HvGemmChoice hv_gemm_choose(const HvGemmParams& p, bool want_stats
     int form128 = hv_gemm_fast_form(p, 128), form64 = hv_gemm_fast_form(p, 64);
     // a positional-encoding table with one row per 16-row fragment (period % 16 == 0 only): the permuted LayerNorm-fold
     // epilogue of the 128 x 128 kernel loads it per fragment (hv_gemm_epilogue_fast_perm)
-    if (form64 == HV_FORM_NONE && g_hv_gemm_perm && p.N % 8 == 0 && p.pe != nullptr && hv_gemm_fast_form(p, 16) == HV_FORM_LN)
+    if (form64 == HV_FORM_NONE && p.N % 8 == 0 && p.pe != nullptr && hv_gemm_fast_form(p, 16) == HV_FORM_LN)
         form64 = HV_FORM_LN;
     if (!(g_hv_gemm_glds && !prologue && p.M >= 256 && span_ok && form64 != HV_FORM_NONE)) return c;
     // 256 x 320 x 64 wide tiles (hv_gemm_wide_kernel) for N = 320, K >= 640 with a plain-output form on the permuted assignment
@@ -1462,7 +1401,7 @@ static inline HvGemmChoice hv_gemm_choose(const HvGemmParams& p, bool want_stats
     // k-steps do not amortise the 320-column epilogue), N = 640 (576 tiles at level 1 = 2.25 rounds over the 256 CUs: projection
     // 0.086 -> 0.097 ms, ff2 0.303 -> 0.296).  Tuning value 6 = never (A/B).  The kernel leaves no normalisation statistics: a
     // problem that asks for them stays on the square tiles.
-    if (g_hv_gemm_glds != 6 && g_hv_gemm_glds != 2 && g_hv_gemm_glds != 3 && p.N == 320 && p.K >= 640 && g_hv_gemm_perm &&
+    if (g_hv_gemm_glds != 6 && g_hv_gemm_glds != 2 && g_hv_gemm_glds != 3 && p.N == 320 && p.K >= 640 &&
         p.perm_p == 0 && p.X2 == nullptr && p.M % 256 == 0 && p.Yt == nullptr && !p.geglu && p.bias != nullptr && !want_stats) {
         const int form32 = hv_gemm_fast_form(p, 32);
         if (form32 == HV_FORM_RES || form32 == HV_FORM_PLAIN || form32 == HV_FORM_LN) {
@@ -1487,7 +1426,7 @@ static inline HvGemmChoice hv_gemm_choose(const HvGemmParams& p, bool want_stats
     c.kernel = big ? 1 : 2;
     c.form = big ? form128 : form64;
     // plain bf16 outputs (plain / residual / LayerNorm fold) and GEGLU with N % 8 == 0: permuted channel assignment, 16-byte epilogue
-    c.perm = g_hv_gemm_perm && p.N % 8 == 0 &&
+    c.perm = p.N % 8 == 0 &&
              (c.form == HV_FORM_RES || c.form == HV_FORM_PLAIN || c.form == HV_FORM_LN || c.form == HV_FORM_LN_GEGLU);
     if (p.perm_p != 0 && !c.perm) return HvGemmChoice{0, HV_FORM_NONE, 1, false};  // row-permuted output: that epilogue only
     return c;
@@ -1522,24 +1461,7 @@ static inline int hv_gemm_launch(const HvGemmParams& p, hipStream_t stream) {
         int grid = ((t256 + 7) / 8) * 8;
         if (grid > 256) grid = 256;
         if (grid > g_hv_gemm_max_grid) grid = g_hv_gemm_max_grid;
-        // hv_gemm_p8_kernel: whole 64-row pieces only (scalar piece bases); GEGLU's fragment rows are a template parameter
-        if (g_hv_gemm_p8 && p.M % 64 == 0 && p.N % 64 == 0) {
-            const bool geglu = c.perm && c.form == HV_FORM_LN_GEGLU;
-            const bool free_run = g_hv_gemm_p8 == 2;
-            hv_note("hv_gemm_p8_kernel<%s%s%s> | %s", c.perm ? "perm" : "", geglu ? ",geglu" : "", free_run ? ",1" : ",0", shape);
-#define HV_P8_LAUNCH(PERM_, GEGLU_, SCHED_) \
-    hv_launch(hv_gemm_p8_kernel<PERM_, GEGLU_, SCHED_>, dim3(grid), dim3(512), stream, p, c.gm, c.form)
-            if (free_run) {
-                if (geglu) HV_P8_LAUNCH(true, true, 1);
-                else if (c.perm) HV_P8_LAUNCH(true, false, 1);
-                else HV_P8_LAUNCH(false, false, 1);
-            } else {
-                if (geglu) HV_P8_LAUNCH(true, true, 0);
-                else if (c.perm) HV_P8_LAUNCH(true, false, 0);
-                else HV_P8_LAUNCH(false, false, 0);
-            }
-#undef HV_P8_LAUNCH
-        } else if (c.perm) {
+        if (c.perm) {
             hv_note("hv_gemm_glds_kernel<256,8,256,1,perm> | %s", shape);
             hv_launch(hv_gemm_glds_kernel<256, 8, 256, 1, true>, dim3(grid), dim3(512), stream, p, c.gm, c.form);
         } else {

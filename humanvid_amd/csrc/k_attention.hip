@@ -8,7 +8,6 @@ int hvk_attention(const hv_attention_params& p, hipStream_t s) {
 }
 void hvk_attention_tune(int head_dim, int v) {
     if (head_dim == 40) g_hv_attn40 = v != 2;  // 0: hv_attention40, 2: the generic kernel (A/B)
-    if (head_dim == 160) g_hv_attn_qt160 = v;
 }
 int hvk_attention_fp8_quantize(const bf16_t* K, long ldk, const bf16_t* Vt, long ldvt, int n, int heads, int D, int L, float* kscale,
                                float* vamax, const float* vfloor, unsigned char* K8, long ldk8, unsigned char* Vt8, long ldvt8,

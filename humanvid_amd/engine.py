@@ -7,20 +7,23 @@ transformer_3d.py:103-169; mutual_self_attention.py:147-228 read mode; motion_mo
 [(b f)][h][w][c] == [(b f)][token][c]; every rearrange / cat / upsample / norm-apply of the
 reference is absorbed into kernel addressing, prologues or epilogues:
 
-  ResnetBlock3D  = gn-stats, conv3x3(GN+SiLU prologue, +bias +temb), gn-stats,
-                   [1x1 shortcut GEMM], conv3x3(GN+SiLU prologue, +bias +residual)
-  Transformer3D  = gn-stats, GEMM proj_in(GN prologue), ln-stats, GEMM qkv(LN folded; V stored
+  ResnetBlock3D  = gn-merge, GN apply + SiLU pass, conv3x3(+bias +temb), gn-merge, [1x1 shortcut
+                   GEMM], GN apply + SiLU pass, conv3x3(+bias +residual)
+  Transformer3D  = gn-merge, GN apply pass, GEMM proj_in, ln-merge, GEMM qkv(LN folded; V stored
                    transposed), flash attention (+bank keys for the conditional half),
-                   GEMM out(+bias +folded cross-attention constant +residual), ln-stats,
+                   GEMM out(+bias +folded cross-attention constant +residual), ln-merge,
                    GEMM ff1(LN folded, GEGLU), GEMM ff2(+residual), GEMM proj_out(+residual)
-  motion module  = gn-stats, GEMM proj_in(GN prologue), 2x[ln-stats, GEMM qkv(LN + positional
-                   encoding folded), temporal attention, GEMM out(+residual)], ln-stats, GEMM ff1,
+  motion module  = gn-merge, GN apply pass, GEMM proj_in, 2x[ln-merge, GEMM qkv(LN + positional
+                   encoding folded), temporal attention, GEMM out(+residual)], ln-merge, GEMM ff1,
                    GEMM ff2(+residual), GEMM proj_out(+residual)
+(gn-/ln-merge: the normalisation statistics come from partial sums that the PRODUCING kernel left in
+its epilogue -- hv_groupnorm_from_parts / hv_layernorm_from_parts read kilobytes, not activations.)
 
 The 1-key CLIP cross-attention is algebraically a per-batch constant (softmax over one key == 1):
 to_out(to_v(e)) + bias, computed once per clip and added in the attn1 out-projection epilogue.
-With `dist` set, images are sharded along the frame axis and the temporal K/V of every motion
-module are all-gathered over RCCL (torch.distributed) before the temporal attention.
+With a FrameShard (runner.py) the images are sharded along the frame axis; around every temporal
+attention q | k | v are re-sharded frames <-> pixels by an all-to-all over RCCL (default), or the K/V
+of all frames are all-gathered (HUMANVID_TEMPORAL_EXCHANGE=allgather) -- DESIGN.md section 5.
 """
 from __future__ import annotations
 

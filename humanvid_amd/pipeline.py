@@ -5,8 +5,9 @@ i == 0, context windows, CFG, DDIM v-prediction, per-frame VAE decode).  The den
 (:454-571) is `denoise()`: everything timestep-independent is hoisted out of the loop (PoseGuider,
 CameraPoseEncoder, window lists, folded cross-attention constants, reference-bank K/V), one step is
 a fixed launch sequence into libhumanvid_hip.so (captured as a HIP graph and replayed), and with a
-`FrameShard` the frames of each window are split over the ranks of a node (all-gather of temporal
-K/V inside the motion modules, all-reduce of the tiny noise accumulator per step).
+`FrameShard` the frames of each window are split over the ranks of a node (frames <-> pixels all-to-all
+around every temporal attention -- or an all-gather of its K/V --, all-reduce of the tiny noise
+accumulator per step; the step is then replayed as command-list segments cut at the collectives).
 
 VAE and CLIP stay stock PyTorch-ROCm modules supplied by the caller (BASELINE.json north_star).
 """

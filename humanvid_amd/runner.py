@@ -212,14 +212,12 @@ class Runner:
         self.gn_parts: Dict[int, torch.Tensor] = {}
         self.ln_parts: Dict[int, torch.Tensor] = {}  # the same for LayerNorm row statistics (gemm_ln / ln_stats)
         self.ws.address_tables += [self.gn_parts, self.ln_parts]
-        # HUMANVID_GN_FUSED=0: every GroupNorm reads its input again (hv_groupnorm_affine), for A/Bs
-        self.gn_fused = os.environ.get("HUMANVID_GN_FUSED", "1") == "1"
-        # GroupNorm apply + SiLU in front of a ResnetBlock3D convolution (resnet.py:215-222, 235-241) as its own pass
-        # (hv_affine_apply / _cat into a scratch activation) instead of the convolution's operand prologue: the prologue
-        # repeats the transform (unpack, fma, SiLU, pack) in every 128-channel output tile (3 .. 10 of them) and halo pixel
-        # (x 1.4) on the k-loop's critical path -- measured 0.83 vs 0.64 ms per 320 -> 320 convolution at 96 x 64 x 48
-        # images, while the pass costs 0.08 ms (profiles/r03_conv_apply_ab.txt).  HUMANVID_CONV_APPLY=0: the prologue (A/B).
-        self.conv_apply = os.environ.get("HUMANVID_CONV_APPLY", "1") == "1"
+        # GroupNorm / LayerNorm statistics come from the producers' epilogues (gn_part / ln_part) wherever the producing
+        # kernel can leave them; GroupNorm apply + SiLU in front of a ResnetBlock3D convolution (resnet.py:215-222, 235-241)
+        # is its own pass (hv_affine_apply / _cat into a scratch activation): the convolution's operand prologue repeats the
+        # transform in every 128-channel output tile (3 .. 10 of them) and halo pixel (x 1.4) on the k-loop's critical path --
+        # 0.83 vs 0.64 ms per 320 -> 320 convolution at 96 x 64 x 48 images against 0.08 ms for the pass
+        # (profiles/r03_conv_apply_ab.txt; the A/B environment switches of rounds 2-4 are retired).
 
     @property
     def st(self) -> int:
@@ -231,7 +229,7 @@ class Runner:
     # current contents only: every producer either refreshes it (conv_with_stats / gemm_with_stats) or drops it.
     def conv_with_stats(self, x, wt, y, **kw):
         """ops.conv3x3 that also leaves the GroupNorm partial statistics of y"""
-        if self.conv_apply and kw.get("pro_scale") is not None and wt.shape[0] > 128:
+        if kw.get("pro_scale") is not None and wt.shape[0] > 128:
             n, h, ww, c1 = x.shape
             x2 = kw.pop("x2", None)
             ctot = c1 + (0 if x2 is None else x2.shape[3])
@@ -240,9 +238,6 @@ class Runner:
                              rows_per_image=h * ww, act=kw.pop("pro_act", A.ACT_NONE),
                              x2=None if x2 is None else x2.view(-1, x2.shape[3]))
             x = xn
-        if not self.gn_fused:
-            ops.conv3x3(self.lib, self.st, x, wt, y, **kw)
-            return
         parts = ops.conv3x3(self.lib, self.st, x, wt, y, query_gn_parts=True, **kw)
         if parts <= 0:
             self.gn_parts.pop(y.data_ptr(), None)
@@ -256,9 +251,7 @@ class Runner:
         """ops.gemm writing the [n, h, w, C] activation y4d (as rows) that also leaves its GroupNorm partial statistics
         where the problem allows (hv_gemm_gn_parts), and drops stale ones where it does not"""
         y2d = y4d.view(-1, y4d.shape[3])
-        parts = 0
-        if self.gn_fused:
-            parts = ops.gemm(self.lib, self.st, x2d, wt, y2d, gn_rows_per_image=rows_per_image, query_gn_parts=True, **kw)
+        parts = ops.gemm(self.lib, self.st, x2d, wt, y2d, gn_rows_per_image=rows_per_image, query_gn_parts=True, **kw)
         if parts <= 0:
             self.gn_parts.pop(y4d.data_ptr(), None)
             ops.gemm(self.lib, self.st, x2d, wt, y2d, **kw)
@@ -298,7 +291,7 @@ class Runner:
     def gemm_ln(self, x2d, wt, y2d, **kw):
         """ops.gemm whose output feeds a LayerNorm: leaves the row sums of what it stores (hv_gemm ln_part) where the problem
         allows, so that ln_stats(y2d) needs no pass over the activation; drops stale ones where it does not"""
-        parts = ops.gemm(self.lib, self.st, x2d, wt, y2d, query_ln_parts=True, **kw) if self.gn_fused else 0
+        parts = ops.gemm(self.lib, self.st, x2d, wt, y2d, query_ln_parts=True, **kw)
         if parts <= 0:
             self.ln_parts.pop(y2d.data_ptr(), None)
             ops.gemm(self.lib, self.st, x2d, wt, y2d, **kw)

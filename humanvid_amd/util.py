@@ -130,3 +130,47 @@ def get_fps(video_path):
     fps = stream.average_rate
     container.close()
     return fps
+
+
+# ---- checkpoint book-keeping and a notebook helper -------------------------------------------------------------------------
+# Not on the denoising path; restored in round 5 because the module is a DROP-IN for src/utils/util.py and the reference's
+# train_stage_1.py:42 / train_stage_2.py:45 import these names from it.  Behaviour follows
+# /root/reference/src/utils/util.py:17-45, 66-79, 165-173.
+def _numbered(names, sep_index):
+    """(number, name) pairs of `<stem>-<n>[.ext]` entries, oldest first"""
+    return sorted((int(n.split("-")[sep_index].split(".")[0]), n) for n in names)
+
+
+def save_checkpoint(model, save_dir, prefix, ckpt_num, total_limit=None, logger=None):
+    """torch.save(model.state_dict()) -> <save_dir>/<prefix>-<ckpt_num>.pth, after pruning the oldest `<prefix>*` files so that
+    at most `total_limit` remain once this one is written; prefix "motion_module" keeps only the motion-module tensors."""
+    if total_limit is not None:
+        have = _numbered([f for f in os.listdir(save_dir) if f.startswith(prefix)], 1)
+        drop = [name for _, name in have[:max(0, len(have) - total_limit + 1)]]
+        if drop and logger is not None:
+            logger.info(f"{len(have)} checkpoints already exist, removing {len(drop)} checkpoints")
+            logger.info(f"removing checkpoints: {', '.join(drop)}")
+        for name in drop:
+            os.remove(osp.join(save_dir, name))
+    state = model.state_dict()
+    if prefix == "motion_module":
+        state = type(state)((k, v) for k, v in state.items() if "motion_module" in k)
+    torch.save(state, osp.join(save_dir, f"{prefix}-{ckpt_num}.pth"))
+
+
+def delete_additional_ckpt(base_path, num_keep):
+    """keep the `num_keep` newest `checkpoint-<n>` directories under base_path"""
+    have = _numbered([d for d in os.listdir(base_path) if d.startswith("checkpoint-")], -1)
+    for _, name in have[:max(0, len(have) - num_keep)]:
+        shutil.rmtree(osp.join(base_path, name), ignore_errors=True)
+
+
+def show_image_grid(images: torch.Tensor, n_rows=6):
+    """display a [n, c, h, w] batch in [0, 1] as one grid (matplotlib is imported on use)"""
+    import matplotlib.pyplot as plt
+
+    grid = (make_grid(images, nrow=n_rows).permute(1, 2, 0).squeeze(-1) * 255).numpy().astype(np.uint8)
+    plt.imshow(Image.fromarray(grid))
+    plt.axis("off")
+    plt.show()
+

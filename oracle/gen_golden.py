@@ -4,7 +4,7 @@
 TEST INFRASTRUCTURE ONLY -- runs in the build container, where /root/reference is mounted:
 
     python oracle/gen_golden.py            # check + write fixtures
-    python oracle/gen_golden.py --check    # check only (used by tests/test_oracle_vs_reference.py)
+    python oracle/gen_golden.py --check    # check only (tests/test_host_logic.py runs it when /root/reference is present)
 
 It imports the reference's model files *verbatim* from /root/reference (package name `src`,
 which is why this must be its own process: the repo's drop-in surface is also called `src`)

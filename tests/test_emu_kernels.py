@@ -168,38 +168,6 @@ def test_gemm_tile_selection_and_k_loop(cx):
         cx.lib.call("hv_set_tuning", 2, 512)
 
 
-def test_gemm_eight_interval_loop(cx):
-    """round 5: the 256x256x64 tiles on the 8-interval loop (hv_gemm_p8_kernel, tuning key 8 = 1, default) against the
-    two-group loop (key 8 = 0): same MFMA order per accumulator -> bit-identical outputs for every epilogue form, with one,
-    two, three and many k-tiles per workgroup (prologue / tail of the two issue cursors), several tiles per workgroup,
-    a second K source, ragged M / N."""
-    cx.lib.call("hv_set_tuning", 3, 2)  # 256x256x64 wherever legal
-    try:
-        for grid in (8, 512):
-            cx.lib.call("hv_set_tuning", 2, grid)
-            cases = [dict(M=320, C=64, N=1024, P=128, form="res", seed=71),       # one k-tile in all
-                     dict(M=320, C=128, N=1024, P=128, form="ln_geglu", seed=72),  # two
-                     dict(M=520, C=192, N=1000, P=128, form="plain", seed=73),    # three; N % 64 != 0: stays on the two-group loop
-                     dict(M=576, C=192, N=960, P=64, form="plain", seed=78),      # ragged M and N in whole 64-row pieces
-                     dict(M=1344, C=192, N=1024, P=128, form="ln", seed=74),
-                     dict(M=1344, C=320, N=1024, P=128, form="ln_yt", seed=75)]
-            for kw in cases:
-                outs = []
-                for p8 in (0, 1, 2):  # two-group loop / 8 intervals / one barrier per k-tile
-                    cx.lib.call("hv_set_tuning", 8, p8)
-                    outs.append(kc.case_gemm_forms(cx, return_output=True, **kw))
-                assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2]), kw
-        cx.lib.call("hv_set_tuning", 2, 8)
-        for p8 in (0, 1, 2):
-            cx.lib.call("hv_set_tuning", 8, p8)
-            kc.case_gemm(cx, M=576, N=1024, K=256, seed=76, two_source=True)   # second source from k-tile 2 on
-            kc.case_gemm(cx, M=1216, N=1024, K=64, seed=77)                    # one k-tile per tile, five tiles per workgroup
-    finally:
-        cx.lib.call("hv_set_tuning", 8, 1)
-        cx.lib.call("hv_set_tuning", 2, 512)
-        cx.lib.call("hv_set_tuning", 3, 1)
-
-
 def test_gemm_lds_dma_256x256_tiles(cx):
     """selection 2: 256x256x64 tiles wherever the shape allows them (N >= 960), waves own 128x64"""
     cx.lib.call("hv_set_tuning", 3, 2)

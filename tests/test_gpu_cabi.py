@@ -1,7 +1,8 @@
 """The C ABI without Python in the process: tools/hwcheck.cpp (built by __graft_entry__.build() into tools/bin/hwcheck)
 links libhumanvid_hip.so through include/humanvid_hip.h alone, runs hv_groupnorm_affine against a double-precision host
-reference (bench shape + edge shapes: concat seam, an empty pixel range, 80 channels per group) and hv_gemm under tile
-policies 9 and 10 at the level-2 / level-3 projection shapes (the two must agree bit for bit; sampled rows against the host)."""
+reference (bench shape + edge shapes: concat seam, an empty pixel range, 80 channels per group) and hv_gemm under its kernel
+selections (HV_TUNE_GEMM_GLDS 1 / 2 / 3 / 0) at the level-2 / level-3 projection shapes: the selections must agree bit for
+bit, and sampled rows are checked against the host."""
 import os
 import subprocess
 

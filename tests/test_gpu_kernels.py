@@ -86,65 +86,6 @@ def test_bench_shape_gemm_forms(cx):
             cx.lib.call("hv_set_tuning", 3, 1)
 
 
-def test_gemm_eight_interval_loop_bitwise(cx):
-    """round 5: hv_gemm_p8_kernel (256x256x64 tiles, two wave groups one barrier interval apart, 3-slot X / 2-slot W rings,
-    counted vmcnt) against the two-group loop of rounds 3-4 at the benchmarked shapes of the step: the MFMA order per
-    accumulator is the same, so the outputs must agree BIT FOR BIT -- any LDS-DMA / fragment-read race shows as a difference.
-    Each shape is repeated (a race is timing dependent); the old loop itself is pinned against fp32 references by
-    test_bench_shape_gemm_forms / test_bench_shape_gemms."""
-    from humanvid_amd import ops
-
-    dev, L, st = cx.device, cx.lib, cx.stream
-    g = torch.Generator(device=dev).manual_seed(1234)
-
-    def rnd(*shape, scale=1.0, dtype=torch.bfloat16):
-        return (torch.randn(*shape, device=dev, generator=g) * scale).to(dtype)
-
-    shapes = [  # (M, N, K, form)
-        (48 * 6144, 2560, 320, "geglu"), (48 * 1536, 5120, 640, "geglu"), (48 * 384, 10240, 1280, "geglu"),
-        (48 * 6144, 960, 320, "ln_yt"), (48 * 1536, 1920, 640, "ln_yt"), (48 * 6144, 960, 320, "ln"),
-        (48 * 384, 1280, 5120, "res"), (48 * 384, 3840, 1280, "plain"), (4608, 10240, 1280, "geglu"),
-        (320, 1024, 64, "res"), (576, 960, 128, "plain"), (256 * 9, 1280, 192, "res"),
-    ]
-    try:
-        for (M, N, K, form) in shapes:
-            x, w = rnd(M, K), rnd(N, K, scale=K**-0.5)
-            bias = rnd(N, scale=0.1, dtype=torch.float32)
-            kw, n_out = dict(bias=bias), N
-            yt = None
-            if form in ("geglu", "ln_yt", "ln"):
-                kw.update(row_mean=rnd(M, scale=0.1, dtype=torch.float32), row_rstd=1 + rnd(M, scale=0.1, dtype=torch.float32),
-                          colsum=rnd(N, scale=0.1, dtype=torch.float32))
-            if form == "geglu":
-                kw.update(geglu=True)
-                n_out = N // 2
-            if form == "ln_yt":
-                n_out = (2 * N // 3) // 64 * 64
-                yt = torch.zeros(N - n_out, M, dtype=torch.bfloat16, device=dev)
-                kw.update(yt=yt, n_split=n_out)
-            res = rnd(M, n_out) if form == "res" else None
-            outs = []
-            for p8, reps in ((0, 1), (1, 3), (2, 3)):  # two-group loop / 8 intervals / one barrier per k-tile
-                L.call("hv_set_tuning", 8, p8)
-                L.call("hv_set_tuning", 3, 2)  # 256x256x64 tiles wherever legal
-                for _ in range(reps):
-                    y = torch.zeros(M, n_out, dtype=torch.bfloat16, device=dev)
-                    if res is not None:
-                        y.copy_(res)
-                        ops.gemm(L, st, x, w, y, residual=y, **kw)
-                    else:
-                        ops.gemm(L, st, x, w, y, **kw)
-                    cx.sync()
-                    outs.append((y, None if yt is None else yt.clone()))
-            for (y, t) in outs[1:]:
-                assert torch.equal(y, outs[0][0]), (M, N, K, form)
-                assert t is None or torch.equal(t, outs[0][1]), (M, N, K, form)
-            assert torch.isfinite(outs[0][0].float()).all() and float(outs[0][0].float().abs().max()) > 0
-    finally:
-        L.call("hv_set_tuning", 8, 1)
-        L.call("hv_set_tuning", 3, 1)
-
-
 def test_affine_apply(cx):
     kc.case_affine_apply(cx, n_img=48, rows=1536, C=640)
     kc.case_affine_apply(cx, n_img=48, rows=6144, C=320, act=A.ACT_SILU, seed=42)
@@ -203,8 +144,7 @@ def test_config5_shape_attention(cx, D, L, fp8):
 
 
 def test_attention_variants(cx):
-    """head dim 40: the generic kernel (tuning value 2) computes the same function as the dedicated one (0); head dim 160:
-    one query fragment per wave"""
+    """head dim 40: the generic kernel (tuning value 2) computes the same function as the dedicated one (0)"""
     try:
         for v in (2, 0):
             cx.lib.call("hv_set_tuning", 0, v)
@@ -212,9 +152,7 @@ def test_attention_variants(cx):
             kc.case_attention(cx, D=40, n_img=4, Lq=1536, Lb=1536, spike=True, seed=73, check=(0, 3), q_stride=4)
     finally:
         cx.lib.call("hv_set_tuning", 0, 0)
-    cx.lib.call("hv_set_tuning", 1, 1)
     kc.case_attention(cx, D=160, n_img=4, Lq=96, Lb=96)
-    cx.lib.call("hv_set_tuning", 1, 2)
 
 
 @pytest.mark.parametrize("D,L", [(40, 1536), (80, 768), (160, 384)])

@@ -105,7 +105,8 @@ def test_script_module_paths_resolve_to_the_native_package():
         "src.models.mutual_self_attention": ["ReferenceAttentionControl"],
         "src.cameractrl.pose_adaptor": ["CameraPoseEncoder"],
         "src.dataset.dance_image_h_v_camera": ["Camera", "ray_condition"],
-        "src.utils.util": ["get_fps", "read_frames", "save_videos_grid", "save_image_grid", "seed_everything"],
+        "src.utils.util": ["get_fps", "read_frames", "save_videos_grid", "save_image_grid", "seed_everything",
+                           "save_checkpoint", "delete_additional_ckpt", "show_image_grid"],  # (train_stage_1.py:42, train_stage_2.py:45)
         "configs.prompts.test_cases": ["TestCasesDict"],
     }
     for mod, names in wanted.items():
@@ -156,6 +157,30 @@ def test_util_grid_and_gif(tmp_path):
     assert Image.open(tmp_path / "o" / "grid.png").size == (3 * 8 + 2, 12)
     with pytest.raises(ValueError):
         save_videos_grid(wide, str(tmp_path / "o" / "x.avi"))
+
+
+def test_util_checkpoint_bookkeeping(tmp_path):
+    """save_checkpoint / delete_additional_ckpt as the reference's training scripts use them (src/utils/util.py:17-45, 66-79):
+    `<prefix>-<n>.pth` files pruned to total_limit, the motion_module filter, `checkpoint-<n>` directories pruned to num_keep"""
+    from src.utils.util import delete_additional_ckpt, save_checkpoint
+
+    class Net(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.conv = torch.nn.Linear(2, 2)
+            self.motion_modules = torch.nn.ModuleList([torch.nn.Linear(2, 2)])
+
+    net = Net()
+    for step in (10, 20, 30, 40):
+        save_checkpoint(net, str(tmp_path), "denoising_unet", step, total_limit=3)
+    assert sorted(os.listdir(tmp_path)) == ["denoising_unet-20.pth", "denoising_unet-30.pth", "denoising_unet-40.pth"]
+    assert set(torch.load(tmp_path / "denoising_unet-40.pth")) == set(net.state_dict())
+    save_checkpoint(net, str(tmp_path), "motion_module", 5)
+    assert set(torch.load(tmp_path / "motion_module-5.pth")) == {"motion_modules.0.weight", "motion_modules.0.bias"}
+    for n in (100, 200, 300):
+        os.makedirs(tmp_path / f"checkpoint-{n}")
+    delete_additional_ckpt(str(tmp_path), 1)
+    assert sorted(d for d in os.listdir(tmp_path) if d.startswith("checkpoint-")) == ["checkpoint-300"]
 
 
 def test_config5_windows_and_bench_pricing():

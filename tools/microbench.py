@@ -46,10 +46,6 @@ def main():
     st = hvlib.current_stream()
     if os.environ.get("HV_GEMM_GLDS"):
         L.call("hv_set_tuning", 3, int(os.environ["HV_GEMM_GLDS"]))  # A/B of the GEMM kernel variants
-    if os.environ.get("HV_GEMM_P8"):
-        L.call("hv_set_tuning", 8, int(os.environ["HV_GEMM_P8"]))  # 256x256x64 tiles: 8-interval loop (1) / two-group loop (0)
-    if os.environ.get("HV_GEMM_PERM"):
-        L.call("hv_set_tuning", 6, int(os.environ["HV_GEMM_PERM"]))
     if os.environ.get("HV_CONV_BIG"):
         L.call("hv_set_tuning", 5, int(os.environ["HV_CONV_BIG"]))
     if os.environ.get("HV_CONV_GLDS"):

@@ -15,8 +15,14 @@ src/pipelines/context.py, noise_pred / counter accumulation, guidance, DDIM step
 
 Compared per step: the latents after the scheduler step and the guided noise prediction (recovered from the latent update,
 which is linear in it).  Stated tolerances (bf16 storage, fp32 accumulation; measured values are printed):
-noise prediction NRMSE <= 2e-2 per step, latents <= 2e-2 (they carry sqrt(1 - abar_prev) of the prediction error, less at the
-early steps), every frame's noise prediction within 1.5 x that bound."""
+guided noise prediction NRMSE <= 2.5e-2 per step, latents <= 1e-2 (they carry sqrt(1 - abar_prev) of the prediction error, less at
+the early steps), every frame's noise prediction within 1.5 x its bound.
+Why 2.5e-2 for the guided prediction when a single forward is held to 2e-2: the guided prediction u + 3.5 (c - u) = 3.5 c - 2.5 u
+weights the two halves' errors with 3.5 and 2.5 while its own norm stays that of c; the storage-format floor of one forward is
+1.44e-2 (oracle/storage_model.py reproduces the native path's distance from the reference: tests/golden/unet3d_config3_storage.npz
+`floor_out`), and only because the halves' rounding errors are strongly correlated does the guided one measure 1.58 - 1.85e-2
+instead of 4.3 x that.  Round 4 held it to 2e-2 with 8 % head-room on a quantity whose FLOOR is 1.4e-2; the check that is meant to
+see a kernel regression is tests/test_gpu_storage_model.py (per block, bounds 2 - 4e-3), not this one."""
 import os
 import sys
 
@@ -31,7 +37,7 @@ import oracle_torch as O  # noqa: E402  (test infrastructure: weight generators 
 
 pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
-TOL = 2e-2
+TOL_NOISE, TOL_LAT = 2.5e-2, 1e-2
 
 
 def nrmse(a, b):
@@ -94,5 +100,5 @@ def test_native_loop_steps_match_the_reference_at_full_size(pipe_and_chan, case)
         per_frame = (noise - want_noise).pow(2).sum(dim=(0, 1, 3, 4)).sqrt() / want_noise.pow(2).sum(dim=(0, 1, 3, 4)).sqrt()
         print(f"[{case}] step {i} t={t}: latents nrmse {e_lat:.4e}  guided noise prediction nrmse {e_noise:.4e}  "
               f"worst frame {float(per_frame.max()):.4e}")
-        assert e_noise < TOL and e_lat < TOL and float(per_frame.max()) < 1.5 * TOL, (case, i, e_lat, e_noise)
+        assert e_noise < TOL_NOISE and e_lat < TOL_LAT and float(per_frame.max()) < 1.5 * TOL_NOISE, (case, i, e_lat, e_noise)
         x_in = x_out  # the next step starts from the native path's own latents, as in a real run

@@ -16,8 +16,10 @@ Two checks, both at config #3's full size (24 frames, latent 96x64, SD-1.5 width
    to the storage model's block, and its output is compared with what the native path stored behind that block.  Ten blocks
    cover every kernel family at its benchmarked shapes (3x3 convolutions at 320 / 1280 / 1280 channels, the GEMM epilogue
    forms, spatial attention at head dims 40 / 80 / 160 with bank keys and the CFG halves, temporal attention, GroupNorm /
-   LayerNorm statistics from the producers' partial sums).  Stated bounds: resnet <= 2.5e-3, motion module <= 3e-3, spatial
-   transformer <= 4e-3 (the measured values are printed) -- a kernel that adds 5e-3 fails.
+   LayerNorm statistics from the producers' partial sums).  Stated bounds: resnet <= 2e-3, spatial transformer <= 3.5e-3,
+   motion module <= 4e-3 (measured on MI355X: 5.0e-4 .. 9.6e-4, 1.7e-3 .. 2.0e-3, 2.1e-3 .. 2.9e-3 -- DESIGN.md section 4;
+   what is left is the decorrelation of a block's own 4 - 12 storage points, about one bf16 rounding rms each) -- a kernel
+   that adds 5e-3 to a block fails it.
 2. END TO END against tests/golden/unet3d_config3_storage.npz (oracle/gen_storage_model_golden.py ran the storage model once
    at this size): the per-image rms of every tap agrees within 5e-4 for all 48 images (against the reference: 2 %), while
    the element-wise distance grows from 1.3e-3 behind the first resnet to ~1.2e-2 at the end -- two realisations of the same
@@ -53,7 +55,7 @@ BLOCKS = [
     ("resnet", "down_blocks.3.resnets.1", "down_blocks.3.motion_modules.0", "down_blocks.3.resnets.1"),
     ("motion", "down_blocks.3.motion_modules.1", "down_blocks.3.resnets.1", "down_blocks.3.motion_modules.1"),
 ]
-TOL_BLOCK = dict(resnet=2.5e-3, motion=3e-3, transformer=4e-3)
+TOL_BLOCK = dict(resnet=2e-3, transformer=3.5e-3, motion=4e-3)
 TOL_E2E, TOL_RMS = 2e-2, 5e-4
 
 
@@ -116,7 +118,7 @@ def test_teacher_forced_blocks_match_the_storage_model(run):
               f"(storage model on the host: {time.time() - t0:.0f} s)", flush=True)
         worst[prefix] = (kind, e, float(d.max()))
     for prefix, (kind, e, dmax) in worst.items():
-        assert e < TOL_BLOCK[kind] and dmax < 1.5 * TOL_BLOCK[kind], (prefix, kind, e, dmax)
+        assert e < TOL_BLOCK[kind] and dmax < 1.25 * TOL_BLOCK[kind], (prefix, kind, e, dmax)
 
 
 def test_end_to_end_against_the_storage_model_golden(run):

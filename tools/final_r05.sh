@@ -10,7 +10,7 @@
 mkdir -p gpurun_out
 export TMPDIR=/tmp
 if [ "$1" != "--no-tests" ] && [ "$1" != "--measure-only" ]; then
-  timeout 1500 python -m pytest tests -m gpu -q -x > gpurun_out/r05_final_pytest.txt 2>&1
+  timeout 2400 python -m pytest tests -m gpu -q -x > gpurun_out/r05_final_pytest.txt 2>&1
   tail -3 gpurun_out/r05_final_pytest.txt
 fi
 MEASURE_ONLY=0; if [ "$1" == "--measure-only" ]; then MEASURE_ONLY=1; fi   # bench line + the three traffic passes only

@@ -300,6 +300,10 @@ def main():
                          "overlapped one has never run with more than one rank on the real transport); 1: on; auto: on after a "
                          "three-step probe run outside the timed region -- if the probe raises, the serial path is timed and the "
                          "line says so (a rank that hangs inside a collective is NOT caught by the probe)")
+    ap.add_argument("--step-graph", default="0", choices=["0", "1"],
+                    help="N > 1 GPUs (or --single-rank-sharded): replay the recorded step -- command-list segments AND the RCCL "
+                         "collectives between them -- as ONE captured device graph per step instead of one launch per segment plus "
+                         "one torch.distributed call per collective.  Default 0: verified bit for bit on a one-rank RCCL group only")
     ap.add_argument("--single-rank-sharded", action="store_true",
                     help="diagnostic (N = 1 only): run the SHARDED code path -- exchange layouts, graph-replayed command-list "
                          "segments, CFG halves on two streams, every collective through RCCL -- with a process group of one rank: "
@@ -439,6 +443,7 @@ def main():
         sh = pipe.shard
         sh.overlap_cfg = args.cfg_streams != "0" and not args.no_graph
         cfg_streams = "on" if sh.overlap_cfg else "off"
+        sh.step_graph = args.step_graph == "1" and not args.no_graph
         if sh.overlap_cfg and args.cfg_streams == "auto":
             # probe outside the timed region: eager step, recorded step, interleaved replay -- the path has only ever run on the
             # host-staged transport of the one-GPU tests; a failure here must not take the bench line down
@@ -498,7 +503,8 @@ def main():
                        # (QK^T reduces over d = 40 / 80 / 160, the 2x-rate MX fp8 MFMA over K = 128), so
                        # the line says which arithmetic the spatial attention of THIS run used
                        "attention_dtype": "fp8 e4m3 (hv_attention_fp8)" if fp8_attn else "bf16",
-                       **({} if cfg_streams is None else {"cfg_streams": cfg_streams})},
+                       **({} if cfg_streams is None else {"cfg_streams": cfg_streams,
+                                                           "step_graph": bool(pipe.shard.step_graph)})},
             "step_algorithmic_tflop": fl_total / 1e12,
             "step_tflops_per_gpu": fl_total / 1e12 / (ms_step / 1e3) / world,
             "step_frac_of_mfma_peak": fl_total / 1e12 / (ms_step / 1e3) / world / PEAK_BF16_TFLOPS,

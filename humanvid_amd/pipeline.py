@@ -71,6 +71,7 @@ class StepRecorder:
     def __init__(self, lib):
         self.lib = lib
         self.items = []  # ("k", list handle) | ("c", callable)
+        self.graph = None  # capture_step_graph: the whole replay as ONE device graph
 
     def begin(self):
         self.lib.call("hv_cmdlist_begin")
@@ -118,7 +119,29 @@ class StepRecorder:
                     else:
                         x()
 
+    @staticmethod
+    def capture_step_graph(lib, replay_fn):
+        """Capture one whole replay -- `replay_fn` = the segments re-issued launch by launch AND the collectives between them
+        (device collectives only: RCCL enqueues on the stream it is called under, and PyTorch's ProcessGroupNCCL records that
+        into an open stream capture) -- as ONE torch.cuda.CUDAGraph: a step is then a single graph launch instead of one launch
+        per segment plus one torch.distributed call per collective (VERDICT r4 #4b).  The capture itself executes nothing.
+        The segments' own per-segment graphs are bypassed while capturing (tuning key 7: hv_cmdlist_run re-issues the recorded
+        closures on the capturing stream)."""
+        g = torch.cuda.CUDAGraph()
+        keep = "7=0" not in os.environ.get("HUMANVID_TUNING", "").replace(" ", "").split(",")
+        torch.cuda.synchronize()
+        lib.call("hv_set_tuning", 7, 0)
+        try:
+            # thread_local: ProcessGroupNCCL's watchdog thread may query events while this thread captures
+            with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                replay_fn()
+        finally:
+            if keep:
+                lib.call("hv_set_tuning", 7, 1)
+        return g
+
     def destroy(self):
+        self.graph = None
         for kind, x in self.items:
             if kind == "k":
                 self.lib.call("hv_cmdlist_destroy", x)
@@ -412,6 +435,13 @@ class Pose2VideoPipeline:
 
         graph = None
         recorder = None
+        # the recorded step (segments + device collectives) as ONE graph: FrameShard.step_graph, opt-in, RCCL only
+        step_graph = bool(self.shard is not None and getattr(self.shard, "step_graph", False) and not self.shard.staged)
+        if step_graph and overlap:
+            # measured (profiles/r05_s9_step_graph.txt): with the collectives of the two halves issued under two forked streams
+            # inside the capture, ProcessGroupNCCL's watchdog thread queries an event recorded in the capturing stream and aborts
+            # the process (hipErrorCapturedEvent); the serial replay captures and replays bit-identically
+            raise NotImplementedError("HUMANVID_STEP_GRAPH=1 captures the serial replay only: unset HUMANVID_CFG_STREAMS")
         n_steps = len(timesteps) if max_steps is None else min(first_step + max_steps, len(timesteps))
         n_batches = len(list(get_context_scheduler(context_schedule)(0, num_inference_steps, F_, context_frames,
                                                                       context_stride, context_overlap)))
@@ -455,7 +485,12 @@ class Pose2VideoPipeline:
                         recorder.end()
                         self.shard.recorder = None
                 else:
-                    recorder.replay()
+                    if step_graph and recorder.graph is None:
+                        recorder.graph = StepRecorder.capture_step_graph(L, recorder.replay)
+                    if recorder.graph is not None:
+                        recorder.graph.replay()
+                    else:
+                        recorder.replay()
             else:
                 one_step()
             if step_hook is not None:

@@ -96,6 +96,13 @@ class FrameShard:
         # multi-rank run has shown bit-identity against the serial replay, the serial replay is the default everywhere
         # (ADVICE round 4).
         self.overlap_cfg = os.environ.get("HUMANVID_CFG_STREAMS") == "1"
+        # the recorded step -- command-list segments AND the collectives between them -- captured as ONE device graph
+        # (StepRecorder.capture_step_graph): one graph launch per step instead of ~85 segment launches + ~85 torch.distributed
+        # calls.  Device collectives only (RCCL calls are recorded into an open stream capture; the host-staged gloo transport
+        # of the CPU / one-GPU tests cannot be).  OPT-IN (HUMANVID_STEP_GRAPH=1, bench.py --step-graph 1) for the same reason
+        # as the two-stream replay: verified bit for bit against the segment replay on a ONE-rank RCCL group
+        # (tests/test_gpu_sharded.py), never run with more than one rank.
+        self.step_graph = os.environ.get("HUMANVID_STEP_GRAPH") == "1"
         # diagnostics for the scaling runs (bench.py --gpus N): with `measure` on, every collective is counted with the bytes
         # this rank sends and bracketed by two events on the compute stream -- the kernels behind a collective wait for
         # it, so the event distance is the exchange time the step is EXPOSED to (nothing overlaps it yet)

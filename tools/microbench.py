@@ -46,6 +46,8 @@ def main():
     st = hvlib.current_stream()
     if os.environ.get("HV_GEMM_GLDS"):
         L.call("hv_set_tuning", 3, int(os.environ["HV_GEMM_GLDS"]))  # A/B of the GEMM kernel variants
+    for kv in filter(None, os.environ.get("HV_TUNE", "").split(",")):  # any tuning key of the loaded library: HV_TUNE="8=1,3=2"
+        L.call("hv_set_tuning", int(kv.split("=")[0]), int(kv.split("=")[1]))
     if os.environ.get("HV_CONV_BIG"):
         L.call("hv_set_tuning", 5, int(os.environ["HV_CONV_BIG"]))
     if os.environ.get("HV_CONV_GLDS"):

@@ -13,7 +13,7 @@ Two checks, both at config #3's full size (24 frames, latent 96x64, SD-1.5 width
    rounding is a full-size perturbation of everything downstream -- so two faithful implementations of the same storage model
    decorrelate with depth (check 2 measures it).  A regression detector therefore has to compare ONE block at a time from
    identical inputs: the native path's own stored activation in front of a resnet / spatial transformer / motion module is fed
-   to the storage model's block, and its output is compared with what the native path stored behind that block.  Ten blocks
+   to the storage model's block, and its output is compared with what the native path stored behind that block (the two largest transformer blocks: on a subset of the images, FRAME_SUBSET).  Ten blocks
    cover every kernel family at its benchmarked shapes (3x3 convolutions at 320 / 1280 / 1280 channels, the GEMM epilogue
    forms, spatial attention at head dims 40 / 80 / 160 with bank keys and the CFG halves, temporal attention, GroupNorm /
    LayerNorm statistics from the producers' partial sums).  Stated bounds: resnet <= 2e-3, spatial transformer <= 3.5e-3,
@@ -56,6 +56,12 @@ BLOCKS = [
     ("motion", "down_blocks.3.motion_modules.1", "down_blocks.3.resnets.1", "down_blocks.3.motion_modules.1"),
 ]
 TOL_BLOCK = dict(resnet=2e-3, transformer=3.5e-3, motion=4e-3)
+# A spatial transformer block is independent per image (GroupNorm, attention and LayerNorm all act inside one image; the bank
+# keys and the constant cross-attention term belong to the CFG half), and the storage model's fp32 attention on the host is what
+# this file spends its time on (level 0: 131 s for the 48 images): the two largest blocks are compared on an evenly spaced
+# subset of the frames of BOTH halves -- every image of the native forward ran, a subset is checked (the driver's GPU tier has a
+# 20-minute budget for the whole suite).
+FRAME_SUBSET = {"down_blocks.0.attentions.1": 4, "down_blocks.1.attentions.1": 8}
 TOL_E2E, TOL_RMS = 2e-2, 5e-4
 
 
@@ -109,7 +115,13 @@ def test_teacher_forced_blocks_match_the_storage_model(run):
         if kind == "resnet":
             y = model.resnet(prefix, x, None, temb)
         elif kind == "transformer":
-            y = model.transformer(prefix, x, run["ehs"], run["banks"][prefix], F, True)
+            fs = F
+            if prefix in FRAME_SUBSET:
+                fs = FRAME_SUBSET[prefix]
+                idx = torch.linspace(0, F - 1, fs).round().long()
+                pick = lambda t: t.view(2, F, *t.shape[1:])[:, idx].reshape(2 * fs, *t.shape[1:])  # noqa: E731
+                x, want = pick(x), pick(want)
+            y = model.transformer(prefix, x, run["ehs"], run["banks"][prefix], fs, True)
         else:
             y = model.motion(prefix, x, F, mmk)
         e = float((want - y).norm() / y.norm())

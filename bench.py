@@ -310,10 +310,12 @@ def main():
                          "what the sharded schedule costs before any byte crosses xGMI (DESIGN.md section 5)")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-baseline", default="full", choices=["quarter", "full"],
-                    help="sample of the CPU baseline (fp32 oracle port on this host's cores): the WHOLE config-3 step (default: a "
-                         "timing, not an extrapolation; ~5.5 min on 128 cores, run after the timed GPU region) or a quarter of "
-                         "the config-3 pixels scaled by the as-written FLOP ratio (~1 min)")
+    ap.add_argument("--cpu-baseline", default="auto", choices=["auto", "quarter", "full"],
+                    help="sample of the CPU baseline (fp32 oracle port on this host's cores): full = the WHOLE config-3 step (a "
+                         "timing, not an extrapolation; ~3.5 min on 128 cores, run after the timed GPU region), quarter = a quarter "
+                         "of the config-3 pixels scaled by the as-written FLOP ratio (~1 min).  auto (default) = full when this "
+                         "process has >= 64 CPU threads (the bench host: 128), quarter otherwise -- on a small host the whole "
+                         "step would take tens of minutes and the line would not be printed inside a driver's time limit")
     ap.add_argument("--no-profile", action="store_true", help="skip the profiled extra step (roofline block)")
     args = ap.parse_args()
 
@@ -516,7 +518,8 @@ def main():
             out["roofline"] = roof
             out["kernels"] = table
         if not sharded and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline((96, 64) if args.cpu_baseline == "full" else (48, 32))
+            full_step = args.cpu_baseline == "full" or (args.cpu_baseline == "auto" and torch.get_num_threads() >= 64)
+            out["cpu_baseline"] = cpu_baseline((96, 64) if full_step else (48, 32))
             ref = os.path.join(REPO, "tests", "golden", f"cpu_reference_config{args.config}.json")
             if os.path.exists(ref):  # the reference SOURCE timed in the build container (oracle/gen_fullsize_golden.py)
                 r = json.load(open(ref))

@@ -3,6 +3,9 @@
 # the second workgroup to arrive on a CU (per-CU atomic counter, CU identity from HW_ID / XCC_ID) starts
 # HV_PHASE_OFFSET x (K / 64) x 1024 cycles late.  ph0 = no offset (same sources), ph1..3 = offsets; applied to the 128x128
 # kernel (two workgroups per CU) and to the archived hv_gemm_g2_kernel (tuning key 8 = 1).
+# Build (here): S=tools/bin/src_ph = a copy of humanvid_amd/csrc/ + include/humanvid_hip.h with profiles/r05_gemm_g2.patch (csrc / include
+#   hunks) and profiles/r05_phase_offset.patch applied; k_gemm.hip compiled with -DHV_PHASE_OFFSET=1|2|3 (ph0: without), hv_api.cpp
+#   once, linked with the other objects of humanvid_amd/lib/obj/ into tools/bin/lib_gemm_ph{0..3}.so.
 mkdir -p gpurun_out
 OUT=gpurun_out/r05_s13.txt
 {

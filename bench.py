@@ -349,18 +349,7 @@ def main():
     from humanvid_amd.scheduler import DDIMScheduler, get_context_scheduler
     from humanvid_amd.workload import unet3d_flops
 
-    if os.environ.get("HUMANVID_GEMM_GLDS"):  # same-box A/B of the GEMM tile selection (hv_set_tuning key 3)
-        from humanvid_amd import lib as hvlib
-
-        hvlib.load().call("hv_set_tuning", 3, int(os.environ["HUMANVID_GEMM_GLDS"]))
-    if os.environ.get("HUMANVID_GEMM_PERM"):  # same-box A/B of the 16-byte GEMM epilogue (hv_set_tuning key 6)
-        from humanvid_amd import lib as hvlib
-
-        hvlib.load().call("hv_set_tuning", 6, int(os.environ["HUMANVID_GEMM_PERM"]))
-    if os.environ.get("HUMANVID_CONV_BIG"):
-        from humanvid_amd import lib as hvlib
-
-        hvlib.load().call("hv_set_tuning", 5, int(os.environ["HUMANVID_CONV_BIG"]))
+    # (same-box A/Bs of kernel selections: HUMANVID_TUNING="key=value,..." -- humanvid_amd/lib.py applies it at load time)
     cfgsel = CONFIGS[args.config]
     F, H, W = args.frames or cfgsel["F"], args.height or cfgsel["H"], args.width or cfgsel["W"]
     h, w = H // 8, W // 8

@@ -131,6 +131,7 @@ PROTOTYPES = {
     "hv_cmdlist_end": (I, [C.POINTER(P)]),
     "hv_cmdlist_size": (I, [P]),
     "hv_cmdlist_run": (I, [P, P]),
+    "hv_cmdlist_fallbacks": (I, []),
     "hv_cmdlist_destroy": (I, [P]),
     "hv_profile_begin": (I, []),
     "hv_profile_end": (I, [C.c_char_p, I]),

@@ -121,11 +121,13 @@ int hv_attention_fp8(const hv_attention_params* p, const float* kscale, const fl
     return hv_check_launch("hv_attention_fp8");
 }
 
+static int g_hv_cmdlist_fallbacks = 0;  // command lists whose graph capture failed (hv_cmdlist_fallbacks())
 static int g_hv_cmdlist_graphs = 1;  // hv_set_tuning(HV_TUNE_CMDLIST_GRAPHS): 0 = hv_cmdlist_run re-issues the closures on every run (A/B)
 int hv_set_tuning(int key, int value) {
     if (key == HV_TUNE_ATTN_D40 && (value == 0 || value == 2)) hvk_attention_tune(40, value);
     else if (key == HV_TUNE_GEMM_MAX_GRID && value >= 8 && value % 8 == 0) hvk_gemm_tune(value);
     else if (key == HV_TUNE_GEMM_GLDS && ((value >= 0 && value <= 3) || value == 6)) hvk_gemm_use_glds(value);
+    else if (key == HV_TUNE_GEMM_W4 && (value == 0 || value == 1)) hvk_gemm_use_w4(value);
     else if (key == HV_TUNE_CONV_GLDS && (value == 0 || value == 1)) hvk_conv_use_glds(value);
     else if (key == HV_TUNE_CONV_BIG && (value >= 0 && value <= 3)) hvk_conv_use_big(value);
     else if (key == HV_TUNE_CONV_RASTER && (value >= 0 && value <= 2)) hvk_conv_raster(value);
@@ -239,6 +241,7 @@ int hv_cmdlist_run(void* list, void* stream) {
             // closures for this list from now on: the launches of a failed capture were never executed.
             hipStream_t cs = nullptr;
             hipGraph_t g = nullptr;
+            (void)hipGetLastError();  // a stale sticky error of an earlier, unrelated call must not fail this capture
             bool ok = hipStreamCreateWithFlags(&cs, hipStreamNonBlocking) == hipSuccess;
             if (ok) {
                 ok = hipStreamBeginCapture(cs, hipStreamCaptureModeRelaxed) == hipSuccess;
@@ -256,6 +259,15 @@ int hv_cmdlist_run(void* list, void* stream) {
                 if (cl->exec) (void)hipGraphExecDestroy(cl->exec);
                 cl->exec = nullptr;
                 cl->no_graph = true;
+                // not an error (the closures are re-issued below), but a silent slow path must be detectable: counted
+                // (hv_cmdlist_fallbacks) and reported once per process
+                static bool said = false;
+                ++g_hv_cmdlist_fallbacks;
+                if (!said) {
+                    said = true;
+                    fprintf(stderr, "humanvid_hip: graph capture of a command list failed; its %zu launches are re-issued one by one from now on\n",
+                            cl->cmds.size());
+                }
             }
         }
         if (cl->exec != nullptr) {
@@ -268,6 +280,7 @@ int hv_cmdlist_run(void* list, void* stream) {
     for (auto& c : cl->cmds) c((hipStream_t)stream);
     return hv_check_launch("hv_cmdlist_run");
 }
+int hv_cmdlist_fallbacks(void) { return g_hv_cmdlist_fallbacks; }
 int hv_cmdlist_destroy(void* list) {
     delete (HvCmdList*)list;
     return HV_OK;

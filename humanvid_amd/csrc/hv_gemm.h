@@ -1353,7 +1353,12 @@ __global__ __launch_bounds__(512, 2) void hv_gemm_wide_kernel(HvGemmParams p, in
     }
 }
 
+#include "hv_gemm4.h"  // the 256 x 256 x 64 tile on four waves of 128 x 128 (round 6)
+
 static int g_hv_gemm_max_grid = 512;  // tuning knob (hv_set_tuning): persistent workgroups
+// tuning knob (hv_set_tuning key 10): 1 (default) = the problems that take 256 x 256 x 64 tiles run on the four-wave kernel
+// (hv_gemm_w4_kernel) when its shape conditions hold (M % 256 == 0, N % 64 == 0, one X source), 0 = always the 8-wave kernel (A/B)
+static int g_hv_gemm_w4 = 1;
 // tuning knob (hv_set_tuning key 3) -- kernel selection:
 //   1 (default): 256 x 320 x 64 wide tiles for N = 320, K >= 640 (M % 256 == 0, plain-output forms); otherwise 256 x 256 x 64
 //      (one 8-wave workgroup per CU) when N >= 960 and its tiles fill the last round over the 256 CUs to >= 90 %, otherwise
@@ -1363,7 +1368,8 @@ static int g_hv_gemm_max_grid = 512;  // tuning knob (hv_set_tuning): persistent
 //   6: as 1 without the wide tiles (the round-3 default; A/B)
 static int g_hv_gemm_glds = 1;
 
-// Which kernel hv_gemm_launch takes for a problem: 0 register-staged, 1 = 256x256x64, 2 = 128x128x64 (LDS-DMA); perm = the
+// Which kernel hv_gemm_launch takes for a problem: 0 register-staged, 1 = 256x256x64, 2 = 128x128x64 (LDS-DMA), 3 = 256x320x64
+// wide tiles, 4 = 256x256x64 on four waves (hv_gemm4.h); perm = the
 // permuted channel assignment.  Shared with hv_gemm_gn_parts so that the caller sizes gn_part for the kernel that will run.
 struct HvGemmChoice {
     int kernel, form, gm;
@@ -1424,6 +1430,7 @@ static inline HvGemmChoice hv_gemm_choose(const HvGemmParams& p, bool want_stats
     const bool big = g_hv_gemm_glds != 3 && shape256 && (fills256 || g_hv_gemm_glds == 2) &&
                      p.perm_p == 0;  // (value 6 selects like 1 here; a row-permuted output: the 128 x 128 kernel's epilogue)
     c.kernel = big ? 1 : 2;
+    if (big && g_hv_gemm_w4 && p.M % 256 == 0 && p.N % 64 == 0 && p.X2 == nullptr) c.kernel = 4;
     c.form = big ? form128 : form64;
     // plain bf16 outputs (plain / residual / LayerNorm fold) and GEGLU with N % 8 == 0: permuted channel assignment, 16-byte epilogue
     c.perm = p.N % 8 == 0 &&
@@ -1467,6 +1474,20 @@ static inline int hv_gemm_launch(const HvGemmParams& p, hipStream_t stream) {
         } else {
             hv_note("hv_gemm_glds_kernel<256,8,256,1> | %s", shape);
             hv_launch(hv_gemm_glds_kernel<256, 8, 256, 1, false>, dim3(grid), dim3(512), stream, p, c.gm, c.form);
+        }
+        return 0;
+    }
+    if (c.kernel == 4) {
+        const int t256 = (p.M / 256) * ((p.N + 255) / 256);
+        int grid = ((t256 + 7) / 8) * 8;
+        if (grid > 256) grid = 256;
+        if (grid > g_hv_gemm_max_grid) grid = g_hv_gemm_max_grid;
+        if (c.perm) {
+            hv_note("hv_gemm_w4_kernel<perm> | %s", shape);
+            hv_launch(hv_gemm_w4_kernel<true>, dim3(grid), dim3(256), stream, p, c.gm, c.form);
+        } else {
+            hv_note("hv_gemm_w4_kernel | %s", shape);
+            hv_launch(hv_gemm_w4_kernel<false>, dim3(grid), dim3(256), stream, p, c.gm, c.form);
         }
         return 0;
     }

@@ -5,5 +5,6 @@
 int hvk_gemm(const hv_gemm_params& p, hipStream_t s) { return hv_gemm_launch(p, s); }
 void hvk_gemm_tune(int max_grid) { g_hv_gemm_max_grid = max_grid; }
 void hvk_gemm_use_glds(int on) { g_hv_gemm_glds = on; }
+void hvk_gemm_use_w4(int on) { g_hv_gemm_w4 = on; }
 int hvk_gemm_gn_parts(const hv_gemm_params& p) { return hv_gemm_gn_parts_of(p); }
 int hvk_gemm_ln_parts(const hv_gemm_params& p) { return hv_gemm_ln_parts_of(p); }

@@ -218,7 +218,9 @@ class Runner:
         self._pe_split: Dict[tuple, tuple] = {}
         self.gn_parts: Dict[int, torch.Tensor] = {}
         self.ln_parts: Dict[int, torch.Tensor] = {}  # the same for LayerNorm row statistics (gemm_ln / ln_stats)
-        self.ws.address_tables += [self.gn_parts, self.ln_parts]
+        # (a cached workspace that is re-linked to a fresh Runner -- Engine.clone_for_half per denoise() call -- keeps only
+        #  the LIVE runner's tables: the previous clone's are unreachable, and Workspace.get walks this list on every regrowth)
+        self.ws.address_tables = [self.gn_parts, self.ln_parts]
         # GroupNorm / LayerNorm statistics come from the producers' epilogues (gn_part / ln_part) wherever the producing
         # kernel can leave them; GroupNorm apply + SiLU in front of a ResnetBlock3D convolution (resnet.py:215-222, 235-241)
         # is its own pass (hv_affine_apply / _cat into a scratch activation): the convolution's operand prologue repeats the

@@ -184,6 +184,32 @@ def test_gemm_lds_dma_256x256_tiles(cx):
         cx.lib.call("hv_set_tuning", 3, 1)
 
 
+def test_gemm_four_wave_256x256_tiles(cx):
+    """hv_gemm_w4_kernel (hv_gemm4.h): the 256x256x64 tile on four waves of 128x128 -- taken where the 8-wave 256x256 kernel
+    would be when M % 256 == 0, N % 64 == 0 and X has one source.  Ring wrap (3 X slots / 2 W slots against 1..5 k-tiles per
+    tile), several tiles per persistent workgroup, the ragged last column tile (N = 960), every epilogue form; the same
+    problems give the same bits on the 8-wave kernel (tuning key 10 = 0)."""
+    import torch
+
+    cx.lib.call("hv_set_tuning", 3, 2)
+    cx.lib.call("hv_set_tuning", 2, 8)
+    try:
+        outs = {}
+        for w4 in (1, 0):
+            cx.lib.call("hv_set_tuning", 10, w4)
+            for form in ("ln", "ln_yt", "ln_geglu", "res", "plain"):
+                outs[(w4, form)] = kc.case_gemm_forms(cx, M=512, C=192, N=960, P=128, form=form, seed=90, return_output=True)
+            outs[(w4, "k1")] = kc.case_gemm_forms(cx, M=256, C=64, N=1024, P=128, form="ln", seed=91, return_output=True)    # one k-tile per tile
+            outs[(w4, "k5")] = kc.case_gemm_forms(cx, M=768, C=320, N=512, P=256, form="ln_geglu", seed=92, return_output=True)  # 12 tiles over 8 workgroups, 5 k-tiles each
+        for k, v in outs.items():
+            if k[0] == 1:
+                assert torch.equal(v, outs[(0, k[1])]), f"four-wave kernel differs from the 8-wave kernel: {k[1]}"
+    finally:
+        cx.lib.call("hv_set_tuning", 10, 1)
+        cx.lib.call("hv_set_tuning", 2, 512)
+        cx.lib.call("hv_set_tuning", 3, 1)
+
+
 def test_gemm_prologue(cx):
     kc.case_gemm_prologue(cx)
 

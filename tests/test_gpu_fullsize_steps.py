@@ -15,14 +15,13 @@ src/pipelines/context.py, noise_pred / counter accumulation, guidance, DDIM step
 
 Compared per step: the latents after the scheduler step and the guided noise prediction (recovered from the latent update,
 which is linear in it).  Stated tolerances (bf16 storage, fp32 accumulation; measured values are printed):
-guided noise prediction NRMSE <= 2.5e-2 per step, latents <= 1e-2 (they carry sqrt(1 - abar_prev) of the prediction error, less at
-the early steps), every frame's noise prediction within 1.5 x its bound.
-Why 2.5e-2 for the guided prediction when a single forward is held to 2e-2: the guided prediction u + 3.5 (c - u) = 3.5 c - 2.5 u
-weights the two halves' errors with 3.5 and 2.5 while its own norm stays that of c; the storage-format floor of one forward is
-1.44e-2 (oracle/storage_model.py reproduces the native path's distance from the reference: tests/golden/unet3d_config3_storage.npz
-`floor_out`), and only because the halves' rounding errors are strongly correlated does the guided one measure 1.58 - 1.85e-2
-instead of 4.3 x that.  Round 4 held it to 2e-2 with 8 % head-room on a quantity whose FLOOR is 1.4e-2; the check that is meant to
-see a kernel regression is tests/test_gpu_storage_model.py (per block, bounds 2 - 4e-3), not this one."""
+guided noise prediction NRMSE <= 2e-2 per step (the bound a single forward is held to), latents <= 1e-2 (they carry
+sqrt(1 - abar_prev) of the prediction error, less at the early steps), every frame's noise prediction within 1.5 x its bound.
+The guided prediction u + 3.5 (c - u) = 3.5 c - 2.5 u weights the two halves' errors with 3.5 and 2.5 while its own norm stays that
+of c; the storage-format floor of one forward is 1.44e-2 (oracle/storage_model.py, tests/golden/unet3d_config3_storage.npz
+`floor_out`) and the halves' rounding errors are strongly correlated, so the guided one measures 1.58 - 1.85e-2 (round 5 had
+loosened this bound to 2.5e-2; round 6 restores 2e-2: every GEMM / norm change since is bit-identical or re-measured under it).
+The check that is meant to see a small kernel regression is tests/test_gpu_storage_model.py (per block, bounds 2 - 4e-3)."""
 import os
 import sys
 
@@ -37,7 +36,7 @@ import oracle_torch as O  # noqa: E402  (test infrastructure: weight generators 
 
 pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
-TOL_NOISE, TOL_LAT = 2.5e-2, 1e-2
+TOL_NOISE, TOL_LAT = 2e-2, 1e-2
 
 
 def nrmse(a, b):

@@ -154,11 +154,9 @@ def main():
             variants = [None]
             if D == 40:
                 variants = [2, 0]  # generic kernel, hv_attention40 (default)
-            if D == 160:
-                variants = [2, 1]
             for var in variants:
                 if var is not None:
-                    L.call("hv_set_tuning", 0 if D == 40 else 1, var)
+                    L.call("hv_set_tuning", 0, var)  # (key 0: the head-dim-40 kernel choice -- the only attention tuning key)
                 ms = timeit(lambda: ops.attention(L, st, qk, qk[:, C:], vt, o, n_images=n, heads=8, D=D, Lq=N_tok,
                                                   L1=N_tok, ldq=2 * C, ldk=2 * C, ldvt=M, ldo=C, k2=k2, vt2=vt2,
                                                   ldk2=C, ldvt2=2 * N_tok, L2=N_tok, bank_sel=sel),

@@ -1356,9 +1356,11 @@ __global__ __launch_bounds__(512, 2) void hv_gemm_wide_kernel(HvGemmParams p, in
 #include "hv_gemm4.h"  // the 256 x 256 x 64 tile on four waves of 128 x 128 (round 6)
 
 static int g_hv_gemm_max_grid = 512;  // tuning knob (hv_set_tuning): persistent workgroups
-// tuning knob (hv_set_tuning key 10): 1 (default) = the problems that take 256 x 256 x 64 tiles run on the four-wave kernel
-// (hv_gemm_w4_kernel) when its shape conditions hold (M % 256 == 0, N % 64 == 0, one X source), 0 = always the 8-wave kernel (A/B)
+// tuning knob (hv_set_tuning key 10): which of the problems that take 256 x 256 x 64 tiles run on the four-wave kernel
+// (hv_gemm_w4_kernel): 1 (default) = the deferred-store forms at K >= 640 (see hv_gemm_choose), 0 = none (always the 8-wave
+// kernel), 2 = every problem whose shape allows it, stores at once, 3 = the same with deferred stores where the form has them
 static int g_hv_gemm_w4 = 1;
+static int g_hv_gemm_w4_units = 1;  // (value 4: as 3 on the plain tile raster instead of the unit raster -- A/B)
 // tuning knob (hv_set_tuning key 3) -- kernel selection:
 //   1 (default): 256 x 320 x 64 wide tiles for N = 320, K >= 640 (M % 256 == 0, plain-output forms); otherwise 256 x 256 x 64
 //      (one 8-wave workgroup per CU) when N >= 960 and its tiles fill the last round over the 256 CUs to >= 90 %, otherwise
@@ -1430,12 +1432,22 @@ static inline HvGemmChoice hv_gemm_choose(const HvGemmParams& p, bool want_stats
     const bool big = g_hv_gemm_glds != 3 && shape256 && (fills256 || g_hv_gemm_glds == 2) &&
                      p.perm_p == 0;  // (value 6 selects like 1 here; a row-permuted output: the 128 x 128 kernel's epilogue)
     c.kernel = big ? 1 : 2;
-    if (big && g_hv_gemm_w4 && p.M % 256 == 0 && p.N % 64 == 0 && p.X2 == nullptr) c.kernel = 4;
     c.form = big ? form128 : form64;
     // plain bf16 outputs (plain / residual / LayerNorm fold) and GEGLU with N % 8 == 0: permuted channel assignment, 16-byte epilogue
     c.perm = p.N % 8 == 0 &&
              (c.form == HV_FORM_RES || c.form == HV_FORM_PLAIN || c.form == HV_FORM_LN || c.form == HV_FORM_LN_GEGLU);
     if (p.perm_p != 0 && !c.perm) return HvGemmChoice{0, HV_FORM_NONE, 1, false};  // row-permuted output: that epilogue only
+    // the four-wave kernel (hv_gemm4.h) where the 8-wave 256 x 256 kernel would run:
+    //   default (tuning 10 = 1): the deferred-store forms (LayerNorm fold with / without GEGLU, permuted channels, M % 192 == 0)
+    //   at K >= 640 -- same-box A/B (profiles/r06_s5_w4_units.txt): level-1 ff1 0.525 -> 0.505 ms, level-2 ff1 0.452 -> 0.401;
+    //   at K = 320 (level 0: five k-tiles per tile) the exposed epilogue of a one-wave-per-SIMD kernel costs more than the
+    //   deferred stores win (QKV 0.285 -> 0.315, ff1 0.72 -> 0.765): those stay on the 8-wave kernel;
+    //   tuning 10 = 2 / 3: wherever its shape conditions hold, without / with deferred stores (A/Bs and tests)
+    if (big && g_hv_gemm_w4 && p.N % 64 == 0 && p.X2 == nullptr) {
+        const bool defer_form = c.perm && (c.form == HV_FORM_LN || c.form == HV_FORM_LN_GEGLU) && p.M % 192 == 0 && p.K >= 320 &&
+                                hv_gemm_fast_form(p, 96) == c.form;
+        if (g_hv_gemm_w4 == 1 ? (defer_form && p.K >= 640) : (p.M % 256 == 0 || (g_hv_gemm_w4 == 3 && defer_form))) c.kernel = 4;
+    }
     return c;
 }
 
@@ -1478,16 +1490,50 @@ static inline int hv_gemm_launch(const HvGemmParams& p, hipStream_t stream) {
         return 0;
     }
     if (c.kernel == 4) {
-        const int t256 = (p.M / 256) * ((p.N + 255) / 256);
-        int grid = ((t256 + 7) / 8) * 8;
-        if (grid > 256) grid = 256;
-        if (grid > g_hv_gemm_max_grid) grid = g_hv_gemm_max_grid;
-        if (c.perm) {
+        // 192-row tiles (waves of 96 x 128) with deferred output stores for the two forms that carry the volume (K >= 320:
+        // four k-tiles of the next tile take them); 256-row tiles with the epilogues of this file otherwise
+        const bool defer = g_hv_gemm_w4 != 2 && c.perm && p.K >= 320 && p.M % 192 == 0 &&
+                           (c.form == HV_FORM_LN || c.form == HV_FORM_LN_GEGLU) && hv_gemm_fast_form(p, 96) == c.form;
+        const int bm = defer ? 192 : 256;
+        const int tiles_m = p.M / bm, tiles_n = (p.N + 255) / 256;
+        const int tiles = tiles_m * tiles_n;
+        auto grid_of = [&](int work) {
+            int g = ((work + 7) / 8) * 8;
+            if (g > 256) g = 256;
+            if (g > g_hv_gemm_max_grid) g = g_hv_gemm_max_grid;
+            return g;
+        };
+        // Unit raster (see the kernel) for the streamed-X shapes (K <= 640: a row block of X is 123 / 246 KB): the largest
+        // number U of column tiles per unit (a divisor of tiles_n) that fills the workgroups' rounds as well as single tiles do
+        int gm = c.gm, grid = grid_of(tiles);
+        if (defer && p.K <= 640 && g_hv_gemm_w4_units) {
+            auto fill = [&](int work) {
+                const int g = grid_of(work), per_xcd = (work + 7) / 8, rounds = (per_xcd + g / 8 - 1) / (g / 8);
+                return (double)work / ((double)rounds * g);
+            };
+            const double f1 = fill(tiles);
+            for (int U = tiles_n; U > 1; --U) {
+                if (tiles_n % U != 0) continue;
+                const int units = tiles_m * (tiles_n / U);
+                if (fill(units) >= 0.97 * f1) {
+                    gm = -U;
+                    grid = grid_of(units);
+                    break;
+                }
+            }
+        }
+        if (defer && c.form == HV_FORM_LN) {
+            hv_note("hv_gemm_w4_kernel<perm,defer,192> | %s", shape);
+            hv_launch(hv_gemm_w4_kernel<true, 1, 6>, dim3(grid), dim3(256), stream, p, gm, c.form);
+        } else if (defer) {
+            hv_note("hv_gemm_w4_kernel<perm,defer,192> | %s", shape);
+            hv_launch(hv_gemm_w4_kernel<true, 2, 6>, dim3(grid), dim3(256), stream, p, gm, c.form);
+        } else if (c.perm) {
             hv_note("hv_gemm_w4_kernel<perm> | %s", shape);
-            hv_launch(hv_gemm_w4_kernel<true>, dim3(grid), dim3(256), stream, p, c.gm, c.form);
+            hv_launch(hv_gemm_w4_kernel<true, 0, 8>, dim3(grid), dim3(256), stream, p, c.gm, c.form);
         } else {
             hv_note("hv_gemm_w4_kernel | %s", shape);
-            hv_launch(hv_gemm_w4_kernel<false>, dim3(grid), dim3(256), stream, p, c.gm, c.form);
+            hv_launch(hv_gemm_w4_kernel<false, 0, 8>, dim3(grid), dim3(256), stream, p, c.gm, c.form);
         }
         return 0;
     }

@@ -184,26 +184,30 @@ def test_gemm_lds_dma_256x256_tiles(cx):
         cx.lib.call("hv_set_tuning", 3, 1)
 
 
-def test_gemm_four_wave_256x256_tiles(cx):
-    """hv_gemm_w4_kernel (hv_gemm4.h): the 256x256x64 tile on four waves of 128x128 -- taken where the 8-wave 256x256 kernel
-    would be when M % 256 == 0, N % 64 == 0 and X has one source.  Ring wrap (3 X slots / 2 W slots against 1..5 k-tiles per
-    tile), several tiles per persistent workgroup, the ragged last column tile (N = 960), every epilogue form; the same
-    problems give the same bits on the 8-wave kernel (tuning key 10 = 0)."""
+def test_gemm_four_wave_tiles(cx):
+    """hv_gemm_w4_kernel (hv_gemm4.h): 256x256x64 / 192x256x64 tiles on four waves of 128x128 / 96x128 -- taken where the
+    8-wave 256x256 kernel would be when M % 256 == 0 (or % 192 with deferred stores), N % 64 == 0 and X has one source.
+    Ring wrap (3 X slots / 2 W slots against 1..6 k-tiles per tile), several tiles per persistent workgroup, the ragged
+    last column tile (N = 960), every epilogue form; the deferred-store forms (LayerNorm fold, with and without GEGLU,
+    K >= 320, M % 192 == 0; tuning key 10 = 3: unit raster, 4: tile raster) against the same kernel without deferral (2) and the
+    8-wave kernel (0): the same problems give the same bits."""
     import torch
 
     cx.lib.call("hv_set_tuning", 3, 2)
     cx.lib.call("hv_set_tuning", 2, 8)
     try:
         outs = {}
-        for w4 in (1, 0):
+        for w4 in (3, 4, 2, 0):
             cx.lib.call("hv_set_tuning", 10, w4)
             for form in ("ln", "ln_yt", "ln_geglu", "res", "plain"):
                 outs[(w4, form)] = kc.case_gemm_forms(cx, M=512, C=192, N=960, P=128, form=form, seed=90, return_output=True)
             outs[(w4, "k1")] = kc.case_gemm_forms(cx, M=256, C=64, N=1024, P=128, form="ln", seed=91, return_output=True)    # one k-tile per tile
-            outs[(w4, "k5")] = kc.case_gemm_forms(cx, M=768, C=320, N=512, P=256, form="ln_geglu", seed=92, return_output=True)  # 12 tiles over 8 workgroups, 5 k-tiles each
+            # deferred stores: 192-row tiles, 5 / 6 k-tiles, two tiles per workgroup (the second carries the first one's stores)
+            outs[(w4, "d_geglu")] = kc.case_gemm_forms(cx, M=768, C=320, N=512, P=384, form="ln_geglu", seed=92, return_output=True)
+            outs[(w4, "d_ln")] = kc.case_gemm_forms(cx, M=768, C=384, N=960, P=384, form="ln", seed=93, return_output=True)
         for k, v in outs.items():
-            if k[0] == 1:
-                assert torch.equal(v, outs[(0, k[1])]), f"four-wave kernel differs from the 8-wave kernel: {k[1]}"
+            if k[0] != 0:
+                assert torch.equal(v, outs[(0, k[1])]), f"four-wave kernel (tuning {k[0]}) differs from the 8-wave kernel: {k[1]}"
     finally:
         cx.lib.call("hv_set_tuning", 10, 1)
         cx.lib.call("hv_set_tuning", 2, 512)

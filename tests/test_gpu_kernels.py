@@ -86,6 +86,33 @@ def test_bench_shape_gemm_forms(cx):
             cx.lib.call("hv_set_tuning", 3, 1)
 
 
+def test_gemm_four_wave_kernel_bench_shapes(cx):
+    """hv_gemm_w4_kernel (hv_gemm4.h) at the step's shapes: the default selection (deferred-store forms at K >= 640), the
+    same kernel forced at level 0 (tuning 10 = 3: unit raster, five k-tiles per tile; 4: tile raster) and with its stores at
+    once (2) give the bits of the 8-wave kernel (0) -- every selection accumulates k-slices in the same order."""
+    import torch
+
+    cases = [dict(M=48 * 1536, C=640, N=2560, P=1536, form="ln_geglu", seed=38),     # level-1 ff1
+             dict(M=48 * 1536, C=640, N=1920, P=1536, form="ln", seed=43),           # level-1 motion-module QKV (PE row per frame)
+             dict(M=48 * 384, C=1280, N=5120, P=384, form="ln_geglu", seed=44),      # level-2 ff1
+             dict(M=48 * 6144, C=320, N=960, P=6144, form="ln", seed=45),            # level 0 (default: 8-wave kernel)
+             dict(M=48 * 6144, C=320, N=1280, P=6144, form="ln_geglu", seed=46)]
+    outs = {}
+    try:
+        for w4 in (0, 1, 3, 4, 2):
+            cx.lib.call("hv_set_tuning", 10, w4)
+            for i, c in enumerate(cases):
+                if w4 in (4, 2) and i not in (1, 3):
+                    continue
+                y = kc.case_gemm_forms(cx, return_output=True, **c)
+                if w4 == 0:
+                    outs[i] = y
+                else:
+                    assert torch.equal(y, outs[i]), f"four-wave kernel (tuning 10 = {w4}) differs from the 8-wave kernel: {c}"
+    finally:
+        cx.lib.call("hv_set_tuning", 10, 1)
+
+
 def test_affine_apply(cx):
     kc.case_affine_apply(cx, n_img=48, rows=1536, C=640)
     kc.case_affine_apply(cx, n_img=48, rows=6144, C=320, act=A.ACT_SILU, seed=42)

@@ -88,6 +88,19 @@ def main():
                     kw = dict(residual=y)
                 ms = timeit(lambda: ops.gemm(L, st, xx, w, y, bias=bias, geglu=geglu, **kw))
                 report(f"gemm {name} M={M} N={Nn} K={K}", ms, 2.0 * M * Nn * K, 2.0 * (M * K + Nn * K + y.numel()))
+                if hasattr(L.cdll, "hv_w4_trace_read"):  # timing build of hv_gemm_w4_kernel (-DHV_W4_TRACE): where a workgroup's time goes
+                    import ctypes
+                    import numpy as np
+                    buf = np.zeros(256 * 8, dtype=np.uint64)
+                    torch.cuda.synchronize()
+                    L.cdll.hv_w4_trace_read(buf.ctypes.data_as(ctypes.c_void_p))
+                    t = buf.reshape(256, 8).astype(np.float64)
+                    t = t[t[:, 4] > 0]
+                    if len(t):
+                        m = t.mean(0)
+                        print(f"    w4 trace (s_memtime ticks, mean over {len(t)} workgroups): kernel {m[0]:.0f}, vmcnt waits {m[1]:.0f}, barriers {m[2]:.0f}, "
+                              f"epilogue {m[3]:.0f}; {m[4]:.0f} k-tiles, {m[5]:.0f} epilogues -> per k-tile: wait {m[1] / m[4]:.1f}, barrier {m[2] / m[4]:.1f}, "
+                              f"rest {(m[0] - m[1] - m[2] - m[3]) / m[4]:.1f}; per epilogue {m[3] / max(m[5], 1):.1f}", flush=True)
                 del w, y
         if only_l0:
             return

@@ -1439,14 +1439,16 @@ static inline HvGemmChoice hv_gemm_choose(const HvGemmParams& p, bool want_stats
     if (p.perm_p != 0 && !c.perm) return HvGemmChoice{0, HV_FORM_NONE, 1, false};  // row-permuted output: that epilogue only
     // the four-wave kernel (hv_gemm4.h) where the 8-wave 256 x 256 kernel would run:
     //   default (tuning 10 = 1): the deferred-store forms (LayerNorm fold with / without GEGLU, permuted channels, M % 192 == 0)
-    //   at K >= 640 -- same-box A/B (profiles/r06_s5_w4_units.txt): level-1 ff1 0.525 -> 0.505 ms, level-2 ff1 0.452 -> 0.401;
-    //   at K = 320 (level 0: five k-tiles per tile) the exposed epilogue of a one-wave-per-SIMD kernel costs more than the
-    //   deferred stores win (QKV 0.285 -> 0.315, ff1 0.72 -> 0.765): those stay on the 8-wave kernel;
-    //   tuning 10 = 2 / 3: wherever its shape conditions hold, without / with deferred stores (A/Bs and tests)
+    //   at K >= 1280 and M >= 16384 -- the one class where it wins INSIDE the step (per-shape step profiles, same box,
+    //   profiles/r06_s7_step_profile_*.tsv: level-2 ff1 0.429 -> 0.415 ms per launch; level-1 ff1 0.474 -> 0.500, level-1
+    //   motion QKV 0.206 -> 0.216, level-3 ff1 0.116 -> 0.121 -- in isolation (microbench, cold X) levels 1 / 2 measured
+    //   -4 / -11 %, profiles/r06_s5_w4_units.txt); at K = 320 (level 0: five k-tiles per tile) the exposed epilogue of a
+    //   one-wave-per-SIMD kernel costs more than the deferred stores win (QKV 0.285 -> 0.315, ff1 0.72 -> 0.765);
+    //   tuning 10 = 2 / 3 / 4: wherever its shape conditions hold, without / with deferred stores (A/Bs and tests)
     if (big && g_hv_gemm_w4 && p.N % 64 == 0 && p.X2 == nullptr) {
         const bool defer_form = c.perm && (c.form == HV_FORM_LN || c.form == HV_FORM_LN_GEGLU) && p.M % 192 == 0 && p.K >= 320 &&
                                 hv_gemm_fast_form(p, 96) == c.form;
-        if (g_hv_gemm_w4 == 1 ? (defer_form && p.K >= 640) : (p.M % 256 == 0 || (g_hv_gemm_w4 == 3 && defer_form))) c.kernel = 4;
+        if (g_hv_gemm_w4 == 1 ? (defer_form && p.K >= 1280 && p.M >= 16384) : (p.M % 256 == 0 || (g_hv_gemm_w4 == 3 && defer_form))) c.kernel = 4;
     }
     return c;
 }

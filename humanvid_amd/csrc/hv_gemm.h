@@ -84,6 +84,9 @@ HV_DEV f32x4 hv_gelu_times(f32x4 x, f32x4 h) {
 }
 
 constexpr int HV_GEMM_EPI_G = 2;  // row fragments per load group of the fast epilogues (the register budget of the 256 x 256 kernel)
+#ifndef HV_EPI_G4
+#define HV_EPI_G4 0  // 1: the permuted epilogue of the 128 x 128 kernel (4 row fragments) requests all its per-row terms in ONE group
+#endif
 
 // ---- epilogue of one wave's (16*NMF) x 64 sub-tile: lane owns token m (column of the MFMA tile) and 4
 //      consecutive channels n; m_base / n_base are the sub-tile origin.
@@ -359,7 +362,7 @@ HV_DEV void hv_gemm_epilogue_fast(const HvGemmParams& p, f32x4 (&acc)[4][NMF], i
 template <int NMF, bool LN, bool RES, int STATS = 0>
 HV_DEV void hv_gemm_epilogue_fast_perm(const HvGemmParams& p, f32x4 (&acc)[4][NMF], int m_base, int n_base, int r16, int quad,
                                        const float* tab_row) {
-    constexpr int G = NMF < HV_GEMM_EPI_G ? NMF : HV_GEMM_EPI_G;  // row fragments per load group
+    constexpr int G = (NMF <= 4 && HV_EPI_G4) ? NMF : (NMF < HV_GEMM_EPI_G ? NMF : HV_GEMM_EPI_G);  // row fragments per load group
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
     int nc[2];
 #pragma unroll

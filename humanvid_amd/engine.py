@@ -71,6 +71,7 @@ class UNet3DEngine:
         # module, named by the reference's module path (e.g. 'down_blocks.0.attentions.1').  Buffers are reused and updated in place: the observer
         # must copy what it wants to keep.  Used by the parity tests; None in production (and under graph capture).
         self.tap = None
+        self.tap_fine = None  # a second observer for the intermediate activations (up path, mid block, resampling convolutions)
         # CFG half this executor instance evaluates when it is given one batch entry (B = 1) of a guided step: None = whole
         # batch ([unconditional | conditional] in one forward), 0 / 1 = that half only (clone_for_half: the two halves of a
         # frame-sharded step run on two streams so that one half's temporal exchange hides under the other's kernels)
@@ -494,9 +495,14 @@ class UNet3DEngine:
             if self.tap is not None:
                 self.tap(name, v)
 
+        def tap_fine(name, v):  # the activations BETWEEN the tap points above (tests/test_gpu_storage_model.py: teacher-forced blocks)
+            if self.tap_fine is not None:
+                self.tap_fine(name, v)
+
         # ---- conv_in (+ pose/camera conditioning)  unet_3d.py:482-484
         x = ws.get("conv_in", (n, H, W, boc[0]))
         conv(x_in, w["conv_in.w"], x, bias=w["conv_in.bias"], residual=cond)
+        tap_fine("conv_in", x)
         skips: List[torch.Tensor] = [x]
         for spec in self.unet.specs:
             p = spec.prefix
@@ -516,19 +522,25 @@ class UNet3DEngine:
                     y = ws.get(f"{p}.down", (n, (h + 1) // 2, (ww + 1) // 2, C))
                     conv(x, w[f"{p}.downsamplers.0.conv.w"], y, mode=A.CONV_S2, bias=w[f"{p}.downsamplers.0.conv.bias"])
                     x = y
+                    tap_fine(f"{p}.downsamplers.0", x)
                     skips.append(x)
             elif spec.kind == "mid":
                 x = resnet("mid_block.resnets.0", x, None, "mid.0")
+                tap_fine("mid_block.resnets.0", x)
                 x = transformer("mid_block.attentions.0", x)
+                tap_fine("mid_block.attentions.0", x)
                 if spec.has_motion:
                     x = motion("mid_block.motion_modules.0", x)
+                    tap_fine("mid_block.motion_modules.0", x)
                 x = resnet("mid_block.resnets.1", x, None, "mid.1")
                 tap("mid_block", x)
             else:
                 for j in range(len(spec.resnets)):
                     x = resnet(f"{p}.resnets.{j}", x, skips.pop(), f"{p}.{j}")
+                    tap_fine(f"{p}.resnets.{j}", x)
                     if spec.has_attn:
                         x = transformer(f"{p}.attentions.{j}", x)
+                        tap_fine(f"{p}.attentions.{j}", x)
                     if spec.has_motion:
                         x = motion(f"{p}.motion_modules.{j}", x)
                     tap(f"{p}.{j}", x)
@@ -537,9 +549,11 @@ class UNet3DEngine:
                     y = ws.get(f"{p}.up", (n, 2 * h, 2 * ww, C))
                     conv(x, w[f"{p}.upsamplers.0.conv.w"], y, mode=A.CONV_UP2, bias=w[f"{p}.upsamplers.0.conv.bias"])
                     x = y
+                    tap_fine(f"{p}.upsamplers.0", x)
         if self.kind == "reference":
             return x  # conv_norm_out / conv_out are removed in the ReferenceNet (unet_2d_condition.py:1295-1299)
         sc, sh = gn_affine(x, "conv_norm_out", self.eps)
         y = ws.get("conv_out", (n, H, W, self.cfg["out_channels"]))
         ops.conv3x3(L, st, x, w["conv_out.w"], y, pro_scale=sc, pro_shift=sh, pro_act=A.ACT_SILU, bias=w["conv_out.bias"])
+        tap_fine("conv_out", y)
         return y

@@ -13,7 +13,11 @@ Two checks, both at config #3's full size (24 frames, latent 96x64, SD-1.5 width
    rounding is a full-size perturbation of everything downstream -- so two faithful implementations of the same storage model
    decorrelate with depth (check 2 measures it).  A regression detector therefore has to compare ONE block at a time from
    identical inputs: the native path's own stored activation in front of a resnet / spatial transformer / motion module is fed
-   to the storage model's block, and its output is compared with what the native path stored behind that block (the two largest transformer blocks: on a subset of the images, FRAME_SUBSET).  Ten blocks
+   to the storage model's block, and its output is compared with what the native path stored behind that block (the two
+   largest transformer blocks: on 12 of the 48 images, both CFG halves -- FRAME_SUBSET).  26 blocks: ten on the down path,
+   and since round 6 the mid block (transformer at 96 tokens / head dim 160, motion module, resnet), a stride-2 downsample, both
+   kinds of upsample-folded convolution, three up-path resnets with the two-source (concatenated) GroupNorm + convolution +
+   1x1 shortcut GEMM at levels 2 / 1 / 0, an up-path transformer and motion module, and conv_norm_out + conv_out.  They
    cover every kernel family at its benchmarked shapes (3x3 convolutions at 320 / 1280 / 1280 channels, the GEMM epilogue
    forms, spatial attention at head dims 40 / 80 / 160 with bank keys and the CFG halves, temporal attention, GroupNorm /
    LayerNorm statistics from the producers' partial sums).  Stated bounds: resnet <= 2e-3, spatial transformer <= 3.5e-3,
@@ -54,14 +58,28 @@ BLOCKS = [
     ("motion", "down_blocks.2.motion_modules.1", "down_blocks.2.attentions.1", "down_blocks.2.motion_modules.1"),
     ("resnet", "down_blocks.3.resnets.1", "down_blocks.3.motion_modules.0", "down_blocks.3.resnets.1"),
     ("motion", "down_blocks.3.motion_modules.1", "down_blocks.3.resnets.1", "down_blocks.3.motion_modules.1"),
+    # round 6 (the down path was a third of the network): the mid block, the up path with its two-source
+    # (concatenated) convolutions, the resampling convolutions, conv_out -- "@name" = a fine tap (engine.tap_fine)
+    ("transformer", "mid_block.attentions.0", "@mid_block.resnets.0", "@mid_block.attentions.0"),
+    ("motion", "mid_block.motion_modules.0", "@mid_block.attentions.0", "@mid_block.motion_modules.0"),
+    ("resnet", "mid_block.resnets.1", "@mid_block.motion_modules.0", "mid_block"),
+    ("down", "down_blocks.1.downsamplers.0", "down_blocks.1.motion_modules.1", "@down_blocks.1.downsamplers.0"),
+    ("up", "up_blocks.0.upsamplers.0", "up_blocks.0.2", "@up_blocks.0.upsamplers.0"),       # 1280 ch, 12x8 -> 24x16: the upsample-folded kernel
+    ("up", "up_blocks.2.upsamplers.0", "up_blocks.2.2", "@up_blocks.2.upsamplers.0"),       # 640 ch, 48x32 -> 96x64
+    ("resnet2", "up_blocks.1.resnets.0", "@up_blocks.0.upsamplers.0", "@up_blocks.1.resnets.0", "down_blocks.2.motion_modules.1"),
+    ("transformer", "up_blocks.1.attentions.0", "@up_blocks.1.resnets.0", "@up_blocks.1.attentions.0"),
+    ("resnet2", "up_blocks.2.resnets.2", "up_blocks.2.1", "@up_blocks.2.resnets.2", "@down_blocks.0.downsamplers.0"),
+    ("resnet2", "up_blocks.3.resnets.2", "up_blocks.3.1", "@up_blocks.3.resnets.2", "@conv_in"),
+    ("motion", "up_blocks.3.motion_modules.2", "@up_blocks.3.attentions.2", "up_blocks.3.2"),
+    ("conv_out", "conv_out", "up_blocks.3.2", "@conv_out"),
 ]
-TOL_BLOCK = dict(resnet=2e-3, transformer=3.5e-3, motion=4e-3)
+TOL_BLOCK = dict(resnet=2e-3, resnet2=2e-3, transformer=3.5e-3, motion=4e-3, down=5e-4, up=5e-4, conv_out=2e-3)
 # A spatial transformer block is independent per image (GroupNorm, attention and LayerNorm all act inside one image; the bank
 # keys and the constant cross-attention term belong to the CFG half), and the storage model's fp32 attention on the host is what
 # this file spends its time on (level 0: 131 s for the 48 images): the two largest blocks are compared on an evenly spaced
 # subset of the frames of BOTH halves -- every image of the native forward ran, a subset is checked (the driver's GPU tier has a
 # 20-minute budget for the whole suite).
-FRAME_SUBSET = {"down_blocks.0.attentions.1": 4, "down_blocks.1.attentions.1": 8}
+FRAME_SUBSET = {"down_blocks.0.attentions.1": 12, "down_blocks.1.attentions.1": 12}
 TOL_E2E, TOL_RMS = 2e-2, 5e-4
 
 
@@ -92,12 +110,16 @@ def run():
         if name in keep:
             full[name] = x.float().permute(0, 3, 1, 2).contiguous().cpu()  # -> (b f) c h w, what the oracle blocks take
 
-    eng.tap = tap
+    def tap_fine(name, x):  # the activations between the 35 tap points (only what a block of BLOCKS needs is kept)
+        if "@" + name in keep:
+            full["@" + name] = x.float().permute(0, 3, 1, 2).contiguous().cpu()
+
+    eng.tap, eng.tap_fine = tap, tap_fine
     try:
         out = net(sample.cuda(), FC.TIMESTEP, ehs.cuda(), pose_cond_fea=pose.cuda(), return_dict=False)[0]
         torch.cuda.synchronize()
     finally:
-        eng.tap = None
+        eng.tap = eng.tap_fine = None
     assert torch.isfinite(out).all()
     return dict(cfg=cfg, sd=sd, F=F, ehs=ehs, banks=banks, out=out.float().cpu(), full=full, slices=got_slice, rms=got_rms)
 
@@ -109,11 +131,22 @@ def test_teacher_forced_blocks_match_the_storage_model(run):
     temb = model.time_embedding(FC.TIMESTEP, 2, F)
     mmk = cfg["motion_module_kwargs"]
     worst = {}
-    for kind, prefix, t_in, t_out in BLOCKS:
+    import torch.nn.functional as TF
+
+    for kind, prefix, t_in, t_out, *t_skip in BLOCKS:
         x, want = run["full"][t_in], run["full"][t_out]
         t0 = time.time()
         if kind == "resnet":
             y = model.resnet(prefix, x, None, temb)
+        elif kind == "resnet2":  # the up path: channels of the skip connection concatenated behind x (unet_3d_blocks.py:715-717)
+            y = model.resnet(prefix, x, run["full"][t_skip[0]], temb)
+        elif kind == "down":
+            y = model.q(model.conv(prefix + ".conv", x, stride=2, padding=1))
+        elif kind == "up":
+            y = model.q(model.conv(prefix + ".conv", TF.interpolate(x, scale_factor=2.0, mode="nearest")))
+        elif kind == "conv_out":  # conv_norm_out -> SiLU -> conv_out (the 4 of 8 padded output channels that exist)
+            y = model.q(model.conv("conv_out", model.q(TF.silu(model.gn("conv_norm_out", x, model.eps)))))
+            want = want[:, : y.shape[1]]
         elif kind == "transformer":
             fs = F
             if prefix in FRAME_SUBSET:

@@ -294,6 +294,15 @@ def main():
     ap.add_argument("--window-groups", type=int, default=1,
                     help="N > 1 GPUs: split the ranks into this many groups that take different context windows of a step "
                          "(window-parallel x frame-shard; clips with several windows per step, e.g. --config 5)")
+    ap.add_argument("--cfg-groups", default="auto", choices=["auto", "1", "2"],
+                    help="N > 1 GPUs: the CFG-parallel axis (FrameShard cfg_groups): 2 = the ranks split into two sub-groups, one per "
+                         "CFG half of the guided step (B = 1 forwards; at N = 2 no temporal exchange at all, one accumulator "
+                         "all-reduce per step), each sharding its frames over N / 2 ranks; 1 = every rank runs both halves of its "
+                         "frames (N-way frame shard); auto = 2 for even N (DESIGN.md section 5)")
+    ap.add_argument("--cfg-half", type=int, default=None, choices=[0, 1],
+                    help="diagnostic (N = 1 only): time the step ONE rank of a two-rank CFG-parallel job runs -- the B = 1 forward of "
+                         "CFG half 0 (unconditional) or 1 (conditional, bank keys), all 24 frames, plus the accumulator all-reduce on "
+                         "a one-rank RCCL group; the line is a diagnostic, not the metric")
     ap.add_argument("--cfg-streams", default="0", choices=["auto", "0", "1"],
                     help="N > 1 GPUs: the two CFG halves of a step on two streams, replayed interleaved, so that one half's temporal "
                          "exchange runs under the other half's kernels (DESIGN.md section 5).  Default 0 = the serial replay (the "
@@ -333,7 +342,12 @@ def main():
     dev = torch.device("cuda", local)
     import torch.distributed as dist
 
-    sharded = world > 1 or args.single_rank_sharded
+    sharded = world > 1 or args.single_rank_sharded or args.cfg_half is not None
+    if args.cfg_half is not None:
+        if world != 1 or args.single_rank_sharded:
+            raise SystemExit("--cfg-half is an N = 1 diagnostic")
+        os.environ.setdefault("MASTER_PORT", "29534")
+        os.environ.update(RANK="0", WORLD_SIZE="1")
     if args.single_rank_sharded:
         if world != 1:
             raise SystemExit("--single-rank-sharded is an N = 1 diagnostic")
@@ -357,8 +371,14 @@ def main():
     sched = DDIMScheduler(beta_start=0.00085, beta_end=0.012, beta_schedule="linear", clip_sample=False, steps_offset=1,
                           prediction_type="v_prediction", rescale_betas_zero_snr=True, timestep_spacing="trailing")
     pipe = Pose2VideoPipeline(None, None, None, unet, pg, cam, sched)
+    cfg_groups = 1
     if sharded:
-        pipe.enable_frame_sharding(window_groups=args.window_groups)
+        if args.cfg_groups == "2" or (args.cfg_groups == "auto" and world % 2 == 0 and args.window_groups == 1):
+            cfg_groups = 2
+        pipe.enable_frame_sharding(window_groups=args.window_groups, cfg_groups=cfg_groups if world > 1 else 1)
+        if args.cfg_half is not None:  # one rank of a two-rank CFG-parallel job, on a one-rank group
+            pipe.shard.cfg_groups, pipe.shard.cfg_group = 2, args.cfg_half
+            cfg_groups = 2
 
     g = torch.Generator().manual_seed(42)
     latents = torch.randn(1, 4, F, h, w, generator=g)
@@ -482,6 +502,13 @@ def main():
         par = "single GPU" if not sharded else ("ONE rank on the sharded code path (diagnostic: --single-rank-sharded)" if world == 1 else (
             f"frame-sharded x{world}: frames<->pixels all-to-all around every temporal attention (RCCL over xGMI)"
             if exch == "alltoall" else f"frame-sharded x{world}: RCCL all-gather of temporal K/V"))
+        if args.cfg_half is not None:
+            par = (f"DIAGNOSTIC (--cfg-half {args.cfg_half}): the step ONE rank of a two-rank CFG-parallel job runs -- B = 1 forward of CFG half "
+                   f"{args.cfg_half} on all frames + the accumulator all-reduce on a one-rank RCCL group; not the metric")
+        elif sharded and world > 1 and cfg_groups == 2:
+            fw = world // 2
+            par = (f"CFG-parallel x2 (one sub-group of {fw} rank(s) per CFG half, B = 1 forwards, accumulator all-reduce over all {world}"
+                   + (": no temporal exchange)" if fw == 1 else f") x frame-sharded x{fw} inside each half ({exch})"))
         out = {
             "metric": f"denoising steps/sec, {F}f x {H}x{W} Pose2Video", "value": K / elapsed, "unit": "steps/s",
             "n_gpus": world, "steps": K, "warmup": Wm, "ms_per_step": ms_step, "higher_is_better": True,

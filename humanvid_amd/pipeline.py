@@ -194,14 +194,17 @@ class Pose2VideoPipeline:
     def _execution_device(self) -> torch.device:  # pipeline_pose2vid_long.py:101-112 (no accelerate hooks here)
         return self.device
 
-    def enable_frame_sharding(self, group=None, window_groups: Optional[int] = None):
+    def enable_frame_sharding(self, group=None, window_groups: Optional[int] = None, cfg_groups: Optional[int] = None):
         """Shard every context window along the frame axis over the ranks of `group` (one process per
         GPU, torch.distributed backend "nccl" = RCCL over xGMI).  window_groups = G (default: HUMANVID_WINDOW_GROUPS or 1)
         splits the ranks into G sub-groups that take different context windows of a step (window-parallel x frame-shard,
-        for clips with several windows per step) -- see FrameShard."""
+        for clips with several windows per step); cfg_groups = 2 (default: HUMANVID_CFG_GROUPS or 1) splits them into two
+        sub-groups that take the two CFG halves of a guided step (CFG-parallel x frame-shard) -- see FrameShard."""
         if window_groups is None:
             window_groups = int(os.environ.get("HUMANVID_WINDOW_GROUPS", "1"))
-        self.shard = FrameShard(group, window_groups=window_groups)
+        if cfg_groups is None:
+            cfg_groups = int(os.environ.get("HUMANVID_CFG_GROUPS", "1"))
+        self.shard = FrameShard(group, window_groups=window_groups, cfg_groups=cfg_groups)
         if self.denoising_unet is not None:
             self.denoising_unet._engine = None  # rebuilt with the shard on first use
         return self
@@ -374,12 +377,22 @@ class Pose2VideoPipeline:
         x_in = [eng.ws.get(f"pipe_x_in_{i}", (rep * fl, h, w, 32)) for i, (_, fl, _) in enumerate(plans)]
         for x in x_in:
             x.zero_()
+        # ---- CFG-parallel axis (FrameShard.cfg_groups == 2): this rank's sub-group runs ONE half of the guided step as a
+        # B = 1 forward and fills that half of the accumulator; the all-reduce over all ranks brings the other half
+        cfg_split = self.shard is not None and self.shard.cfg_groups == 2 and do_cfg
+        if cfg_split:
+            hf_mine = self.shard.cfg_group
+            eng_half = eng.clone_for_half(hf_mine)
+            x_half_mine = [eng_half.ws.get(f"pipe_x_in_{i}", (fl, h, w, 32)) for i, (_, fl, _) in enumerate(plans)]
+            for x in x_half_mine:
+                x.zero_()
+            counter_other = torch.zeros_like(counter)  # the window counter is accumulated once per frame: by half 0's ranks
 
         # ---- exchange / compute overlap for frame-sharded guided steps (FrameShard.overlap_cfg): the two CFG halves never
         # interact before hv_cfg_ddim_step, so each runs as its own B = 1 forward on its own stream (own workspace), recorded
         # once as command-list segments cut at its collectives and replayed INTERLEAVED with the other half
         sharded = self.shard is not None and self.shard.active
-        overlap = sharded and do_cfg and use_graph and getattr(self.shard, "overlap_cfg", False)
+        overlap = sharded and do_cfg and use_graph and getattr(self.shard, "overlap_cfg", False) and self.shard.cfg_groups == 1
         if overlap:
             # the two half-engines' workspaces and their streams live on the pipeline: torch caches freed blocks per stream and
             # torch.cuda.Stream() rotates through a pool, so per-call clones re-allocated every buffer; the
@@ -417,6 +430,15 @@ class Pose2VideoPipeline:
                 ops.cfg_ddim_step(L, hvlib.current_stream(), latents, acc, counter, rep, coeffs)
 
         def one_step():
+            if cfg_split:
+                st = hvlib.current_stream()
+                for (frames, fl, _), cond, xi in zip(plans, conds, x_half_mine):
+                    ops.pack_ncfhw(L, st, latents, xi, rep=1, frames=frames)
+                    y = eng_half.forward_nhwc(xi, t_dev[hf_mine:hf_mine + 1], cond, B=1, F=fl)
+                    ops.accumulate_window(L, st, y, 1, C, frames, acc[hf_mine:hf_mine + 1], counter if hf_mine == 0 else counter_other)
+                self.shard.all_reduce(acc_cnt)
+                ops.cfg_ddim_step(L, st, latents, acc, counter, rep, coeffs)
+                return
             if overlap:  # (eager form: the halves one after the other on their streams -- steps 0 and the recorded one)
                 fork()
                 for hf in (0, 1):
@@ -448,7 +470,7 @@ class Pose2VideoPipeline:
         for i in range(first_step, n_steps):
             t_dev.copy_(t_table[i].expand(rep))
             coeffs.copy_(c_table[i])
-            multi = sharded or (self.shard is not None and self.shard.window_groups > 1)
+            multi = sharded or cfg_split or (self.shard is not None and self.shard.window_groups > 1)
             if use_graph and not multi and i >= first_step + 1:
                 if graph is None:
                     # step 0 ran eagerly (allocates every workspace buffer); capture step 1 and replay it

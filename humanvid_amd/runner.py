@@ -52,26 +52,42 @@ class FrameShard:
     """Frame-axis sharding of one context window over the ranks of a torch.distributed group
     (backend "nccl" == RCCL over xGMI on the GPU box, "gloo" in the CPU tests)."""
 
-    def __init__(self, group=None, window_groups: int = 1):
+    def __init__(self, group=None, window_groups: int = 1, cfg_groups: int = 1):
         """window_groups = G > 1 (long clips with several context windows per step, e.g. config #5):
         the ranks of `group` are split into G consecutive sub-groups; sub-group g takes the context windows i with
         i % G == g and shards THEIR frames over its own ranks only (smaller all-to-all groups, no exchange between
-        windows); the per-step noise accumulator is all-reduced over the whole group as before."""
+        windows); the per-step noise accumulator is all-reduced over the whole group as before.
+        cfg_groups = 2 (round 6): the CFG-parallel axis.  The two halves of a guided step -- the unconditional and the
+        conditional forward -- do not interact before the guidance combine (pipeline_pose2vid_long.py:555-559): the ranks are
+        split into two consecutive sub-groups, sub-group h runs the B = 1 forward of half h (Engine.clone_for_half) and
+        shards ITS frames over its own ranks; each sub-group fills its half of the noise accumulator and the accumulator
+        all-reduce over all ranks (which the sharded step issues anyway) hands both halves to everyone.  At two ranks the
+        frame groups have ONE rank each: no temporal exchange at all, one 4.7 MB all-reduce per step."""
         import torch.distributed as dist
 
         self.dist = dist
         self.all_group = group  # accumulator all-reduce (every rank of the job)
         self.window_groups = int(window_groups)
         self.window_group = 0
-        if self.window_groups > 1:
+        self.cfg_groups = int(cfg_groups)
+        self.cfg_group = 0
+        if self.cfg_groups not in (1, 2):
+            raise ValueError("cfg_groups is 1 or 2 (a guided step has two halves)")
+        if self.cfg_groups > 1 and self.window_groups > 1:
+            raise NotImplementedError("cfg_groups and window_groups split the same ranks: use one of them")
+        splits = max(self.window_groups, self.cfg_groups)
+        if splits > 1:
             total, me = dist.get_world_size(group), dist.get_rank(group)
-            if total % self.window_groups:
-                raise ValueError(f"{total} ranks do not split into {self.window_groups} window groups")
-            per = total // self.window_groups
+            if total % splits:
+                raise ValueError(f"{total} ranks do not split into {splits} {'CFG' if self.cfg_groups > 1 else 'window'} groups")
+            per = total // splits
             base = dist.get_process_group_ranks(group) if group is not None else list(range(total))
-            subs = [dist.new_group(ranks=base[g * per:(g + 1) * per]) for g in range(self.window_groups)]  # collective
-            self.window_group = me // per
-            group = subs[self.window_group]
+            subs = [dist.new_group(ranks=base[g * per:(g + 1) * per]) for g in range(splits)]  # collective
+            if self.cfg_groups > 1:
+                self.cfg_group = me // per
+            else:
+                self.window_group = me // per
+            group = subs[me // per]
         self.group = group  # frame sharding + temporal exchange
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)

@@ -137,6 +137,68 @@ def test_window_groups_shard_inside_and_reduce_across(tmp_path):
         assert err < 4e-3, (grp, err)
 
 
+def _cfg_group_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from humanvid_amd import ops
+    from humanvid_amd.runner import FrameShard
+
+    shard = FrameShard(cfg_groups=2)  # 4 ranks -> CFG half h = rank // 2, two frame-sharding ranks per half
+    assert (shard.world, shard.rank, shard.cfg_group, shard.all_world) == (2, rank % 2, rank // 2, 4)
+    with pytest.raises(NotImplementedError):
+        FrameShard(cfg_groups=2, window_groups=2)
+    # one guided step's accumulator plumbing on the emulated kernels: every rank adds ITS half's prediction for ITS frames,
+    # the window counter is added once per frame (by half 0's ranks), one all-reduce over all four ranks, then hv_cfg_ddim_step
+    run = _runner(_weights()[0], shard)  # (injects the emulated library)
+    L = run.lib
+    Cc, Fr, hh, ww = 4, 4, 4, 4
+    g = torch.Generator().manual_seed(7)
+    lat = torch.randn(1, Cc, Fr, hh, ww, generator=g)
+    pred = torch.randn(2, Fr, hh, ww, 8, generator=g).to(torch.bfloat16)  # [half][frame] rows, 4 of 8 padded channels used
+    f0, fl = shard.frame_range(Fr)
+    frames = torch.arange(f0, f0 + fl, dtype=torch.int32)
+    acc_cnt = torch.zeros(2 * Cc * Fr * hh * ww + Fr)
+    acc, counter = acc_cnt[:2 * Cc * Fr * hh * ww].view(2, Cc, Fr, hh, ww), acc_cnt[2 * Cc * Fr * hh * ww:]
+    spare = torch.zeros_like(counter)
+    hf = shard.cfg_group
+    ops.accumulate_window(L, None, pred[hf, f0:f0 + fl].contiguous(), 1, Cc, frames, acc[hf:hf + 1], counter if hf == 0 else spare)
+    shard.all_reduce(acc_cnt)
+    coeffs = torch.tensor([3.5, 0.6, 0.8, 0.7, 0.71414], dtype=torch.float32)
+    out = lat.clone()
+    ops.cfg_ddim_step(L, None, out, acc, counter, 2, coeffs)
+    torch.save(out, os.path.join(out_dir, f"r{rank}.pt"))
+    dist.destroy_process_group()
+
+
+def test_cfg_groups_split_the_guided_step(tmp_path):
+    """CFG-parallel x frame-shard on 4 ranks (round 6): two sub-groups, one per CFG half, each sharding its frames over two
+    ranks; the accumulator all-reduce over all four delivers both halves everywhere -- every rank's latents after the fused
+    CFG + DDIM step equal the single-process step bit for bit"""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    import build_emu
+
+    build_emu.build()
+    mp.spawn(_cfg_group_worker, args=(4, port, str(tmp_path)), nprocs=4, join=True)
+    from humanvid_amd import ops
+
+    run = _runner(_weights()[0])
+    L = run.lib
+    Cc, Fr, hh, ww = 4, 4, 4, 4
+    g = torch.Generator().manual_seed(7)
+    lat = torch.randn(1, Cc, Fr, hh, ww, generator=g)
+    pred = torch.randn(2, Fr, hh, ww, 8, generator=g).to(torch.bfloat16)
+    acc, counter = torch.zeros(2, Cc, Fr, hh, ww), torch.zeros(Fr)
+    ops.accumulate_window(L, None, pred.reshape(2 * Fr, hh, ww, 8), 2, Cc, torch.arange(Fr, dtype=torch.int32), acc, counter)
+    ref = lat.clone()
+    ops.cfg_ddim_step(L, None, ref, acc, counter, 2, torch.tensor([3.5, 0.6, 0.8, 0.7, 0.71414], dtype=torch.float32))
+    for r in range(4):
+        got = torch.load(os.path.join(str(tmp_path), f"r{r}.pt"))
+        assert torch.equal(got, ref), (r, float((got - ref).abs().max()))
+
+
 class _ToyVae(torch.nn.Module):
     """stand-in for AutoencoderKL.decode: frames are independent batch items (GroupNorm is per sample)"""
 

@@ -39,7 +39,7 @@ def _inputs(F=4, hw=8):
 
 
 def _worker(rank, world, port, out_path, backend="gloo", frames=4, window_groups=1, context_frames=24, context_overlap=4,
-            check_stats=True, hw=8, max_steps=3):
+            check_stats=True, hw=8, max_steps=3, cfg_groups=1):
     import torch.distributed as dist
 
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
@@ -70,7 +70,7 @@ def _worker(rank, world, port, out_path, backend="gloo", frames=4, window_groups
     sched = DDIMScheduler(beta_start=0.00085, beta_end=0.012, beta_schedule="linear", clip_sample=False, steps_offset=1,
                           prediction_type="v_prediction", rescale_betas_zero_snr=True, timestep_spacing="trailing")
     pipe = Pose2VideoPipeline(None, None, None, net, pg.to("cuda"), cam.to("cuda"), sched).enable_frame_sharding(
-        window_groups=window_groups)
+        window_groups=window_groups, cfg_groups=cfg_groups)
     net._engine = eng = UNet3DEngine(net, shard=pipe.shard)
     eng.set_reference_banks({k: v.cuda() for k, v in banks.items()}, do_cfg=True)
     eng._banks_from_modules = lambda: None
@@ -85,7 +85,9 @@ def _worker(rank, world, port, out_path, backend="gloo", frames=4, window_groups
         sh.measure = False
         windows = -(-frames // max(1, context_frames - context_overlap)) if frames > context_frames else 1
         assert sh.stats["collectives"] >= 1 and (sh.stats["bytes_sent"] > 0 or world == 1) and sh.exposed_ms() > 0.0, sh.stats
-        if window_groups == 1 and check_stats:  # 2 exchanges per temporal attention block (all-to-all) or 1 (all-gather) + ONE all-reduce
+        if cfg_groups == 2 and world == 2:  # one rank per CFG half: NO temporal exchange, only the accumulator all-reduce
+            assert sh.stats["collectives"] == windows, sh.stats
+        elif window_groups == 1 and check_stats:  # 2 exchanges per temporal attention block (all-to-all) or 1 (all-gather) + ONE all-reduce
             per_attn = 2 if sh.exchange == "alltoall" else 1
             n_attn = sum(1 for k in eng.w if k.endswith(".qkv.w") and "motion_modules" in k)
             assert sh.stats["collectives"] == windows * per_attn * n_attn + 1, (sh.stats["collectives"], n_attn)
@@ -252,3 +254,66 @@ def test_single_rank_rccl_step_graph(tmp_path, monkeypatch):
     assert len(segments) == len(graph) == 4
     for i, (a, b) in enumerate(zip(segments, graph)):
         assert torch.isfinite(b).all() and torch.equal(a, b), (i, float((a - b).abs().max()))
+
+
+def test_cfg_parallel_two_ranks_bit_identical_to_one_process(tmp_path):
+    """The CFG-parallel axis (FrameShard cfg_groups = 2, round 6): two ranks, rank h runs the B = 1 forward of CFG half h on
+    ALL frames (no temporal exchange), the accumulator all-reduce hands both halves to both ranks.  Every kernel result is
+    independent of the batch a row sits in, so the latents must equal the single-process run BIT FOR BIT (step 0 eager,
+    1 recorded as command-list segments around the collective, 2 replayed) -- and match the oracle loop like every other path."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    out_path = str(tmp_path / "cfg2.pt")
+    mp.spawn(_worker, args=(2, port, out_path, "gloo", 4, 1, 24, 4, True, 8, 3, 2), nprocs=2, join=True)
+    got = torch.load(out_path)
+    # the single-process run of the same problem (world 1, no sharding: the path bench.py times)
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ref_path = str(tmp_path / "single.pt")
+    mp.spawn(_single_worker, args=(ref_path,), nprocs=1, join=True)
+    ref = torch.load(ref_path)
+    assert len(got) == 3 and len(ref) == 3
+    for i, (a, b) in enumerate(zip(got, ref)):
+        assert torch.equal(a, b), (i, float((a - b).abs().max()))
+    O, cfg, sd, lat, pose, pl, clip, banks = _inputs()
+    trace = []
+    O.denoise_loop(sd, cfg, O.make_pose_guider_weights(), O.make_camera_encoder_weights(), lat.clone(), pose, pl, clip,
+                   banks, 4, 3.5, max_steps=3, trace=trace)
+    errs = [float((a - b).norm() / b.norm()) for a, b in zip(got, trace)]
+    print("CFG-parallel (2 ranks) latent nrmse per step", errs)
+    assert max(errs) < 2e-2, errs
+
+
+def _single_worker(rank, out_path):
+    torch.cuda.set_device(0)
+    O, cfg, sd, lat, pose, pl, clip, banks = _inputs()
+    from humanvid_amd.conditioning import CameraPoseEncoder, PoseGuider
+    from humanvid_amd.pipeline import Pose2VideoPipeline
+    from humanvid_amd.scheduler import DDIMScheduler
+    from humanvid_amd.unet3d import UNet3DConditionModel
+
+    net = UNet3DConditionModel(**dict(cfg, use_inflated_groupnorm=True, unet_use_cross_frame_attention=False,
+                                      unet_use_temporal_attention=False, motion_module_type="Vanilla"))
+    net.load_state_dict(sd, strict=True)
+    net = net.to("cuda")
+    pg = PoseGuider(320, block_out_channels=(16, 32, 96, 256))
+    pg.load_state_dict(O.make_pose_guider_weights(), strict=True)
+    cam = CameraPoseEncoder(downscale_factor=8, channels=[320], nums_rb=2, cin=384, ksize=1, sk=True, use_conv=False,
+                            compression_factor=1, temporal_attention_nhead=8, attention_block_types=["Temporal_Self"],
+                            temporal_position_encoding=True, temporal_position_encoding_max_len=24)
+    cam.load_state_dict(O.make_camera_encoder_weights(), strict=True)
+    sched = DDIMScheduler(beta_start=0.00085, beta_end=0.012, beta_schedule="linear", clip_sample=False, steps_offset=1,
+                          prediction_type="v_prediction", rescale_betas_zero_snr=True, timestep_spacing="trailing")
+    pipe = Pose2VideoPipeline(None, None, None, net, pg.to("cuda"), cam.to("cuda"), sched)
+    eng = net.engine()
+    eng.set_reference_banks({k: v.cuda() for k, v in banks.items()}, do_cfg=True)
+    eng._banks_from_modules = lambda: None
+    got = []
+    pipe.denoise(lat.clone().cuda(), pose.cuda(), pl.cuda(), clip.cuda(), 4, 3.5, max_steps=3,
+                 callback=lambda i, t, x: got.append(x.detach().float().cpu().clone()))
+    torch.cuda.synchronize()
+    torch.save(got, out_path)

@@ -378,6 +378,7 @@ def main():
         pipe.enable_frame_sharding(window_groups=args.window_groups, cfg_groups=cfg_groups if world > 1 else 1)
         if args.cfg_half is not None:  # one rank of a two-rank CFG-parallel job, on a one-rank group
             pipe.shard.cfg_groups, pipe.shard.cfg_group = 2, args.cfg_half
+            pipe.shard.cfg_half_diagnostic = True  # the absent rank's half of the accumulator: a copy of this one's (pipeline.py)
             cfg_groups = 2
 
     g = torch.Generator().manual_seed(42)

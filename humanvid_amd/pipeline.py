@@ -436,6 +436,12 @@ class Pose2VideoPipeline:
                     ops.pack_ncfhw(L, st, latents, xi, rep=1, frames=frames)
                     y = eng_half.forward_nhwc(xi, t_dev[hf_mine:hf_mine + 1], cond, B=1, F=fl)
                     ops.accumulate_window(L, st, y, 1, C, frames, acc[hf_mine:hf_mine + 1], counter if hf_mine == 0 else counter_other)
+                    if getattr(self.shard, "cfg_half_diagnostic", False):
+                        # bench.py --cfg-half (ONE rank of a two-rank job, alone): nobody fills the other half -- stand in this
+                        # half's prediction for it, so that the guided update stays a sane trajectory (with a zero half the
+                        # latents blow up after step 0 and the attention kernels take their overflow re-run on every launch)
+                        o = 1 - hf_mine
+                        ops.accumulate_window(L, st, y, 1, C, frames, acc[o:o + 1], counter if o == 0 else counter_other)
                 self.shard.all_reduce(acc_cnt)
                 ops.cfg_ddim_step(L, st, latents, acc, counter, rep, coeffs)
                 return

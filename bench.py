@@ -194,7 +194,7 @@ def roofline_from_profile(kernels, traffic_file):
         t = json.load(open(traffic_file))
         if t.get("csrc_digest") != csrc_digest():
             roof["traffic_note"] = (f"refused {os.path.basename(traffic_file)}: collected with kernel sources "
-                                    f"{t.get('csrc_digest')}, this build is {csrc_digest()} (re-run tools/final_r05.sh)")
+                                    f"{t.get('csrc_digest')}, this build is {csrc_digest()} (re-run tools/final_r06.sh)")
         else:
             k = t.get("kernels", {}).get(name)
             if k is not None:
@@ -531,7 +531,11 @@ def main():
         if exchange is not None:
             out["exchange"] = exchange
         if "kernels" in prof:
-            roof, table = roofline_from_profile(prof["kernels"], os.path.join(REPO, "profiles", "r05_pmc_traffic.json"))
+            # the newest committed counter summary (profiles/rNN_pmc_traffic.json); one made from other kernel sources is refused
+            import glob
+
+            tfiles = sorted(glob.glob(os.path.join(REPO, "profiles", "r[0-9][0-9]_pmc_traffic.json")))
+            roof, table = roofline_from_profile(prof["kernels"], tfiles[-1] if tfiles else "")
             out["roofline"] = roof
             out["kernels"] = table
         if not sharded and not args.no_cpu_baseline:

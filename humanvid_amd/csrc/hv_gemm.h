@@ -1357,12 +1357,14 @@ __global__ __launch_bounds__(512, 2) void hv_gemm_wide_kernel(HvGemmParams p, in
 }
 
 #include "hv_gemm4.h"  // the 256 x 256 x 64 tile on four waves of 128 x 128 (round 6)
+#include "hv_gemm_xs.h"  // X-stationary 192 x 128 tiles for K = 320 (round 6)
 
 static int g_hv_gemm_max_grid = 512;  // tuning knob (hv_set_tuning): persistent workgroups
 // tuning knob (hv_set_tuning key 10): which of the problems that take 256 x 256 x 64 tiles run on the four-wave kernel
 // (hv_gemm_w4_kernel): 1 (default) = the deferred-store forms at K >= 640 (see hv_gemm_choose), 0 = none (always the 8-wave
 // kernel), 2 = every problem whose shape allows it, stores at once, 3 = the same with deferred stores where the form has them
 static int g_hv_gemm_w4 = 1;
+static int g_hv_gemm_xs = 0;  // tuning knob (hv_set_tuning key 11): 1 = the LayerNorm-fold forms at K = 320 on hv_gemm_xs_kernel
 static int g_hv_gemm_w4_units = 1;  // (value 4: as 3 on the plain tile raster instead of the unit raster -- A/B)
 // tuning knob (hv_set_tuning key 3) -- kernel selection:
 //   1 (default): 256 x 320 x 64 wide tiles for N = 320, K >= 640 (M % 256 == 0, plain-output forms); otherwise 256 x 256 x 64
@@ -1448,6 +1450,12 @@ static inline HvGemmChoice hv_gemm_choose(const HvGemmParams& p, bool want_stats
     //   -4 / -11 %, profiles/r06_s5_w4_units.txt); at K = 320 (level 0: five k-tiles per tile) the exposed epilogue of a
     //   one-wave-per-SIMD kernel costs more than the deferred stores win (QKV 0.285 -> 0.315, ff1 0.72 -> 0.765);
     //   tuning 10 = 2 / 3 / 4: wherever its shape conditions hold, without / with deferred stores (A/Bs and tests)
+    // X-stationary kernel (hv_gemm_xs.h): K = 320, the LayerNorm-fold forms on the permuted assignment
+    if (big && g_hv_gemm_xs && p.K == 320 && p.N % 64 == 0 && p.N >= 128 && p.X2 == nullptr && p.M % 192 == 0 && c.perm &&
+        (c.form == HV_FORM_LN || c.form == HV_FORM_LN_GEGLU) && hv_gemm_fast_form(p, 96) == c.form) {
+        c.kernel = 5;
+        return c;
+    }
     if (big && g_hv_gemm_w4 && p.N % 64 == 0 && p.X2 == nullptr) {
         const bool defer_form = c.perm && (c.form == HV_FORM_LN || c.form == HV_FORM_LN_GEGLU) && p.M % 192 == 0 && p.K >= 320 &&
                                 hv_gemm_fast_form(p, 96) == c.form;
@@ -1492,6 +1500,33 @@ static inline int hv_gemm_launch(const HvGemmParams& p, hipStream_t stream) {
             hv_note("hv_gemm_glds_kernel<256,8,256,1> | %s", shape);
             hv_launch(hv_gemm_glds_kernel<256, 8, 256, 1, false>, dim3(grid), dim3(512), stream, p, c.gm, c.form);
         }
+        return 0;
+    }
+    if (c.kernel == 5) {
+        const int tiles_m = p.M / 192, tiles_n = (p.N + 127) / 128;
+        auto grid_of = [&](int work) {
+            int g = ((work + 7) / 8) * 8;
+            if (g > 256) g = 256;
+            if (g > g_hv_gemm_max_grid) g = g_hv_gemm_max_grid;
+            return g;
+        };
+        auto fill = [&](int work) {
+            const int g = grid_of(work), per_xcd = (work + 7) / 8, rounds = (per_xcd + g / 8 - 1) / (g / 8);
+            return (double)work / ((double)rounds * g);
+        };
+        // column tiles per unit: the largest divisor of tiles_n whose units fill the workgroups' rounds (the resident X block
+        // is loaded once per unit)
+        int U = 1;
+        const double f1 = fill(tiles_m * tiles_n);
+        for (int u = tiles_n; u > 1; --u)
+            if (tiles_n % u == 0 && fill(tiles_m * (tiles_n / u)) >= 0.97 * f1) {
+                U = u;
+                break;
+            }
+        const int grid = grid_of(tiles_m * (tiles_n / U));
+        hv_note("hv_gemm_xs_kernel | %s", shape);
+        if (c.form == HV_FORM_LN) hv_launch(hv_gemm_xs_kernel<1>, dim3(grid), dim3(256), stream, p, U);
+        else hv_launch(hv_gemm_xs_kernel<2>, dim3(grid), dim3(256), stream, p, U);
         return 0;
     }
     if (c.kernel == 4) {

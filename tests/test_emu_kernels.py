@@ -208,7 +208,20 @@ def test_gemm_four_wave_tiles(cx):
         for k, v in outs.items():
             if k[0] != 0:
                 assert torch.equal(v, outs[(0, k[1])]), f"four-wave kernel (tuning {k[0]}) differs from the 8-wave kernel: {k[1]}"
+        # hv_gemm_xs_kernel (hv_gemm_xs.h, tuning key 11): K = 320, the row block's X resident in LDS, W streamed in 128-column
+        # tiles, the epilogue software-pipelined into the next tile; two units per workgroup (the second unit's X streams in during
+        # the first one's last tile), ragged N (960 = 7.5 tiles of 128: the last tile is moved onto its neighbour)
+        cx.lib.call("hv_set_tuning", 10, 0)
+        cx.lib.call("hv_set_tuning", 11, 1)
+        y = kc.case_gemm_forms(cx, M=768, C=320, N=512, P=384, form="ln_geglu", seed=92, return_output=True)
+        assert torch.equal(y, outs[(0, "d_geglu")]), "X-stationary kernel differs from the 8-wave kernel: ln_geglu"
+        cx.lib.call("hv_set_tuning", 11, 0)
+        ref = kc.case_gemm_forms(cx, M=768, C=320, N=960, P=384, form="ln", seed=94, return_output=True)
+        cx.lib.call("hv_set_tuning", 11, 1)
+        y = kc.case_gemm_forms(cx, M=768, C=320, N=960, P=384, form="ln", seed=94, return_output=True)
+        assert torch.equal(y, ref), "X-stationary kernel differs from the 8-wave kernel: ln"
     finally:
+        cx.lib.call("hv_set_tuning", 11, 0)
         cx.lib.call("hv_set_tuning", 10, 1)
         cx.lib.call("hv_set_tuning", 2, 512)
         cx.lib.call("hv_set_tuning", 3, 1)

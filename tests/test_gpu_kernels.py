@@ -109,7 +109,14 @@ def test_gemm_four_wave_kernel_bench_shapes(cx):
                     outs[i] = y
                 else:
                     assert torch.equal(y, outs[i]), f"four-wave kernel (tuning 10 = {w4}) differs from the 8-wave kernel: {c}"
+        # the X-stationary kernel (hv_gemm_xs.h, tuning key 11) on the two level-0 shapes
+        cx.lib.call("hv_set_tuning", 10, 1)
+        cx.lib.call("hv_set_tuning", 11, 1)
+        for i in (3, 4):
+            y = kc.case_gemm_forms(cx, return_output=True, **cases[i])
+            assert torch.equal(y, outs[i]), f"X-stationary kernel differs from the 8-wave kernel: {cases[i]}"
     finally:
+        cx.lib.call("hv_set_tuning", 11, 0)
         cx.lib.call("hv_set_tuning", 10, 1)
 
 

@@ -1442,24 +1442,30 @@ static inline HvGemmChoice hv_gemm_choose(const HvGemmParams& p, bool want_stats
     c.perm = p.N % 8 == 0 &&
              (c.form == HV_FORM_RES || c.form == HV_FORM_PLAIN || c.form == HV_FORM_LN || c.form == HV_FORM_LN_GEGLU);
     if (p.perm_p != 0 && !c.perm) return HvGemmChoice{0, HV_FORM_NONE, 1, false};  // row-permuted output: that epilogue only
-    // the four-wave kernel (hv_gemm4.h) where the 8-wave 256 x 256 kernel would run:
-    //   default (tuning 10 = 1): the deferred-store forms (LayerNorm fold with / without GEGLU, permuted channels, M % 192 == 0)
-    //   at K >= 1280 and M >= 16384 -- the one class where it wins INSIDE the step (per-shape step profiles, same box,
-    //   profiles/r06_s7_step_profile_*.tsv: level-2 ff1 0.429 -> 0.415 ms per launch; level-1 ff1 0.474 -> 0.500, level-1
-    //   motion QKV 0.206 -> 0.216, level-3 ff1 0.116 -> 0.121 -- in isolation (microbench, cold X) levels 1 / 2 measured
-    //   -4 / -11 %, profiles/r06_s5_w4_units.txt); at K = 320 (level 0: five k-tiles per tile) the exposed epilogue of a
-    //   one-wave-per-SIMD kernel costs more than the deferred stores win (QKV 0.285 -> 0.315, ff1 0.72 -> 0.765);
+    // the four-wave kernel (hv_gemm4.h):
+    //   default (tuning 10 = 1): the deferred-store forms (LayerNorm fold with / without GEGLU, bias + residual; permuted
+    //   channels, M % 192 == 0) at K >= 1280 and M >= 16384 where 256-wide tiles fit N -- the class where it wins INSIDE the
+    //   step (per-shape step profiles, same box, profiles/r06_s18.txt: level-2 ff1 0.470 -> 0.441 ms per launch, level-2 ff2
+    //   (K = 5120, residual in place) 0.258 -> 0.210, level-2 motion QKV 0.198 -> 0.182: -0.93 ms per step).  Not taken:
+    //   level 1 (K = 640: ff1 0.474 -> 0.500, QKV 0.206 -> 0.216 in the step although -4 % in isolation), level 3 (M = 4608:
+    //   ff1 0.116 -> 0.121), level 0 (K = 320, five k-tiles per tile: the exposed epilogue of a one-wave-per-SIMD kernel
+    //   costs more than the deferred stores win: QKV 0.285 -> 0.315, ff1 0.72 -> 0.765);
     //   tuning 10 = 2 / 3 / 4: wherever its shape conditions hold, without / with deferred stores (A/Bs and tests)
-    // X-stationary kernel (hv_gemm_xs.h): K = 320, the LayerNorm-fold forms on the permuted assignment
-    if (big && g_hv_gemm_xs && p.K == 320 && p.N % 64 == 0 && p.N >= 128 && p.X2 == nullptr && p.M % 192 == 0 && c.perm &&
-        (c.form == HV_FORM_LN || c.form == HV_FORM_LN_GEGLU) && hv_gemm_fast_form(p, 96) == c.form) {
-        c.kernel = 5;
-        return c;
-    }
-    if (big && g_hv_gemm_w4 && p.N % 64 == 0 && p.X2 == nullptr) {
-        const bool defer_form = c.perm && (c.form == HV_FORM_LN || c.form == HV_FORM_LN_GEGLU) && p.M % 192 == 0 && p.K >= 320 &&
+    if (g_hv_gemm_w4 && p.N % 64 == 0 && p.X2 == nullptr && p.perm_p == 0 && g_hv_gemm_glds != 3) {
+        // (the residual form stores in place: no overlapping last column tile, and no statistics variant of this kernel)
+        const bool res_ok = c.form == HV_FORM_RES && p.N % 256 == 0 && !want_stats && p.gn_part == nullptr && p.ln_part == nullptr;
+        const bool defer_form = c.perm && (c.form == HV_FORM_LN || c.form == HV_FORM_LN_GEGLU || res_ok) && p.M % 192 == 0 && p.K >= 320 &&
                                 hv_gemm_fast_form(p, 96) == c.form;
-        if (g_hv_gemm_w4 == 1 ? (defer_form && p.K >= 1280 && p.M >= 16384) : (p.M % 256 == 0 || (g_hv_gemm_w4 == 3 && defer_form))) c.kernel = 4;
+        // (192-row tiles quantise finer than 256-row ones: level-2 QKV, M = 18 432, N = 3 840, is 5.6 rounds of 192 x 256 tiles
+        //  = 94 % where 256 x 256 tiles are 4.2 rounds = 84 % and the selection above takes the 128 x 128 kernel)
+        const int t192 = (p.M / 192) * (n256 / 256), rounds192 = (t192 + 255) / 256;
+        const bool fills192 = t192 * 10 >= rounds192 * 256 * 9;
+        const bool wide = p.N >= 960 && (n256 - p.N) * 8 <= p.N;
+        if (g_hv_gemm_w4 == 1) {
+            if (defer_form && wide && (big || fills192) && p.K >= 1280 && p.M >= 16384) c.kernel = 4;
+        } else if (big && (p.M % 256 == 0 || (g_hv_gemm_w4 == 3 && defer_form))) {
+            c.kernel = 4;
+        }
     }
     return c;
 }
@@ -1533,7 +1539,9 @@ static inline int hv_gemm_launch(const HvGemmParams& p, hipStream_t stream) {
         // 192-row tiles (waves of 96 x 128) with deferred output stores for the two forms that carry the volume (K >= 320:
         // four k-tiles of the next tile take them); 256-row tiles with the epilogues of this file otherwise
         const bool defer = g_hv_gemm_w4 != 2 && c.perm && p.K >= 320 && p.M % 192 == 0 &&
-                           (c.form == HV_FORM_LN || c.form == HV_FORM_LN_GEGLU) && hv_gemm_fast_form(p, 96) == c.form;
+                           (c.form == HV_FORM_LN || c.form == HV_FORM_LN_GEGLU ||
+                            (c.form == HV_FORM_RES && p.N % 256 == 0 && p.gn_part == nullptr && p.ln_part == nullptr)) &&
+                           hv_gemm_fast_form(p, 96) == c.form;
         const int bm = defer ? 192 : 256;
         const int tiles_m = p.M / bm, tiles_n = (p.N + 255) / 256;
         const int tiles = tiles_m * tiles_n;
@@ -1565,6 +1573,9 @@ static inline int hv_gemm_launch(const HvGemmParams& p, hipStream_t stream) {
         if (defer && c.form == HV_FORM_LN) {
             hv_note("hv_gemm_w4_kernel<perm,defer,192> | %s", shape);
             hv_launch(hv_gemm_w4_kernel<true, 1, 6>, dim3(grid), dim3(256), stream, p, gm, c.form);
+        } else if (defer && c.form == HV_FORM_RES) {
+            hv_note("hv_gemm_w4_kernel<perm,defer,192> | %s", shape);
+            hv_launch(hv_gemm_w4_kernel<true, 3, 6>, dim3(grid), dim3(256), stream, p, gm, c.form);
         } else if (defer) {
             hv_note("hv_gemm_w4_kernel<perm,defer,192> | %s", shape);
             hv_launch(hv_gemm_w4_kernel<true, 2, 6>, dim3(grid), dim3(256), stream, p, gm, c.form);

@@ -74,7 +74,7 @@ HV_DEV void hv_acc_settle() {
 struct HvGemm4Cols {
     f32x4 add[4], cs[4], tab[4];
 };
-template <bool GEGLU>
+template <bool GEGLU, bool LN = true>
 HV_DEV void hv_gemm4_load_cols(const HvGemmParams& p, int n_base, int quad, const float* tab_row, HvGemm4Cols& c) {
     auto ld4 = [&](const float* base, unsigned byte_ofs) __attribute__((always_inline)) {
         return *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(base) + byte_ofs);
@@ -88,7 +88,7 @@ HV_DEV void hv_gemm4_load_cols(const HvGemmParams& p, int n_base, int quad, cons
 #pragma unroll
     for (int nf = 0; nf < 4; ++nf) {
         c.add[nf] = p.bias != nullptr ? ld4(p.bias, nb[nf]) : f32x4{0.f, 0.f, 0.f, 0.f};
-        c.cs[nf] = ld4(p.colsum, nb[nf]);
+        c.cs[nf] = LN ? ld4(p.colsum, nb[nf]) : f32x4{0.f, 0.f, 0.f, 0.f};
         c.tab[nf] = tab_row != nullptr ? ld4(tab_row, nb[nf]) : f32x4{0.f, 0.f, 0.f, 0.f};
     }
 }
@@ -130,6 +130,40 @@ HV_DEV void hv_gemm4_pack_ln(f32x4 (&acc)[4][NMF], const HvGemm4Cols& c, const f
     }
 }
 
+// bias (+ table row) + residual, permuted channels: the arithmetic of hv_gemm_epilogue_fast_perm<NMF, false, true> (hv_gemm.h).
+// res[mf][h]: the residual's 8 bf16 at the lane's row of fragment mf, channels 32 h + 8 quad .. (loaded by the caller, one group
+// of loads for the whole 64-channel block)
+template <int NMF>
+HV_DEV void hv_gemm4_pack_res(f32x4 (&acc)[4][NMF], const HvGemm4Cols& c, const u32x4 (&res)[NMF][2], u32x4 (&outp)[NMF][2]) {
+    constexpr int G = HV_GEMM_EPI_G;
+#pragma unroll
+    for (int g = 0; g < NMF; g += G) {
+#pragma unroll
+        for (int j = 0; j < G; ++j) {
+            const int mf = g + j;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                u32x4 o;
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    const int nf = 2 * h + k;
+                    f32x4 v = hv_acc_take(acc[nf][mf]);
+                    v += c.add[nf];
+                    const unsigned r0 = res[mf][h][2 * k], r1 = res[mf][h][2 * k + 1];
+                    v += f32x4{hv_bf2f((bf16_t)(r0 & 0xffff)), hv_bf2f((bf16_t)(r0 >> 16)), hv_bf2f((bf16_t)(r1 & 0xffff)),
+                               hv_bf2f((bf16_t)(r1 >> 16))};
+                    o[2 * k] = hv_pack2(v[0], v[1]);
+                    o[2 * k + 1] = hv_pack2(v[2], v[3]);
+                }
+                outp[mf][h] = o;
+            }
+        }
+#if !defined(HV_EMU)
+        __builtin_amdgcn_sched_barrier(0);
+#endif
+    }
+}
+
 template <int NMF>
 HV_DEV void hv_gemm4_pack_geglu(f32x4 (&acc)[4][NMF], const HvGemm4Cols& c, const float (&mean)[NMF], const float (&rstd)[NMF],
                                 u32x4 (&outp)[NMF]) {
@@ -162,7 +196,7 @@ HV_DEV void hv_gemm4_pack_geglu(f32x4 (&acc)[4][NMF], const HvGemm4Cols& c, cons
 // DEFER: 0 = the epilogues of hv_gemm.h, stores issued at once (every output form);
 //        1 = LayerNorm-fold form, permuted channels: 4 NMF packed 16-byte results per wave and tile, stored NMF per k-tile
 //            behind the first four k-tiles of the next tile;  2 = LayerNorm fold + GEGLU: 2 NMF results, NMF / 2 per k-tile.
-//            (K >= 320: five k-tiles)
+//            (K >= 320: five k-tiles)   3 = bias (+ table row) + residual, in place or not (N % 256 == 0: no tile overlap), as 1.
 #ifdef HV_W4_TRACE
 // timing build (tools/build_variant.sh w4trace k_gemm -DHV_W4_TRACE): per workgroup, wave 0 accumulates s_memtime ticks spent
 // [0] in the whole kernel, [1] in the counted vmcnt waits, [2] at the barriers, [3] in the epilogue (pack), [4] k-tiles, [5] tiles
@@ -393,7 +427,7 @@ __global__ __launch_bounds__(256, 1) void hv_gemm_w4_kernel(HvGemmParams p, int 
     constexpr int EXTRA = NP - NB;                  // main blocks that carry two pieces (0 or 2)
     constexpr int SB = 6 - EXTRA;                   // first main block whose pieces are all X pieces: 6 (NMF 8) / 4 (NMF 6)
     static_assert(NB - 2 - SB == NMF, "one store slot per X piece block");
-    constexpr int NOUT = DEFER == 1 ? 4 * NMF : (DEFER == 2 ? 2 * NMF : 1);
+    constexpr int NOUT = (DEFER == 1 || DEFER == 3) ? 4 * NMF : (DEFER == 2 ? 2 * NMF : 1);
     constexpr int NS = DEFER != 0 ? NOUT / 4 : 0;   // group 0: stored at once by the epilogue
     constexpr int ND = DEFER != 0 ? NOUT - NS : 0;  // deferred: spread over the first FIVE k-tiles of the next tile
     u32x4 outp[NOUT];  // DEFER 1: [h][mf][c] (c: channel halves 32 c + 8 quad of the block), DEFER 2: [h][mf]
@@ -406,12 +440,12 @@ __global__ __launch_bounds__(256, 1) void hv_gemm_w4_kernel(HvGemmParams p, int 
         int m0, n0;
         tile_origin(first, m0, n0);
         const int mb = m0 + WTM * wm, nb = n0 + 128 * wn;
-        ydef = reinterpret_cast<const char*>(p.Y) + ((long)mb * p.ldy + (DEFER == 1 ? nb : (nb >> 1))) * 2;
+        ydef = reinterpret_cast<const char*>(p.Y) + ((long)mb * p.ldy + (DEFER != 2 ? nb : (nb >> 1))) * 2;
     }
     const unsigned ylane = ((unsigned)r16 * (unsigned)p.ldy + 8u * (unsigned)quad) * 2u;
     const unsigned yfrag = 16u * (unsigned)p.ldy * 2u;  // bytes between row fragments
     auto store_out = [&](int i) __attribute__((always_inline)) {  // (i is a constant after inlining)
-        if constexpr (DEFER == 1) {
+        if constexpr (DEFER == 1 || DEFER == 3) {
             const int h = i / (2 * NMF), mf = (i / 2) % NMF, c = i & 1;
             hv_st16(const_cast<char*>(ydef) + ((unsigned)mf * yfrag + (unsigned)(128 * h + 64 * c)) + ylane, outp[i]);
         } else if constexpr (DEFER == 2) {
@@ -419,6 +453,14 @@ __global__ __launch_bounds__(256, 1) void hv_gemm_w4_kernel(HvGemmParams p, int 
             hv_st16(const_cast<char*>(ydef) + ((unsigned)mf * yfrag + (unsigned)(64 * h)) + ylane, outp[i]);
         }
     };
+    if constexpr (DEFER == 3) {
+        // the residual form may store IN PLACE (Y is the residual): the first tile's unconditional store slots must not put
+        // garbage where that tile's own epilogue reads the residual later -- they write back what is there
+        hv_static_for<NOUT>([&](auto I) __attribute__((always_inline)) {
+            constexpr int i = decltype(I)::value, h = i / (2 * NMF), mf = (i / 2) % NMF, c = i & 1;
+            outp[i] = hv_ld16(ydef + ((unsigned)mf * yfrag + (unsigned)(128 * h + 64 * c)) + ylane);
+        });
+    }
     auto pack_tile = [&](int ti) __attribute__((always_inline)) {
         int m0, n0;
         tile_origin(ti, m0, n0);
@@ -426,6 +468,30 @@ __global__ __launch_bounds__(256, 1) void hv_gemm_w4_kernel(HvGemmParams p, int 
         if constexpr (DEFER == 0) {
             hv_gemm_epilogue_form<NMF, PERM, 0>(form, p, reinterpret_cast<f32x4(&)[4][NMF]>(acc[0]), mb, nb, r16, quad);
             hv_gemm_epilogue_form<NMF, PERM, 0>(form, p, reinterpret_cast<f32x4(&)[4][NMF]>(acc[4]), mb, nb + 64, r16, quad);
+        } else if constexpr (DEFER == 3) {
+            const float* tab = nullptr;
+            if (p.pe != nullptr) tab = p.pe + (long)((mb / p.pe_period) % p.pe_frames) * p.N;
+            else if (p.rowvec != nullptr) tab = p.rowvec + (long)(mb / p.rowvec_period) * p.N;
+            hv_acc_settle();
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {  // one 64-channel block at a time: its residual rows are 12 loads in flight (48 registers)
+                HvGemm4Cols c0;
+                hv_gemm4_load_cols<false, false>(p, nb + 64 * h, quad, tab, c0);
+                u32x4 res[NMF][2];
+#pragma unroll
+                for (int mf = 0; mf < NMF; ++mf)
+#pragma unroll
+                    for (int c = 0; c < 2; ++c)
+                        res[mf][c] = hv_ld16(reinterpret_cast<const char*>(p.residual) +
+                                             (((unsigned)(mb + 16 * mf + r16) * (unsigned)p.ldr + (unsigned)(nb + 64 * h + 32 * c + 8 * quad)) * 2u));
+                fence();
+                hv_gemm4_fold_cols(c0, tab != nullptr);
+                hv_gemm4_pack_res<NMF>(reinterpret_cast<f32x4(&)[4][NMF]>(acc[4 * h]), c0, res, reinterpret_cast<u32x4(&)[NMF][2]>(outp[2 * NMF * h]));
+                fence();
+            }
+            ydef = reinterpret_cast<const char*>(p.Y) + ((long)mb * p.ldy + nb) * 2;
+#pragma unroll
+            for (int i = 0; i < NS; ++i) store_out(i);
         } else {
             const float* tab = nullptr;  // one table row per wave sub-tile (hv_gemm_fast_form(p, WTM))
             if (p.pe != nullptr) tab = p.pe + (long)((mb / p.pe_period) % p.pe_frames) * p.N;

@@ -205,6 +205,7 @@ def test_gemm_four_wave_tiles(cx):
             # deferred stores: 192-row tiles, 5 / 6 k-tiles, two tiles per workgroup (the second carries the first one's stores)
             outs[(w4, "d_geglu")] = kc.case_gemm_forms(cx, M=768, C=320, N=512, P=384, form="ln_geglu", seed=92, return_output=True)
             outs[(w4, "d_ln")] = kc.case_gemm_forms(cx, M=768, C=384, N=960, P=384, form="ln", seed=93, return_output=True)
+            outs[(w4, "d_res")] = kc.case_gemm_forms(cx, M=768, C=320, N=1024, P=384, form="res", seed=95, return_output=True)  # in place
         for k, v in outs.items():
             if k[0] != 0:
                 assert torch.equal(v, outs[(0, k[1])]), f"four-wave kernel (tuning {k[0]}) differs from the 8-wave kernel: {k[1]}"

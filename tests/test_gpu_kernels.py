@@ -87,7 +87,7 @@ def test_bench_shape_gemm_forms(cx):
 
 
 def test_gemm_four_wave_kernel_bench_shapes(cx):
-    """hv_gemm_w4_kernel (hv_gemm4.h) at the step's shapes: the default selection (deferred-store forms at K >= 640), the
+    """hv_gemm_w4_kernel (hv_gemm4.h) at the step's shapes: the default selection (deferred-store forms at K >= 1280, M >= 16384), the
     same kernel forced at level 0 (tuning 10 = 3: unit raster, five k-tiles per tile; 4: tile raster) and with its stores at
     once (2) give the bits of the 8-wave kernel (0) -- every selection accumulates k-slices in the same order."""
     import torch
@@ -95,14 +95,16 @@ def test_gemm_four_wave_kernel_bench_shapes(cx):
     cases = [dict(M=48 * 1536, C=640, N=2560, P=1536, form="ln_geglu", seed=38),     # level-1 ff1
              dict(M=48 * 1536, C=640, N=1920, P=1536, form="ln", seed=43),           # level-1 motion-module QKV (PE row per frame)
              dict(M=48 * 384, C=1280, N=5120, P=384, form="ln_geglu", seed=44),      # level-2 ff1
-             dict(M=48 * 6144, C=320, N=960, P=6144, form="ln", seed=45),            # level 0 (default: 8-wave kernel)
+             dict(M=48 * 384, C=5120, N=1280, P=24 * 384, form="res", seed=47),      # level-2 ff2: deferred residual form, in place
+             dict(M=48 * 384, C=1280, N=3840, P=384, form="ln", seed=48),            # level-2 motion-module QKV (192-row tiles fill)
+             dict(M=48 * 6144, C=320, N=960, P=6144, form="ln", seed=45),            # level 0 (default: 8-wave kernel) [5]
              dict(M=48 * 6144, C=320, N=1280, P=6144, form="ln_geglu", seed=46)]
     outs = {}
     try:
         for w4 in (0, 1, 3, 4, 2):
             cx.lib.call("hv_set_tuning", 10, w4)
             for i, c in enumerate(cases):
-                if w4 in (4, 2) and i not in (1, 3):
+                if w4 in (4, 2) and i not in (1, 5):
                     continue
                 y = kc.case_gemm_forms(cx, return_output=True, **c)
                 if w4 == 0:
@@ -112,7 +114,7 @@ def test_gemm_four_wave_kernel_bench_shapes(cx):
         # the X-stationary kernel (hv_gemm_xs.h, tuning key 11) on the two level-0 shapes
         cx.lib.call("hv_set_tuning", 10, 1)
         cx.lib.call("hv_set_tuning", 11, 1)
-        for i in (3, 4):
+        for i in (5, 6):
             y = kc.case_gemm_forms(cx, return_output=True, **cases[i])
             assert torch.equal(y, outs[i]), f"X-stationary kernel differs from the 8-wave kernel: {cases[i]}"
     finally:

@@ -4,6 +4,8 @@
     python oracle/gen_fullsize_steps_golden.py steps3      # two consecutive steps (t = 999, 966) at 24f x 96x64 latents
     python oracle/gen_fullsize_steps_golden.py windows48   # one + one step of a 48-frame clip, three windows per step
     python oracle/gen_fullsize_steps_golden.py edge_t32    # the last step of the 30-step schedule (final_alpha_cumprod)
+    python oracle/gen_fullsize_steps_golden.py traj30      # all 30 steps at 24f x 96x64 (2.5 h on 8 cores); keeps the latents
+                                                           # after steps 0, 4, 9, ... 29 as fp16 and every step's rms
 
 Runs in the build container (needs /root/reference).  The reference's UNet3DConditionModel (read mode, CFG, seeded fp16
 banks), PoseGuider and CameraPoseEncoder are imported verbatim and driven by the statements of the reference's loop body,
@@ -116,9 +118,17 @@ def main():
             arrs["latents_in"] = latents.numpy().copy()
         latents = scheduler.step(noise_pred, int(t), latents)
         assert torch.isfinite(latents).all()
-        arrs[f"noise_pred{i}"] = noise_pred.half().numpy()
-        arrs[f"latents{i}"] = latents.numpy().copy()
-        arrs[f"counter{i}"] = counter.reshape(-1).numpy().copy()
+        keep = geo.get("keep")
+        if keep is None:
+            arrs[f"noise_pred{i}"] = noise_pred.half().numpy()
+            arrs[f"latents{i}"] = latents.numpy().copy()
+            arrs[f"counter{i}"] = counter.reshape(-1).numpy().copy()
+        else:  # a long trajectory: the latents of a few steps as fp16, rms of every step; written as it goes
+            arrs[f"latent_rms{i}"] = float(latents.pow(2).mean().sqrt())
+            arrs[f"noise_rms{i}"] = float(noise_pred.pow(2).mean().sqrt())
+            if i in keep:
+                arrs[f"latents{i}"] = latents.half().numpy()
+                np.savez_compressed(os.path.join(refenv.REPO, "tests", "golden", f"steps_{case}.partial.npz"), **arrs)
         arrs[f"t{i}"] = int(t)
         print(f"[{case}] step {i} t={int(t)} windows={len(context_queue)} {time.time() - t0:.0f}s  "
               f"noise rms {noise_pred.pow(2).mean().sqrt():.4f} latent rms {latents.pow(2).mean().sqrt():.4f}", flush=True)

@@ -84,10 +84,14 @@ def rms_nhwc(x: torch.Tensor) -> torch.Tensor:
 # "windows48": one step of a 48-frame clip (context 24, overlap 4 -> three overlapping windows, the geometry of config #5's
 #             step) at a reduced 32 x 32 latent: window accumulation + counter division + CFG + DDIM
 # "edge_t32": the LAST step of the 30-step schedule (t = 32 -> prev < 0 -> final_alpha_cumprod) at config #3's size
+# "traj30":   all 30 steps at config #3's size from the same seeded start: the trajectory the benchmark times, end to end
 STEP_CASES = {
     "steps3": dict(F=24, h=96, w=64, steps=(0, 1), num_inference_steps=30),
     "windows48": dict(F=48, h=32, w=32, steps=(0, 1), num_inference_steps=30),
     "edge_t32": dict(F=24, h=96, w=64, steps=(29,), num_inference_steps=30),
+    # the WHOLE 30-step trajectory at config #3's size (2.5 h of host time once); only the latents after the steps in `keep`
+    # are committed (fp16)
+    "traj30": dict(F=24, h=96, w=64, steps=tuple(range(30)), num_inference_steps=30, keep=(0, 4, 9, 14, 19, 24, 29)),
 }
 GUIDANCE = 3.5
 

@@ -423,6 +423,8 @@ __global__ __launch_bounds__(2 * 64 * (NPIX / WPX), (WPX == 128 ? 2 : 1)) void h
     }
 }
 
+#include "hv_conv4.h"  // hv_conv_w4_kernel: 12 x 16 pixels x 320 channels on four waves (plain single-source stride-1 inputs)
+
 static int g_hv_conv_glds = 1;  // tuning knob (hv_set_tuning): LDS-DMA weight tiles
 
 static int g_hv_conv_big = 1;  // tuning knob: 256-pixel tiles (8 waves) on images that fill them
@@ -447,6 +449,10 @@ static inline void hv_conv3x3_launch_t(const hv_conv3x3_params& p, hipStream_t s
 // (tile rows, tile columns, pixel halves per tile) of the kernel hv_conv3x3_launch selects for this problem: the layout of
 // gn_part is [n_images][tiles_y * tiles_x * WM][Cout][2]
 static inline void hv_conv3x3_tile_shape(const hv_conv3x3_params& p, int& TH, int& TW, int& WM) {
+    if (hv_conv_w4_applies(p)) {
+        TH = HvConv4Geom::TH, TW = HvConv4Geom::TW, WM = HvConv4Geom::WM;
+        return;
+    }
     const bool narrow = p.Wo <= 8;
     const bool big = g_hv_conv_big && !narrow && p.Ho >= 16 && p.mode == HV_CONV_UP2;
     TW = narrow ? 8 : 16;
@@ -468,6 +474,10 @@ static inline int hv_conv3x3_launch(const hv_conv3x3_params& p, hipStream_t stre
     if (p.mode == HV_CONV_S1 && (p.Ho != p.Hs || p.Wo != p.Ws)) return -1;
     if (p.mode == HV_CONV_S2 && (p.Ho != (p.Hs + 1) / 2 || p.Wo != (p.Ws + 1) / 2)) return -1;
     if (p.mode == HV_CONV_UP2 && (p.Ho != 2 * p.Hs || p.Wo != 2 * p.Ws)) return -1;
+    if (hv_conv_w4_applies(p)) {
+        hv_conv_w4_launch(p, g_hv_conv_raster == 2 ? ((long)p.C1 * p.Cout >= 640L * 640 ? 1 : 0) : g_hv_conv_raster, stream);
+        return 0;
+    }
     // narrow images use the tall 16x8 patch so that the patch is not mostly padding; images with at
     // least 16 output rows use the 256-pixel (16x16) patch, except for the stride-2 form whose input
     // halo (33x33 pixels) would not fit two buffers in LDS

@@ -14,6 +14,7 @@ void hvk_gemm_use_xs(int on);
 void hvk_conv_use_glds(int on);
 void hvk_conv_use_big(int on);
 void hvk_conv_raster(int v);
+void hvk_conv_use_w4(int v);
 int hvk_conv3x3(const hv_conv3x3_params& p, hipStream_t s);
 int hvk_conv3x3_gn_parts(const hv_conv3x3_params& p);
 int hvk_groupnorm(const hv_groupnorm_params& p, hipStream_t s);

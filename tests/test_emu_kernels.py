@@ -289,6 +289,28 @@ def test_conv_64_channel_chunks(cx):
         cx.lib.call("hv_set_tuning", 5, 1)
 
 
+def test_conv_four_wave_tiles(cx):
+    """hv_conv_w4_kernel (12 x 16 pixels x 320 channels on four waves, halo and weights by LDS-DMA; tuning 12 = 2: wherever
+    the structure allows): exact and ragged patches, image borders on every side (zero padding through switched-off lanes),
+    one / two / three 64-channel chunks (the halo buffers and weight slots flip per chunk), two channel tiles on both
+    rasters, every epilogue operand on and off, the GroupNorm partial statistics of the output"""
+    cx.lib.call("hv_set_tuning", 12, 2)
+    try:
+        kc.case_conv(cx, n=2, H=12, W=16, C1=64, Cout=320, pro=False, seed=71)
+        kc.case_conv(cx, n=1, H=13, W=20, C1=128, Cout=320, pro=False, seed=72)                                   # ragged patches, 2 chunks
+        kc.case_conv(cx, n=1, H=24, W=16, C1=192, Cout=640, pro=False, temb=False, residual=False, seed=73)       # 3 chunks, 2 channel tiles
+        kc.case_conv(cx, n=1, H=5, W=35, C1=64, Cout=320, pro=False, out_act=A.ACT_SILU, seed=74)                 # three patches in a row
+        cx.lib.call("hv_set_tuning", 9, 1)
+        kc.case_conv(cx, n=2, H=12, W=16, C1=64, Cout=640, pro=False, seed=75)                                    # raster 1
+        cx.lib.call("hv_set_tuning", 9, 2)
+        kc.case_conv(cx, n=1, H=12, W=16, C1=64, Cout=320, pro=True, seed=76)                                     # prologue: the 128-channel kernels
+        kc.case_gn_parts_conv(cx, n=2, H=16, W=16, Cin=64, Cout=320)                                              # two patches x two pixel halves, ragged
+        kc.case_gn_parts_conv(cx, n=1, H=24, W=32, Cin=64, Cout=320, offset=3.0, seed=55)
+    finally:
+        cx.lib.call("hv_set_tuning", 9, 2)
+        cx.lib.call("hv_set_tuning", 12, 1)
+
+
 def test_conv_register_staged_variant(cx):
     cx.lib.call("hv_set_tuning", 4, 0)
     try:

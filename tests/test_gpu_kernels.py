@@ -140,6 +140,28 @@ def test_conv_shapes(cx):
     kc.case_conv(cx, n=2, H=64, W=48, C1=32, Cout=16, pro=False, temb=False, residual=False, out_act=A.ACT_SILU)
 
 
+def test_conv_four_wave_kernel(cx):
+    """hv_conv_w4_kernel at the shapes the denoising path takes it for (48 images; the CPU reference on three of them: first,
+    an inner one, last) and at forced shapes (tuning 12 = 2): ragged patches, two channel tiles on both rasters, GroupNorm
+    partial statistics of the output"""
+    kc.case_conv(cx, n=48, H=96, W=64, C1=320, Cout=320, pro=False, check=(0, 17, 47), seed=81)       # level-0 conv2 (residual)
+    kc.case_conv(cx, n=48, H=48, W=32, C1=640, Cout=640, pro=False, check=(0, 47), seed=82)           # level 1, raster 1
+    kc.case_conv(cx, n=48, H=96, W=64, C1=640, Cout=320, pro=False, residual=False, check=(0, 47), seed=83)  # up path, 10 chunks
+    cx.lib.call("hv_set_tuning", 12, 2)
+    try:
+        kc.case_conv(cx, n=3, H=64, W=64, C1=320, Cout=320, pro=False, seed=84)                       # config #2: ragged rows
+        kc.case_conv(cx, n=2, H=30, W=72, C1=128, Cout=640, pro=False, out_act=A.ACT_SILU, seed=85)   # ragged both ways
+        kc.case_conv(cx, n=2, H=24, W=16, C1=1280, Cout=1280, pro=False, seed=86)                     # level 2: 20 chunks, 4 channel tiles
+        cx.lib.call("hv_set_tuning", 9, 0)
+        kc.case_conv(cx, n=2, H=24, W=16, C1=640, Cout=640, pro=False, seed=87)                       # raster 0
+        cx.lib.call("hv_set_tuning", 9, 2)
+        kc.case_gn_parts_conv(cx, n=2, H=16, W=16, Cin=64, Cout=320)
+        kc.case_gn_parts_conv(cx, n=3, H=48, W=32, Cin=128, Cout=640, offset=3.0, seed=56)
+    finally:
+        cx.lib.call("hv_set_tuning", 9, 2)
+        cx.lib.call("hv_set_tuning", 12, 1)
+
+
 def test_layernorm_stats(cx):
     for C, M in ((320, 48 * 6144), (640, 48 * 1536 + 3), (1280, 4608), (192, 1000)):
         kc.case_layernorm_stats(cx, M=M, C=C)

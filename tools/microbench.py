@@ -34,6 +34,28 @@ def timeit(fn, iters=5, warmup=2):
     return s.elapsed_time(e) / iters
 
 
+def c4_trace(L):
+    """timing build of hv_conv_w4_kernel (-DHV_C4_TRACE): s_memtime marks of the last launch, per workgroup"""
+    if not hasattr(L.cdll, "hv_c4_trace_read"):
+        return
+    import ctypes
+    import numpy as np
+    import torch
+    buf = np.zeros(2048 * 8, dtype=np.uint64)
+    torch.cuda.synchronize()
+    L.cdll.hv_c4_trace_read(buf.ctypes.data_as(ctypes.c_void_p))
+    t = buf.reshape(2048, 8).astype(np.float64)
+    t = t[t[:, 4] > t[:, 0]]
+    if not len(t):
+        return
+    t0 = t[:, 0].min()
+    d = np.diff(t[:, :5], axis=1)
+    print(f"    c4 trace ({len(t)} workgroups, s_memtime ticks): prologue {d[:, 0].mean():.0f}, k-loop {d[:, 1].mean():.0f}, epilogue load issue "
+          f"{d[:, 2].mean():.0f}, arithmetic + stores {d[:, 3].mean():.0f}; launch span {t[:, 4].max() - t0:.0f}; workgroup starts (sorted, every 128th): "
+          + " ".join(f"{v - t0:.0f}" for v in np.sort(t[:, 0])[::128]), flush=True)
+    buf[:] = 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--quick", action="store_true")
@@ -129,6 +151,17 @@ def main():
             report(f"conv3x3 GN+SiLU fused {C}->{C} @{H}x{W}", ms, 2.0 * n * H * W * C * C * 9, 4.0 * n * H * W * C)
             ms = timeit(lambda: ops.conv3x3(L, st, x, w, y, bias=bias))
             report(f"conv3x3 plain {C}->{C} @{H}x{W}", ms, 2.0 * n * H * W * C * C * 9, 4.0 * n * H * W * C)
+            c4_trace(L)
+        # the up path's plain convolutions (the concatenated, normalised activation comes from hv_affine_apply_cat)
+        for (Ci, Co, H, W) in ((640, 320, 96, 64), (960, 320, 96, 64), (1280, 640, 48, 32), (1920, 640, 48, 32), (2560, 1280, 24, 16)):
+            x = rnd(n, H, W, Ci)
+            w = rnd(Co, 9, Ci, scale=(9 * Ci) ** -0.5)
+            y = torch.empty(n, H, W, Co, dtype=BF16, device=dev)
+            res = rnd(n, H, W, Co)
+            ms = timeit(lambda: ops.conv3x3(L, st, x, w, y, residual=res))
+            report(f"conv3x3 plain {Ci}->{Co} @{H}x{W} + residual", ms, 2.0 * n * H * W * Ci * Co * 9, 2.0 * n * H * W * (Ci + 2 * Co))
+            c4_trace(L)
+            del x, w, y, res
         # two-source + upsample + stride 2 at representative sizes
         x1, x2 = rnd(n, 48, 32, 640), rnd(n, 48, 32, 320)
         w = rnd(640, 9, 960, scale=0.01)

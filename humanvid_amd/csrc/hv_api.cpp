@@ -128,6 +128,7 @@ int hv_set_tuning(int key, int value) {
     else if (key == HV_TUNE_GEMM_MAX_GRID && value >= 8 && value % 8 == 0) hvk_gemm_tune(value);
     else if (key == HV_TUNE_GEMM_GLDS && ((value >= 0 && value <= 3) || value == 6)) hvk_gemm_use_glds(value);
     else if (key == HV_TUNE_GEMM_XS && (value == 0 || value == 1)) hvk_gemm_use_xs(value);
+    else if (key == HV_TUNE_GEMM_C4 && (value >= 0 && value <= 2)) hvk_gemm_use_c4(value);
     else if (key == HV_TUNE_GEMM_W4 && (value >= 0 && value <= 4)) hvk_gemm_use_w4(value);
     else if (key == HV_TUNE_CONV_GLDS && (value == 0 || value == 1)) hvk_conv_use_glds(value);
     else if (key == HV_TUNE_CONV_BIG && (value >= 0 && value <= 3)) hvk_conv_use_big(value);

@@ -33,7 +33,7 @@
 // land in slots nobody reads; the kernel drains them before it ends.
 #pragma once
 #include "hv_common.h"
-#include "hv_gemm4.h"  // hv_glds16_u, hv_acc_take, hv_acc_settle
+#include "hv_gemm4.h"  // hv_glds16_u, hv_acc_take, hv_acc_settle, hv_mfma_tied
 #include "humanvid_hip.h"
 
 struct HvConv4Geom {
@@ -61,19 +61,6 @@ HV_DEV void hv_glds16_um(const void* base_uniform, unsigned byte_ofs, void* lds_
 HV_DEV unsigned long hv_lane_mask(bool on) { return on ? 1ul : 0ul; }  // emulator: the lane's own bit
 #endif
 
-// acc += A . B with the accumulator TIED to its accumulation registers.  With the builtin hipcc's allocator takes the untied
-// form for a third of this kernel's 1 080 MFMAs per loop body (240 accumulators in 256 registers leave it room to) and then
-// permutes the accumulators back at the loop head: ~630 v_accvgpr moves per nine k-tiles.  An asm statement gets no hazard
-// padding from hipcc: operands from ds_read are covered by the s_waitcnt the compiler still places in front of the statement,
-// an accumulator is touched once per 60 MFMAs, and the epilogue leaves the read-after-MFMA wait states itself (hv_acc_settle).
-HV_DEV void hv_mfma_tied(f32x4& acc, const bf16x8& a, const bf16x8& b) {
-#ifndef HV_EMU
-    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
-#else
-    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc, 0, 0, 0);
-#endif
-}
-
 #ifdef HV_C4_TRACE
 // timing build (tools/build_variant.sh c4trace k_conv -DHV_C4_TRACE): per workgroup (first 2048), wave 0: s_memtime at kernel
 // start [0], behind barrier 0 [1], behind the k-loop [2], behind the epilogue's operand loads [3], at the end [4]
@@ -83,6 +70,7 @@ __device__ unsigned long long g_hv_c4_trace[2048 * 8];
 #define HV_C4_MARK(i)
 #endif
 
+template <int V = 0>  // (a template only so that the header may be included by several translation units)
 __global__ __launch_bounds__(256, 1) void hv_conv_w4_kernel(hv_conv3x3_params p, int raster) {
     using G = HvConv4Geom;
     constexpr int TW = G::TW, TH = G::TH, HW = G::HW;
@@ -376,5 +364,5 @@ static inline void hv_conv_w4_launch(const hv_conv3x3_params& p, int raster, hip
     const int grid = ((tiles + 7) / 8) * 8;
     hv_note("hv_conv_w4_kernel | n=%d Hs=%d Ws=%d Ho=%d Wo=%d Cin=%d Cout=%d gn=%d res=%d", p.n_images, p.Hs, p.Ws, p.Ho, p.Wo, p.C1,
             p.Cout, 0, p.residual != nullptr);
-    hv_launch(hv_conv_w4_kernel, dim3(grid), dim3(256), stream, p, raster);
+    hv_launch(hv_conv_w4_kernel<0>, dim3(grid), dim3(256), stream, p, raster);
 }

@@ -1357,7 +1357,8 @@ __global__ __launch_bounds__(512, 2) void hv_gemm_wide_kernel(HvGemmParams p, in
 }
 
 #include "hv_gemm4.h"  // the 256 x 256 x 64 tile on four waves of 128 x 128 (round 6)
-#include "hv_gemm_xs.h"  // X-stationary 192 x 128 tiles for K = 320 (round 6)
+#include "hv_gemm_xs.h"
+#include "hv_gemm_c4.h"  // X-stationary 192 x 128 tiles for K = 320 (round 6)
 
 static int g_hv_gemm_max_grid = 512;  // tuning knob (hv_set_tuning): persistent workgroups
 // tuning knob (hv_set_tuning key 10): which of the problems that take 256 x 256 x 64 tiles run on the four-wave kernel
@@ -1382,6 +1383,10 @@ struct HvGemmChoice {
     int kernel, form, gm;
     bool perm;
 };
+// 0: never; 1 (default): deep-K plain / residual projections whose N is a multiple of 320 and that neither the 256-wide
+// four-wave tiles nor the statistics-bearing kernels are meant for; 2: wherever the structure allows (tests)
+static int g_hv_gemm_c4 = 1;
+
 static inline HvGemmChoice hv_gemm_choose(const HvGemmParams& p, bool want_stats);
 
 // parts per image of the GroupNorm partial statistics (0 = this problem's kernel cannot emit them)
@@ -1409,6 +1414,21 @@ static inline HvGemmChoice hv_gemm_choose(const HvGemmParams& p, bool want_stats
     if (form64 == HV_FORM_NONE && p.N % 8 == 0 && p.pe != nullptr && hv_gemm_fast_form(p, 16) == HV_FORM_LN)
         form64 = HV_FORM_LN;
     if (!(g_hv_gemm_glds && !prologue && p.M >= 256 && span_ok && form64 != HV_FORM_NONE)) return c;
+    // 192 x 320 x 64 tiles on four waves (hv_gemm_c4_kernel): bias (+ residual) outputs without statistics or tables, N a
+    // multiple of 320, M of 192.  Default: K >= 1280 with at least 384 tiles, and not where 256-wide tiles fit N (N % 256 == 0:
+    // the deferred residual form of hv_gemm_w4_kernel) -- the feed-forward output projections of levels 0 and 1.
+    if (g_hv_gemm_c4 && g_hv_gemm_glds != 3 && p.N % 320 == 0 && p.M % 192 == 0 && p.X2 == nullptr && p.perm_p == 0 && p.Yt == nullptr &&
+        !p.geglu && !want_stats && p.gn_part == nullptr && p.ln_part == nullptr && p.pe == nullptr && p.rowvec == nullptr) {
+        const int form96 = hv_gemm_fast_form(p, 96);
+        const long tiles = (long)(p.M / 192) * (p.N / 320);
+        if ((form96 == HV_FORM_RES || form96 == HV_FORM_PLAIN) &&
+            (g_hv_gemm_c4 == 2 || (p.K >= 1280 && tiles >= 384 && p.N % 256 != 0))) {
+            c.kernel = 6;
+            c.form = form96;
+            c.perm = true;
+            return c;
+        }
+    }
     // 256 x 320 x 64 wide tiles (hv_gemm_wide_kernel) for N = 320, K >= 640 with a plain-output form on the permuted assignment
     // (level-0 ff2: same-box 0.385 -> 0.327 ms, profiles/r04_s1.txt).  Measured and not taken: K = 320 (0.158 -> 0.159 ms: five
     // k-steps do not amortise the 320-column epilogue), N = 640 (576 tiles at level 1 = 2.25 rounds over the 256 CUs: projection
@@ -1506,6 +1526,12 @@ static inline int hv_gemm_launch(const HvGemmParams& p, hipStream_t stream) {
             hv_note("hv_gemm_glds_kernel<256,8,256,1> | %s", shape);
             hv_launch(hv_gemm_glds_kernel<256, 8, 256, 1, false>, dim3(grid), dim3(512), stream, p, c.gm, c.form);
         }
+        return 0;
+    }
+    if (c.kernel == 6) {
+        const int tiles = (p.M / 192) * (p.N / 320);
+        hv_note("hv_gemm_c4_kernel | %s", shape);
+        hv_launch(hv_gemm_c4_kernel<0>, dim3(((tiles + 7) / 8) * 8), dim3(256), stream, p);
         return 0;
     }
     if (c.kernel == 5) {

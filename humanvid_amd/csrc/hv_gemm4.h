@@ -63,6 +63,19 @@ HV_DEV void hv_acc_settle() {
 #endif
 }
 
+// acc += A . B with the accumulator TIED to its accumulation registers.  With the builtin hipcc's allocator takes the untied
+// form for a third of hv_conv_w4_kernel's 1 080 MFMAs per loop body (240 accumulators in 256 registers leave it room to) and then
+// permutes the accumulators back at the loop head: ~630 v_accvgpr moves per nine k-tiles.  An asm statement gets no hazard
+// padding from hipcc: operands from ds_read are covered by the s_waitcnt the compiler still places in front of the statement,
+// an accumulator is touched once per 60 MFMAs, and the epilogue leaves the read-after-MFMA wait states itself (hv_acc_settle).
+HV_DEV void hv_mfma_tied(f32x4& acc, const bf16x8& a, const bf16x8& b) {
+#ifndef HV_EMU
+    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
+#else
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc, 0, 0, 0);
+#endif
+}
+
 // ---- epilogue of the deferred forms, in two phases so that ALL of a tile's operand loads are one round trip: the trace
 // build (profiles/r06_s4_w4_trace.txt) showed the epilogue at 5 800 - 8 200 cycles per tile with the loads requested group by
 // group (six dependent L2 round trips behind the in-flight LDS-DMA).

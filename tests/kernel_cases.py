@@ -248,7 +248,7 @@ def case_gemm_lnfold(cx: Ctx, B=2, Fr=3, P=20, C=320, N=192, seed=2):
     return e
 
 
-def case_gemm_forms(cx: Ctx, M=520, C=128, N=192, P=128, form="ln", seed=30, return_output=False):
+def case_gemm_forms(cx: Ctx, M=520, C=128, N=192, P=128, form="ln", seed=30, return_output=False, res_rowvec=True):
     """The epilogue forms of the denoising path as the engine launches them (hv_gemm_epilogue_fast on the LDS-DMA kernel
     when M >= 256 and the per-row table period P is a multiple of the wave sub-tile):
       ln        LayerNorm fold + bias + positional-encoding row (motion-module QKV)
@@ -305,9 +305,13 @@ def case_gemm_forms(cx: Ctx, M=520, C=128, N=192, P=128, form="ln", seed=30, ret
             nb = (M + P - 1) // P
             rv = rnd(g, nb, N, scale=0.3)
             res = rnd(g, M, N)
-            ref = ref + rv[torch.arange(M) // P] + r(res)
+            ref = ref + r(res)
             y.copy_(cx.bf(res))  # the residual stream is updated in place
-            ops.gemm(cx.lib, cx.stream, xd, cx.bf(w), y, bias=cx.dev(bias), rowvec=cx.dev(rv), rowvec_period=P, residual=y)
+            if res_rowvec:
+                ref = ref + rv[torch.arange(M) // P]
+                ops.gemm(cx.lib, cx.stream, xd, cx.bf(w), y, bias=cx.dev(bias), rowvec=cx.dev(rv), rowvec_period=P, residual=y)
+            else:  # the feed-forward output projection: bias + residual only
+                ops.gemm(cx.lib, cx.stream, xd, cx.bf(w), y, bias=cx.dev(bias), residual=y)
         else:
             ops.gemm(cx.lib, cx.stream, xd, cx.bf(w), y, bias=cx.dev(bias))
         cx.sync()

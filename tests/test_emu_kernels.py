@@ -228,6 +228,26 @@ def test_gemm_four_wave_tiles(cx):
         cx.lib.call("hv_set_tuning", 3, 1)
 
 
+def test_gemm_c4_tiles(cx):
+    """hv_gemm_c4_kernel (hv_gemm_c4.h, tuning key 13 = 2: wherever the structure allows): 192 x 320 x 64 tiles on four waves --
+    one / two / three / five / seven k-tiles (the 3-slot X ring and 2-slot W ring wrap; copies past the end are clamped), two
+    row blocks and two column tiles, bias + residual in place and bias only: the same bits as the other kernel selections"""
+    import torch
+
+    cases = [dict(M=192, C=64, N=320, form="plain", seed=101), dict(M=384, C=128, N=640, form="res", seed=102),
+             dict(M=192, C=192, N=320, form="res", seed=103), dict(M=384, C=320, N=320, form="res", seed=104),
+             dict(M=192, C=448, N=640, form="plain", seed=105)]
+    try:
+        for c in cases:
+            cx.lib.call("hv_set_tuning", 13, 0)
+            ref = kc.case_gemm_forms(cx, P=192, return_output=True, res_rowvec=False, **c)
+            cx.lib.call("hv_set_tuning", 13, 2)
+            y = kc.case_gemm_forms(cx, P=192, return_output=True, res_rowvec=False, **c)
+            assert torch.equal(y, ref), f"hv_gemm_c4_kernel differs from the default selection: {c}"
+    finally:
+        cx.lib.call("hv_set_tuning", 13, 1)
+
+
 def test_gemm_prologue(cx):
     kc.case_gemm_prologue(cx)
 

@@ -122,6 +122,27 @@ def test_gemm_four_wave_kernel_bench_shapes(cx):
         cx.lib.call("hv_set_tuning", 10, 1)
 
 
+def test_gemm_c4_kernel_bench_shapes(cx):
+    """hv_gemm_c4_kernel (hv_gemm_c4.h: 192 x 320 x 64 tiles on four waves) at the shapes the denoising path takes it for -- the
+    feed-forward output projections of levels 0 and 1, residual in place -- and forced (tuning 13 = 2) at a short reduction:
+    the bits of the default selection without it (13 = 0)"""
+    import torch
+
+    cases = [dict(M=48 * 6144, C=1280, N=320, P=6144, form="res", seed=111),    # level-0 ff2
+             dict(M=48 * 1536, C=2560, N=640, P=1536, form="res", seed=112),    # level-1 ff2
+             dict(M=48 * 6144, C=320, N=320, P=6144, form="res", seed=113),     # forced: five k-tiles
+             dict(M=48 * 384, C=1280, N=1280, P=384, form="plain", seed=114)]   # forced: four column tiles, bias only
+    try:
+        for i, c in enumerate(cases):
+            cx.lib.call("hv_set_tuning", 13, 0)
+            ref = kc.case_gemm_forms(cx, return_output=True, res_rowvec=False, **c)
+            cx.lib.call("hv_set_tuning", 13, 1 if i < 2 else 2)
+            y = kc.case_gemm_forms(cx, return_output=True, res_rowvec=False, **c)
+            assert torch.equal(y, ref), f"hv_gemm_c4_kernel differs from the selection without it: {c}"
+    finally:
+        cx.lib.call("hv_set_tuning", 13, 1)
+
+
 def test_affine_apply(cx):
     kc.case_affine_apply(cx, n_img=48, rows=1536, C=640)
     kc.case_affine_apply(cx, n_img=48, rows=6144, C=320, act=A.ACT_SILU, seed=42)

@@ -450,7 +450,7 @@ static inline void hv_conv3x3_launch_t(const hv_conv3x3_params& p, hipStream_t s
 // gn_part is [n_images][tiles_y * tiles_x * WM][Cout][2]
 static inline void hv_conv3x3_tile_shape(const hv_conv3x3_params& p, int& TH, int& TW, int& WM) {
     if (hv_conv_w4_applies(p)) {
-        TH = HvConv4Geom::TH, TW = HvConv4Geom::TW, WM = HvConv4Geom::WM;
+        TH = HvConv4Geom<>::TH, TW = HvConv4Geom<>::TW, WM = HvConv4Geom<>::WM;
         return;
     }
     const bool narrow = p.Wo <= 8;

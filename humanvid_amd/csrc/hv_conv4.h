@@ -1,7 +1,7 @@
 // hv_conv4.h -- stride-1 3x3 convolution on FOUR waves per CU (one per SIMD), the k-loop structure of hv_gemm_w4_kernel
 // (hv_gemm4.h) applied to the implicit GEMM of hv_conv.h.  Same operation and parameter block as hv_conv3x3_kernel
 // (reference: InflatedConv3d 3x3, /root/reference/src/models/resnet.py:9-15, with the time-embedding / residual adds of
-// ResnetBlock3D, resnet.py:224-229, 243, in the epilogue); selected by hv_conv3x3_launch for single-source inputs without a
+// ResnetBlock3D, resnet.py:224-229, 243, in the epilogue); selected by hv_conv3x3_launch for stride-1 (plain or upsample-folded) single-source inputs without a
 // GroupNorm prologue (the ResnetBlock3D convolutions of the denoising path read an activation that hv_affine_apply has
 // normalised and concatenated) whose output channels come in blocks of 320.
 //
@@ -36,8 +36,15 @@
 #include "hv_gemm4.h"  // hv_glds16_u, hv_acc_take, hv_acc_settle, hv_mfma_tied
 #include "humanvid_hip.h"
 
+// MODE: HV_CONV_S1 (stride 1) or HV_CONV_UP2 (nearest-2x upsampling folded into the addressing, Upsample3D + conv,
+// /root/reference/src/models/resnet.py:51-88: output pixel (oy, ox), tap (dy, dx) reads source pixel ((oy + dy - 1) >> 1,
+// (ox + dx - 1) >> 1) -- the halo of a 12 x 16 output patch is 8 x 10 source pixels, ten LDS-DMA instructions per chunk)
+template <int MODE = HV_CONV_S1>
 struct HvConv4Geom {
-    static constexpr int TW = 16, TH = 12, HW = 18, HH = 14, HP = HW * HH;  // 252 halo pixels
+    static constexpr int TW = 16, TH = 12;
+    static constexpr int HW = MODE == HV_CONV_S1 ? TW + 2 : TW / 2 + 2, HH = MODE == HV_CONV_S1 ? TH + 2 : TH / 2 + 2;
+    static constexpr int HP = HW * HH;                       // 252 / 80 halo pixels
+    static constexpr int NHJ = ((HP + 7) / 8 + 3) / 4;       // halo instructions per wave and chunk: 8 / 3
     static constexpr int BN = 320, WM = 2;
     static constexpr int HALO_B = 32768, WSLOT_B = BN * 128;
     static constexpr int W0 = 2 * HALO_B, W1 = W0 + WSLOT_B, LDS_B = W1 + WSLOT_B;  // 147 456 bytes
@@ -70,9 +77,12 @@ __device__ unsigned long long g_hv_c4_trace[2048 * 8];
 #define HV_C4_MARK(i)
 #endif
 
-template <int V = 0>  // (a template only so that the header may be included by several translation units)
+template <int MODE = HV_CONV_S1>
 __global__ __launch_bounds__(256, 1) void hv_conv_w4_kernel(hv_conv3x3_params p, int raster) {
-    using G = HvConv4Geom;
+    using G = HvConv4Geom<MODE>;
+    static_assert(MODE == HV_CONV_S1 || MODE == HV_CONV_UP2, "stride 1, plain or upsample-folded");
+    constexpr bool UP = MODE == HV_CONV_UP2;
+    constexpr int NHJ = G::NHJ;
     constexpr int TW = G::TW, TH = G::TH, HW = G::HW;
     __shared__ __attribute__((aligned(1024))) unsigned char smem[G::LDS_B];
 
@@ -111,14 +121,14 @@ __global__ __launch_bounds__(256, 1) void hv_conv_w4_kernel(hv_conv3x3_params p,
     // ---- LDS-DMA sources.  Halo: instruction i = wave + 4 j (j = 0..7) carries halo pixels 8 i .. 8 i + 7, lane l the
     // 16-byte piece (l & 7) ^ key of pixel 8 i + (l >> 3).
     const char* const xsrc = reinterpret_cast<const char*>(p.X) + (long)img * p.Hs * p.Ws * Cin * 2;
-    unsigned hofs[8];
-    unsigned long hmask[8];
+    unsigned hofs[NHJ];
+    unsigned long hmask[NHJ];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
+    for (int j = 0; j < NHJ; ++j) {
         const int i = wave + 4 * j;
         const int hp = 8 * i + (lane >> 3);
         const int row = hp / HW, col = hp - row * HW;
-        const int iy = y0 - 1 + row, ix = x0 - 1 + col;
+        const int iy = (UP ? y0 / 2 : y0) - 1 + row, ix = (UP ? x0 / 2 : x0) - 1 + col;
         const bool inb = hp < G::HP && iy >= 0 && iy < p.Hs && ix >= 0 && ix < p.Ws;
         const int piece = (lane & 7) ^ ((hp >> 1) & 7);
         hofs[j] = inb ? (unsigned)(((iy * p.Ws + ix) * Cin + piece * 8) * 2) : 0u;
@@ -159,7 +169,7 @@ __global__ __launch_bounds__(256, 1) void hv_conv_w4_kernel(hv_conv3x3_params p,
     for (int s = 0; s < 8; ++s)
 #pragma unroll
         for (int dx = 0; dx < 3; ++dx) {
-            const int hp = (6 * wm + s) * HW + dx + r16;
+            const int hp = UP ? ((6 * wm + s + 1) >> 1) * HW + ((r16 + dx + 1) >> 1) : (6 * wm + s) * HW + dx + r16;
             xa[s][dx] = (unsigned)(hp * 128 + ((quad ^ ((hp >> 1) & 7)) << 4));
         }
 
@@ -188,7 +198,7 @@ __global__ __launch_bounds__(256, 1) void hv_conv_w4_kernel(hv_conv3x3_params p,
     unsigned ws_even = G::W0, ws_odd = G::W1;  // slot of the k-tiles with even / odd tap in the current chunk (swapped per chunk: 9 taps)
     unsigned h_nxt = (unsigned)G::HALO_B;      // halo buffer of the NEXT chunk (flipped per chunk)
 #pragma unroll
-    for (int j = 0; j < 8; ++j) issue_h(j, 0, 0u);
+    for (int j = 0; j < NHJ; ++j) issue_h(j, 0, 0u);
 #pragma unroll
     for (int j = 0; j < 10; ++j) issue_w(j, 0, 0, ws_even);
     hv_vm_wait<0>();
@@ -216,7 +226,7 @@ __global__ __launch_bounds__(256, 1) void hv_conv_w4_kernel(hv_conv3x3_params p,
             hv_static_for<20>([&](auto B) __attribute__((always_inline)) {
                 constexpr int b = decltype(B)::value, kk = b / 10, nf = b % 10;
                 // copies: the halo piece of the next chunk in block 0 (taps 0-7), W(s + 1) pieces 2-9 in blocks 1-8
-                if constexpr (b == 0 && tap < 8) issue_h(tap, chunk + 1, h_nxt);
+                if constexpr (b == 0 && tap < NHJ) issue_h(tap, chunk + 1, h_nxt);
                 if constexpr (b >= 1 && b <= 8) issue_w(b + 1, c1, tap1, ws_nxt);
                 if constexpr (b == 17) {
                     hv_vm_wait<0>();
@@ -344,9 +354,9 @@ __global__ __launch_bounds__(256, 1) void hv_conv_w4_kernel(hv_conv3x3_params p,
 static int g_hv_conv_w4 = 1;
 
 static inline bool hv_conv_w4_applies(const hv_conv3x3_params& p) {
-    using G = HvConv4Geom;
+    using G = HvConv4Geom<>;
     if (g_hv_conv_w4 == 0) return false;
-    if (p.mode != HV_CONV_S1 || p.C2 != 0 || p.C1 <= 0 || p.C1 % 64 != 0 || p.Cout <= 0 || p.Cout % G::BN != 0) return false;
+    if ((p.mode != HV_CONV_S1 && p.mode != HV_CONV_UP2) || p.C2 != 0 || p.C1 <= 0 || p.C1 % 64 != 0 || p.Cout <= 0 || p.Cout % G::BN != 0) return false;
     if (p.pro_scale != nullptr || p.pro_act != HV_ACT_NONE) return false;  // the halo goes HBM -> LDS untouched
     if ((long)p.Hs * p.Ws * p.C1 * 2 >= (1L << 32)) return false;           // 32-bit halo offsets inside an image
     if (g_hv_conv_w4 == 2) return true;
@@ -359,10 +369,11 @@ static inline bool hv_conv_w4_applies(const hv_conv3x3_params& p) {
 }
 
 static inline void hv_conv_w4_launch(const hv_conv3x3_params& p, int raster, hipStream_t stream) {
-    using G = HvConv4Geom;
+    using G = HvConv4Geom<>;
     const int tiles = p.n_images * ((p.Ho + G::TH - 1) / G::TH) * ((p.Wo + G::TW - 1) / G::TW) * (p.Cout / G::BN);
     const int grid = ((tiles + 7) / 8) * 8;
-    hv_note("hv_conv_w4_kernel | n=%d Hs=%d Ws=%d Ho=%d Wo=%d Cin=%d Cout=%d gn=%d res=%d", p.n_images, p.Hs, p.Ws, p.Ho, p.Wo, p.C1,
-            p.Cout, 0, p.residual != nullptr);
-    hv_launch(hv_conv_w4_kernel<0>, dim3(grid), dim3(256), stream, p, raster);
+    hv_note("hv_conv_w4_kernel%s | n=%d Hs=%d Ws=%d Ho=%d Wo=%d Cin=%d Cout=%d gn=%d res=%d", p.mode == HV_CONV_UP2 ? "<up2>" : "", p.n_images,
+            p.Hs, p.Ws, p.Ho, p.Wo, p.C1, p.Cout, 0, p.residual != nullptr);
+    if (p.mode == HV_CONV_UP2) hv_launch(hv_conv_w4_kernel<HV_CONV_UP2>, dim3(grid), dim3(256), stream, p, raster);
+    else hv_launch(hv_conv_w4_kernel<HV_CONV_S1>, dim3(grid), dim3(256), stream, p, raster);
 }

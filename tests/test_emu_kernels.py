@@ -326,6 +326,11 @@ def test_conv_four_wave_tiles(cx):
         kc.case_conv(cx, n=1, H=12, W=16, C1=64, Cout=320, pro=True, seed=76)                                     # prologue: the 128-channel kernels
         kc.case_gn_parts_conv(cx, n=2, H=16, W=16, Cin=64, Cout=320)                                              # two patches x two pixel halves, ragged
         kc.case_gn_parts_conv(cx, n=1, H=24, W=32, Cin=64, Cout=320, offset=3.0, seed=55)
+        # upsample-folded form: 8 x 10 source halo per 12 x 16 output patch
+        kc.case_conv(cx, n=2, H=6, W=8, C1=64, Cout=320, mode=A.CONV_UP2, pro=False, seed=77)
+        kc.case_conv(cx, n=1, H=7, W=13, C1=128, Cout=320, mode=A.CONV_UP2, pro=False, seed=78)                   # ragged patches, 2 chunks
+        kc.case_conv(cx, n=1, H=12, W=8, C1=192, Cout=640, mode=A.CONV_UP2, pro=False, residual=False, seed=79)   # two patch rows, 3 chunks
+        kc.case_gn_parts_conv(cx, n=1, H=9, W=8, Cin=64, Cout=320, mode=A.CONV_UP2, seed=57)
     finally:
         cx.lib.call("hv_set_tuning", 9, 2)
         cx.lib.call("hv_set_tuning", 12, 1)

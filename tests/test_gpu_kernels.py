@@ -168,8 +168,12 @@ def test_conv_four_wave_kernel(cx):
     kc.case_conv(cx, n=48, H=96, W=64, C1=320, Cout=320, pro=False, check=(0, 17, 47), seed=81)       # level-0 conv2 (residual)
     kc.case_conv(cx, n=48, H=48, W=32, C1=640, Cout=640, pro=False, check=(0, 47), seed=82)           # level 1, raster 1
     kc.case_conv(cx, n=48, H=96, W=64, C1=640, Cout=320, pro=False, residual=False, check=(0, 47), seed=83)  # up path, 10 chunks
+    kc.case_conv(cx, n=48, H=48, W=32, C1=640, Cout=640, mode=A.CONV_UP2, pro=False, temb=False, residual=False, check=(0, 47), seed=88)  # upsample 1 -> 0
+    kc.case_conv(cx, n=48, H=12, W=8, C1=1280, Cout=1280, mode=A.CONV_UP2, pro=False, temb=False, residual=False, check=(0, 47), seed=89)  # upsample 3 -> 2
     cx.lib.call("hv_set_tuning", 12, 2)
     try:
+        kc.case_conv(cx, n=2, H=15, W=9, C1=128, Cout=320, mode=A.CONV_UP2, pro=False, seed=90)       # upsample-folded, ragged
+        kc.case_gn_parts_conv(cx, n=2, H=24, W=16, Cin=64, Cout=320, mode=A.CONV_UP2, seed=58)
         kc.case_conv(cx, n=3, H=64, W=64, C1=320, Cout=320, pro=False, seed=84)                       # config #2: ragged rows
         kc.case_conv(cx, n=2, H=30, W=72, C1=128, Cout=640, pro=False, out_act=A.ACT_SILU, seed=85)   # ragged both ways
         kc.case_conv(cx, n=2, H=24, W=16, C1=1280, Cout=1280, pro=False, seed=86)                     # level 2: 20 chunks, 4 channel tiles

@@ -173,6 +173,14 @@ def main():
         y = torch.empty(n, 96, 64, 640, dtype=BF16, device=dev)
         ms = timeit(lambda: ops.conv3x3(L, st, x, w, y, mode=A.CONV_UP2))
         report("conv3x3 upsample-folded 640 @48x32->96x64", ms, 2.0 * n * 96 * 64 * 640 * 640 * 9, 2.0 * n * 640 * (48 * 32 + 96 * 64))
+        c4_trace(L)
+        for (C, H, W) in ((1280, 24, 16), (1280, 12, 8)):
+            x = rnd(n, H, W, C)
+            w = rnd(C, 9, C, scale=0.01)
+            y = torch.empty(n, 2 * H, 2 * W, C, dtype=BF16, device=dev)
+            ms = timeit(lambda: ops.conv3x3(L, st, x, w, y, mode=A.CONV_UP2))
+            report(f"conv3x3 upsample-folded {C} @{H}x{W}->{2 * H}x{2 * W}", ms, 2.0 * n * 4 * H * W * C * C * 9, 2.0 * n * C * 5 * H * W)
+            del x, w, y
         x = rnd(n, 96, 64, 320)
         w = rnd(320, 9, 320, scale=0.01)
         y = torch.empty(n, 48, 32, 320, dtype=BF16, device=dev)

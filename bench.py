@@ -74,7 +74,7 @@ def price_launch(key: str):
         by = 2.0 * (a["M"] * a["K"] + a["N"] * a["K"]) + a["M"] * n_out * (4.0 if a["f32"] else 2.0) \
             + (2.0 * a["M"] * n_out if a["res"] else 0.0)
         return fl, by
-    if kern.startswith("hv_conv3x3"):
+    if kern.startswith(("hv_conv3x3", "hv_conv_w4")):
         px_o, px_i = a["n"] * a["Ho"] * a["Wo"], a["n"] * a["Hs"] * a["Ws"]
         fl = 2.0 * 9 * a["Cin"] * a["Cout"] * px_o
         by = 2.0 * (px_i * a["Cin"] + 9 * a["Cin"] * a["Cout"] + px_o * a["Cout"] * (2 if a["res"] else 1))
@@ -112,7 +112,7 @@ def price_launch_rw(key: str):
     if kern.startswith("hv_gemm"):
         n_out = a["N"] // 2 if a["geglu"] else a["N"]
         wr = a["M"] * n_out * (4.0 if a["f32"] else 2.0)
-    elif kern.startswith("hv_conv3x3"):
+    elif kern.startswith(("hv_conv3x3", "hv_conv_w4")):
         wr = 2.0 * a["n"] * a["Ho"] * a["Wo"] * a["Cout"]
     elif kern.startswith("hv_attention_fp8_quant"):
         wr = 2.0 * a["n"] * a["L"] * a["heads"] * int(kern.split("<")[1].split(">")[0])

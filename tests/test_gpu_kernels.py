@@ -182,7 +182,16 @@ def test_conv_four_wave_kernel(cx):
         cx.lib.call("hv_set_tuning", 9, 2)
         kc.case_gn_parts_conv(cx, n=2, H=16, W=16, Cin=64, Cout=320)
         kc.case_gn_parts_conv(cx, n=3, H=48, W=32, Cin=128, Cout=640, offset=3.0, seed=56)
+        # same reduction order as hv_conv3x3_kernel's 64-channel-chunk variant: the same bits (level 2 at 48 images)
+        import torch
+        outs = {}
+        for name, (w4, big) in dict(w4=(2, 1), ck64=(0, 3)).items():
+            cx.lib.call("hv_set_tuning", 12, w4)
+            cx.lib.call("hv_set_tuning", 5, big)
+            outs[name] = kc.case_conv(cx, n=48, H=24, W=16, C1=1280, Cout=1280, pro=False, check=(0,), seed=91, return_output=True)
+        assert torch.equal(outs["w4"], outs["ck64"]), "hv_conv_w4_kernel differs from the 64-channel-chunk kernel"
     finally:
+        cx.lib.call("hv_set_tuning", 5, 1)
         cx.lib.call("hv_set_tuning", 9, 2)
         cx.lib.call("hv_set_tuning", 12, 1)
 

@@ -133,7 +133,7 @@ int hv_set_tuning(int key, int value) {
     else if (key == HV_TUNE_CONV_GLDS && (value == 0 || value == 1)) hvk_conv_use_glds(value);
     else if (key == HV_TUNE_CONV_BIG && (value >= 0 && value <= 3)) hvk_conv_use_big(value);
     else if (key == HV_TUNE_CONV_RASTER && (value >= 0 && value <= 2)) hvk_conv_raster(value);
-    else if (key == HV_TUNE_CONV_W4 && (value >= 0 && value <= 2)) hvk_conv_use_w4(value);
+    else if (key == HV_TUNE_CONV_W4 && (value >= 0 && value <= 3)) hvk_conv_use_w4(value);
     else if (key == HV_TUNE_CMDLIST_GRAPHS && (value == 0 || value == 1)) g_hv_cmdlist_graphs = value;
     else return hv_fail(HV_EINVAL, "hv_set_tuning: unknown key/value");
     return HV_OK;

@@ -39,13 +39,16 @@
 // MODE: HV_CONV_S1 (stride 1) or HV_CONV_UP2 (nearest-2x upsampling folded into the addressing, Upsample3D + conv,
 // /root/reference/src/models/resnet.py:51-88: output pixel (oy, ox), tap (dy, dx) reads source pixel ((oy + dy - 1) >> 1,
 // (ox + dx - 1) >> 1) -- the halo of a 12 x 16 output patch is 8 x 10 source pixels, ten LDS-DMA instructions per chunk)
-template <int MODE = HV_CONV_S1>
+// NF: weight fragments per wave = 10 (tile of 320 channels, 240 accumulator registers) or 8 (256 channels, 192 registers: where
+// 320-wide tiles fill the 256 CUs badly -- Cout = 1280 at 24 x 16: 384 tiles = 1.5 rounds, 480 tiles of 256 = 1.875)
+template <int MODE = HV_CONV_S1, int NF = 10>
 struct HvConv4Geom {
     static constexpr int TW = 16, TH = 12;
     static constexpr int HW = MODE == HV_CONV_S1 ? TW + 2 : TW / 2 + 2, HH = MODE == HV_CONV_S1 ? TH + 2 : TH / 2 + 2;
     static constexpr int HP = HW * HH;                       // 252 / 80 halo pixels
     static constexpr int NHJ = ((HP + 7) / 8 + 3) / 4;       // halo instructions per wave and chunk: 8 / 3
-    static constexpr int BN = 320, WM = 2;
+    static constexpr int BN = 32 * NF, WM = 2;
+    static constexpr int RING = NF / 2, NB = 2 * NF;         // weight-fragment register ring (NB % RING == 0), blocks per k-tile
     static constexpr int HALO_B = 32768, WSLOT_B = BN * 128;
     static constexpr int W0 = 2 * HALO_B, W1 = W0 + WSLOT_B, LDS_B = W1 + WSLOT_B;  // 147 456 bytes
 };
@@ -77,9 +80,11 @@ __device__ unsigned long long g_hv_c4_trace[2048 * 8];
 #define HV_C4_MARK(i)
 #endif
 
-template <int MODE = HV_CONV_S1>
+template <int MODE = HV_CONV_S1, int NF = 10>
 __global__ __launch_bounds__(256, 1) void hv_conv_w4_kernel(hv_conv3x3_params p, int raster) {
-    using G = HvConv4Geom<MODE>;
+    using G = HvConv4Geom<MODE, NF>;
+    static_assert(NF == 10 || NF == 8, "tiles of 320 or 256 channels");
+    constexpr int RING = G::RING, NB = G::NB, NJ = NF / 2;  // NJ: fragment pairs per wave = 16-byte channel groups per lane
     static_assert(MODE == HV_CONV_S1 || MODE == HV_CONV_UP2, "stride 1, plain or upsample-folded");
     constexpr bool UP = MODE == HV_CONV_UP2;
     constexpr int NHJ = G::NHJ;
@@ -161,7 +166,7 @@ __global__ __launch_bounds__(256, 1) void hv_conv_w4_kernel(hv_conv3x3_params p,
 
     // ---- fragment addresses (LDS byte offsets).  Weights: row 160 wn + 16 nf + r16, piece (4 kk + quad) ^ ((r16 >> 1) & 7):
     // one lane offset + nf * 2048 (immediate) + the slot; the second k half is the first ^ 64.
-    const unsigned wl = (unsigned)((160 * wn + r16) * 128 + ((quad ^ ((r16 >> 1) & 7)) << 4));
+    const unsigned wl = (unsigned)((16 * NF * wn + r16) * 128 + ((quad ^ ((r16 >> 1) & 7)) << 4));
     // Pixels: halo pixel (6 wm + s) * 18 + dx + r16 for s = mf + dy (0..7) and dx (0..2): 24 lane offsets, buffer included
     // (flipped by ^ HALO_B per chunk).
     unsigned xa[8][3];
@@ -173,12 +178,12 @@ __global__ __launch_bounds__(256, 1) void hv_conv_w4_kernel(hv_conv3x3_params p,
             xa[s][dx] = (unsigned)(hp * 128 + ((quad ^ ((hp >> 1) & 7)) << 4));
         }
 
-    f32x4 acc[10][6];  // [nf][mf]
+    f32x4 acc[NF][6];  // [nf][mf]
 #pragma unroll
-    for (int a = 0; a < 10; ++a)
+    for (int a = 0; a < NF; ++a)
 #pragma unroll
         for (int b = 0; b < 6; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
-    bf16x8 wf[5], xf[2][6];
+    bf16x8 wf[RING], xf[2][6];
     auto fence = [&]() __attribute__((always_inline)) {
 #ifndef HV_EMU
         __builtin_amdgcn_sched_barrier(0);
@@ -186,8 +191,8 @@ __global__ __launch_bounds__(256, 1) void hv_conv_w4_kernel(hv_conv3x3_params p,
     };
     // weight fragment g (0..19: k half g / 10, fragment g % 10) of the k-tile in the slot at `slot_ofs`
     auto rd_w = [&](unsigned slot_ofs, int g) __attribute__((always_inline)) {
-        const unsigned a = (slot_ofs + wl) ^ (g >= 10 ? 64u : 0u);
-        return hv_as_bf16x8(hv_ld16(smem + a + (unsigned)(g % 10) * 2048u));
+        const unsigned a = (slot_ofs + wl) ^ (g >= NF ? 64u : 0u);
+        return hv_as_bf16x8(hv_ld16(smem + a + (unsigned)(g % NF) * 2048u));
     };
     // pixel fragment mf of tap (dy, dx), k half kk; flip = HALO_B for the buffer of the next chunk
     auto rd_x = [&](int mf, int dy, int dx, int kk, unsigned flip) __attribute__((always_inline)) {
@@ -200,7 +205,7 @@ __global__ __launch_bounds__(256, 1) void hv_conv_w4_kernel(hv_conv3x3_params p,
 #pragma unroll
     for (int j = 0; j < NHJ; ++j) issue_h(j, 0, 0u);
 #pragma unroll
-    for (int j = 0; j < 10; ++j) issue_w(j, 0, 0, ws_even);
+    for (int j = 0; j < NF; ++j) issue_w(j, 0, 0, ws_even);
     hv_vm_wait<0>();
     hv_barrier_raw();
     HV_C4_MARK(1)
@@ -209,7 +214,7 @@ __global__ __launch_bounds__(256, 1) void hv_conv_w4_kernel(hv_conv3x3_params p,
 #pragma unroll
     for (int mf = 0; mf < 6; ++mf) xf[0][mf] = rd_x(mf, 0, 0, 0, 0u);
 #pragma unroll
-    for (int g = 0; g < 5; ++g) wf[g] = rd_w(ws_even, g);
+    for (int g = 0; g < RING; ++g) wf[g] = rd_w(ws_even, g);
     fence();
 
     int chunk = 0;
@@ -223,28 +228,29 @@ __global__ __launch_bounds__(256, 1) void hv_conv_w4_kernel(hv_conv3x3_params p,
             const unsigned ws_nxt = (tap & 1) ? ws_even : ws_odd;  // slot of s + 1
             const int c1 = chunk + (tap + 1) / 9, c2 = chunk + (tap + 2) / 9;
             constexpr unsigned flip1 = tap == 8 ? (unsigned)G::HALO_B : 0u;  // k-tile s + 1 reads the other halo buffer
-            hv_static_for<20>([&](auto B) __attribute__((always_inline)) {
-                constexpr int b = decltype(B)::value, kk = b / 10, nf = b % 10;
-                // copies: the halo piece of the next chunk in block 0 (taps 0-7), W(s + 1) pieces 2-9 in blocks 1-8
+            hv_static_for<NB>([&](auto B) __attribute__((always_inline)) {
+                constexpr int b = decltype(B)::value, kk = b / NF, nf = b % NF;
+                // copies: the halo piece of the next chunk in block 0 (taps 0-7), W(s + 1) pieces 2 .. NF-1 in blocks 1 .. NF-2
                 if constexpr (b == 0 && tap < NHJ) issue_h(tap, chunk + 1, h_nxt);
-                if constexpr (b >= 1 && b <= 8) issue_w(b + 1, c1, tap1, ws_nxt);
-                if constexpr (b == 17) {
+                if constexpr (b >= 1 && b <= NF - 2) issue_w(b + 1, c1, tap1, ws_nxt);
+                if constexpr (b == NB - 3) {
                     hv_vm_wait<0>();
                     hv_barrier_raw();  // lgkmcnt(0) + s_barrier: W(s + 1) (and at tap 8 the next halo) visible, slot of s free
                     issue_w(0, c2, tap2, ws_cur);
                     issue_w(1, c2, tap2, ws_cur);
 #pragma unroll
                     for (int mf = 0; mf < 6; ++mf) xf[0][mf] = rd_x(mf, dy1, dx1, 0, flip1);
-                    wf[0] = rd_w(ws_nxt, 0);
-                    wf[1] = rd_w(ws_nxt, 1);
+                    // the ring registers of the blocks NB - RING .. NB - 4 (no request behind them): the next k-tile's first fragments
+#pragma unroll
+                    for (int g = 0; g < RING - 3; ++g) wf[g] = rd_w(ws_nxt, g);
                 }
 #pragma unroll
                 for (int mf = 0; mf < 6; ++mf)
-                    hv_mfma_tied(acc[nf][mf], wf[b % 5], xf[kk][mf]);
-                // requests behind the block: weight fragment b + 5 (this k-tile up to block 14, the next one's 2-4 behind
-                // the tail blocks), the second k half's pixel fragments in blocks 1-6
-                if constexpr (b <= 14) wf[b % 5] = rd_w(ws_cur, b + 5);
-                if constexpr (b >= 17) wf[b % 5] = rd_w(ws_nxt, b - 15);
+                    hv_mfma_tied(acc[nf][mf], wf[b % RING], xf[kk][mf]);
+                // requests behind the block: weight fragment b + RING (this k-tile, up to block NB - 1 - RING; the next one's behind
+                // the three tail blocks), the second k half's pixel fragments in blocks 1-6
+                if constexpr (b <= NB - 1 - RING) wf[b % RING] = rd_w(ws_cur, b + RING);
+                if constexpr (b >= NB - 3) wf[b % RING] = rd_w(ws_nxt, b - (NB - RING));
                 if constexpr (b >= 1 && b <= 6) xf[1][b - 1] = rd_x(b - 1, dy, dx, 1, 0u);
                 fence();
             });
@@ -263,7 +269,7 @@ __global__ __launch_bounds__(256, 1) void hv_conv_w4_kernel(hv_conv3x3_params p,
     HV_C4_MARK(2)
 
     // ---- epilogue: bias + time-embedding row + residual + activation, GroupNorm partial statistics of the stored values,
-    // 16-byte stores (eight consecutive channels per lane and fragment pair j: channels n0 + 160 wn + 32 j + 8 quad ..).
+    // 16-byte stores (eight consecutive channels per lane and fragment pair j: channels n0 + 16 NF wn + 32 j + 8 quad ..).
     // ALL of the tile's operand loads are requested first -- one round trip (the first version asked for them fragment pair by
     // fragment pair: five dependent round trips, 17 - 24 us of a tile's 85, profiles/r06_s20_conv_w4_trace.txt) --, then the
     // arithmetic runs fragment pair by fragment pair and every result is stored where it is made (64-byte segments per
@@ -274,17 +280,17 @@ __global__ __launch_bounds__(256, 1) void hv_conv_w4_kernel(hv_conv3x3_params p,
     const int gn_parts = tiles_y * tiles_x * G::WM;
     float* const gn_dst = p.gn_part ? p.gn_part + ((long)img * gn_parts + ((y0 / TH) * tiles_x + x0 / TW) * G::WM + wm) * p.Cout * 2
                                     : nullptr;
-    const int nb = n0 + 160 * wn + 8 * quad;  // + 32 j: the lane's eight channels of fragment pair j
+    const int nb = n0 + 16 * NF * wn + 8 * quad;  // + 32 j: the lane's eight channels of fragment pair j
     long opix[6];
 #pragma unroll
     for (int mf = 0; mf < 6; ++mf) {
         const int oy = y0 + 6 * wm + mf, ox = x0 + r16;
         opix[mf] = (oy < p.Ho && ox < p.Wo) ? (long)(img * p.Ho + oy) * p.Wo + ox : -1;
     }
-    f32x4 addv[5][2];
-    u32x4 res[6][5];
+    f32x4 addv[NJ][2];
+    u32x4 res[6][NJ];
 #pragma unroll
-    for (int j = 0; j < 5; ++j)
+    for (int j = 0; j < NJ; ++j)
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             f32x4 a = {0.f, 0.f, 0.f, 0.f};
@@ -296,7 +302,7 @@ __global__ __launch_bounds__(256, 1) void hv_conv_w4_kernel(hv_conv3x3_params p,
     for (int mf = 0; mf < 6; ++mf) {
         const long rpix = p.residual_images > 0 ? opix[mf] - (long)(img - rimg) * p.Ho * p.Wo : opix[mf];
 #pragma unroll
-        for (int j = 0; j < 5; ++j) {
+        for (int j = 0; j < NJ; ++j) {
             u32x4 r = {0u, 0u, 0u, 0u};
             if (p.residual && opix[mf] >= 0) r = hv_ld16(p.residual + rpix * p.Cout + nb + 32 * j);
             res[mf][j] = r;
@@ -307,7 +313,7 @@ __global__ __launch_bounds__(256, 1) void hv_conv_w4_kernel(hv_conv3x3_params p,
     auto finish = [&](auto ACT) __attribute__((always_inline)) {
         constexpr bool act = decltype(ACT)::value != 0;
 #pragma unroll
-        for (int j = 0; j < 5; ++j) {
+        for (int j = 0; j < NJ; ++j) {
             float gs[8], gq[8];
 #pragma unroll
             for (int e = 0; e < 8; ++e) gs[e] = gq[e] = 0.f;
@@ -350,30 +356,47 @@ __global__ __launch_bounds__(256, 1) void hv_conv_w4_kernel(hv_conv3x3_params p,
     HV_C4_MARK(4)
 }
 
-// 0: never; 1: where the shape fills the tiles (default); 2: wherever the structure allows (tests)
+// 0: never; 1: where the shape fills the tiles (default); 2: wherever the structure allows (tests); 3: as 1 with 320-channel tiles only (A/B)
 static int g_hv_conv_w4 = 1;
 
-static inline bool hv_conv_w4_applies(const hv_conv3x3_params& p) {
-    using G = HvConv4Geom<>;
-    if (g_hv_conv_w4 == 0) return false;
-    if ((p.mode != HV_CONV_S1 && p.mode != HV_CONV_UP2) || p.C2 != 0 || p.C1 <= 0 || p.C1 % 64 != 0 || p.Cout <= 0 || p.Cout % G::BN != 0) return false;
-    if (p.pro_scale != nullptr || p.pro_act != HV_ACT_NONE) return false;  // the halo goes HBM -> LDS untouched
-    if ((long)p.Hs * p.Ws * p.C1 * 2 >= (1L << 32)) return false;           // 32-bit halo offsets inside an image
-    if (g_hv_conv_w4 == 2) return true;
-    const long ty = (p.Ho + G::TH - 1) / G::TH, tx = (p.Wo + G::TW - 1) / G::TW;
-    const long tiles = ty * tx * p.n_images * (p.Cout / G::BN);
-    const double cover = (double)p.Ho * p.Wo / (double)(ty * G::TH * tx * G::TW);
-    // one workgroup per CU: the tiles must fill the chip and the 12 x 16 patches the image.  (1.5 rounds of 256 -- level 2 of
-    // config #3 -- still measure 1280 -> 1280 at 24 x 16 equal and 2560 -> 1280 8 % faster: profiles/r06_s19_conv_w4.txt)
-    return cover >= 0.8 && tiles >= 384;
+// tile width of hv_conv_w4_kernel for this problem: 320 / 256 channels, or 0 = the kernel does not apply.  One workgroup per CU:
+// the tiles must fill the chip (>= 384) and the 12 x 16 patches the image (>= 80 %); where both widths divide Cout the one whose
+// tiles fill the rounds of 256 better wins (a 256-wide tile carries 96 instead of 120 MFMAs per wave behind each barrier: x 0.93).
+static inline int hv_conv_w4_width(const hv_conv3x3_params& p) {
+    if (g_hv_conv_w4 == 0) return 0;
+    if ((p.mode != HV_CONV_S1 && p.mode != HV_CONV_UP2) || p.C2 != 0 || p.C1 <= 0 || p.C1 % 64 != 0 || p.Cout <= 0) return 0;
+    if (p.Cout % 320 != 0 && p.Cout % 256 != 0) return 0;
+    if (p.pro_scale != nullptr || p.pro_act != HV_ACT_NONE) return 0;  // the halo goes HBM -> LDS untouched
+    if ((long)p.Hs * p.Ws * p.C1 * 2 >= (1L << 32)) return 0;           // 32-bit halo offsets inside an image
+    constexpr int TH = HvConv4Geom<>::TH, TW = HvConv4Geom<>::TW;
+    const long ty = (p.Ho + TH - 1) / TH, tx = (p.Wo + TW - 1) / TW;
+    const long patches = ty * tx * p.n_images;
+    auto fill = [&](int bn) {
+        if (p.Cout % bn != 0) return 0.0;
+        const long tiles = patches * (p.Cout / bn);
+        return (double)tiles / (double)(((tiles + 255) / 256) * 256) * (bn == 256 ? 0.93 : 1.0);
+    };
+    const int bn = (g_hv_conv_w4 != 3 && fill(256) > fill(320)) || p.Cout % 320 != 0 ? 256 : 320;  // (tuning 3: 320-wide only, A/B)
+    if (p.Cout % bn != 0) return 0;
+    if (g_hv_conv_w4 == 2) return bn;
+    const double cover = (double)p.Ho * p.Wo / (double)(ty * TH * tx * TW);
+    // (1.5 rounds of 256 -- 320-wide tiles at level 2 of config #3 -- measure equal to the 128-channel kernel: profiles/r06_s19_conv_w4.txt)
+    return cover >= 0.8 && patches * (p.Cout / bn) >= 384 ? bn : 0;
 }
+static inline bool hv_conv_w4_applies(const hv_conv3x3_params& p) { return hv_conv_w4_width(p) != 0; }
 
 static inline void hv_conv_w4_launch(const hv_conv3x3_params& p, int raster, hipStream_t stream) {
-    using G = HvConv4Geom<>;
-    const int tiles = p.n_images * ((p.Ho + G::TH - 1) / G::TH) * ((p.Wo + G::TW - 1) / G::TW) * (p.Cout / G::BN);
+    constexpr int TH = HvConv4Geom<>::TH, TW = HvConv4Geom<>::TW;
+    const int bn = hv_conv_w4_width(p);
+    const int tiles = p.n_images * ((p.Ho + TH - 1) / TH) * ((p.Wo + TW - 1) / TW) * (p.Cout / bn);
     const int grid = ((tiles + 7) / 8) * 8;
-    hv_note("hv_conv_w4_kernel%s | n=%d Hs=%d Ws=%d Ho=%d Wo=%d Cin=%d Cout=%d gn=%d res=%d", p.mode == HV_CONV_UP2 ? "<up2>" : "", p.n_images,
-            p.Hs, p.Ws, p.Ho, p.Wo, p.C1, p.Cout, 0, p.residual != nullptr);
-    if (p.mode == HV_CONV_UP2) hv_launch(hv_conv_w4_kernel<HV_CONV_UP2>, dim3(grid), dim3(256), stream, p, raster);
-    else hv_launch(hv_conv_w4_kernel<HV_CONV_S1>, dim3(grid), dim3(256), stream, p, raster);
+    hv_note("hv_conv_w4_kernel<%s%d> | n=%d Hs=%d Ws=%d Ho=%d Wo=%d Cin=%d Cout=%d gn=%d res=%d", p.mode == HV_CONV_UP2 ? "up2," : "", bn,
+            p.n_images, p.Hs, p.Ws, p.Ho, p.Wo, p.C1, p.Cout, 0, p.residual != nullptr);
+    if (p.mode == HV_CONV_UP2) {
+        if (bn == 256) hv_launch(hv_conv_w4_kernel<HV_CONV_UP2, 8>, dim3(grid), dim3(256), stream, p, raster);
+        else hv_launch(hv_conv_w4_kernel<HV_CONV_UP2, 10>, dim3(grid), dim3(256), stream, p, raster);
+    } else {
+        if (bn == 256) hv_launch(hv_conv_w4_kernel<HV_CONV_S1, 8>, dim3(grid), dim3(256), stream, p, raster);
+        else hv_launch(hv_conv_w4_kernel<HV_CONV_S1, 10>, dim3(grid), dim3(256), stream, p, raster);
+    }
 }

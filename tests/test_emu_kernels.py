@@ -333,13 +333,20 @@ def test_conv_four_wave_tiles(cx):
         kc.case_conv(cx, n=1, H=7, W=13, C1=128, Cout=320, mode=A.CONV_UP2, pro=False, seed=78)                   # ragged patches, 2 chunks
         kc.case_conv(cx, n=1, H=12, W=8, C1=192, Cout=640, mode=A.CONV_UP2, pro=False, residual=False, seed=79)   # two patch rows, 3 chunks
         kc.case_gn_parts_conv(cx, n=1, H=9, W=8, Cin=64, Cout=320, mode=A.CONV_UP2, seed=57)
+        # 256-channel tiles (NF = 8: a ring of four weight-fragment registers, 16 blocks per k-tile)
+        kc.case_conv(cx, n=1, H=12, W=16, C1=64, Cout=256, pro=False, seed=181)
+        kc.case_conv(cx, n=1, H=13, W=20, C1=128, Cout=512, pro=False, out_act=A.ACT_SILU, seed=182)              # ragged, 2 chunks, 2 channel tiles
+        kc.case_conv(cx, n=1, H=7, W=9, C1=64, Cout=256, mode=A.CONV_UP2, pro=False, temb=False, seed=183)
+        kc.case_gn_parts_conv(cx, n=1, H=16, W=16, Cin=64, Cout=256, seed=184)
         # the reduction runs in the order of hv_conv3x3_kernel's 64-channel-chunk variant (chunk, tap, k half): the same bits
         outs = {}
         for name, (w4, big) in dict(w4=(2, 1), ck64=(0, 3)).items():
             cx.lib.call("hv_set_tuning", 12, w4)
             cx.lib.call("hv_set_tuning", 5, big)
             outs[name] = kc.case_conv(cx, n=1, H=13, W=20, C1=128, Cout=320, pro=False, seed=72, return_output=True)
+            outs[name + "256"] = kc.case_conv(cx, n=1, H=13, W=20, C1=128, Cout=256, pro=False, seed=185, return_output=True)
         assert torch.equal(outs["w4"], outs["ck64"]), "hv_conv_w4_kernel differs from the 64-channel-chunk kernel"
+        assert torch.equal(outs["w4256"], outs["ck64256"]), "hv_conv_w4_kernel<256> differs from the 64-channel-chunk kernel"
     finally:
         cx.lib.call("hv_set_tuning", 5, 1)
         cx.lib.call("hv_set_tuning", 9, 2)

@@ -107,9 +107,11 @@ def test_native_loop_steps_match_the_reference_at_full_size(pipe_and_chan, case)
 # modules driven by the statements of its loop body, 2.5 h of host time once -- oracle/gen_fullsize_steps_golden.py traj30).
 # Unlike the per-step cases above the native path is NOT re-synchronised to the reference: every step starts from its own
 # latents, so the bound is a drift bound -- bf16 storage noise of 1.5e-2 per guided prediction, fed back 30 times through a
-# random-weight network.  TRAJ_BOUNDS: step -> bound on the latents' nrmse (2 x what MI355X measured when the fixture was made:
-# profiles/r06_traj30.txt); the final latents must also keep the reference's scale (rms within 2 %).
-TRAJ_BOUNDS = {0: 2e-3, 4: 1e-2, 9: 2e-2, 14: 3e-2, 19: 4e-2, 24: 5e-2, 29: 6e-2}
+# random-weight network.  TRAJ_BOUNDS: step -> bound on the latents' nrmse, 2 x what MI355X measured when the fixture was made
+# (profiles/r06_traj30.txt: 3.3e-4 after step 0, 2.6e-3 after 10, 6.0e-3 after 20, 7.3e-3 at the end -- the drift grows more
+# slowly than the per-step noise would if it accumulated coherently); the latents must also keep the reference's scale (the
+# reference's rms grows 1.00 -> 2.57 over the trajectory; within 1 %: measured 0.05 %).
+TRAJ_BOUNDS = {0: 1e-3, 4: 2.5e-3, 9: 5e-3, 14: 9e-3, 19: 1.2e-2, 24: 1.4e-2, 29: 1.5e-2}
 
 
 def test_thirty_step_trajectory_matches_the_reference_at_full_size(pipe_and_chan):
@@ -135,4 +137,4 @@ def test_thirty_step_trajectory_matches_the_reference_at_full_size(pipe_and_chan
         e = nrmse(x, want)
         rms, rms_ref = float(x.pow(2).mean().sqrt()), float(z[f"latent_rms{i}"])
         print(f"[traj30] step {i} t={t}: latents nrmse {e:.4e}  rms {rms:.4f} (reference {rms_ref:.4f})")
-        assert e < TRAJ_BOUNDS[i] and abs(rms / rms_ref - 1) < 2e-2, (i, e, rms, rms_ref)
+        assert e < TRAJ_BOUNDS[i] and abs(rms / rms_ref - 1) < 1e-2, (i, e, rms, rms_ref)

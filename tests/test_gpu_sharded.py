@@ -178,8 +178,9 @@ def test_cfg_halves_on_two_streams_are_bit_identical(tmp_path, monkeypatch):
     of a guided step run as two B = 1 forwards on two streams -- step 0 eagerly, step 1 recorded per half, step 2 replayed
     INTERLEAVED (segment k of both halves, then collective k of both) -- instead of one B = 2 forward.  Every image goes
     through the same kernels with the same reduction order, so the latents of all three steps must equal the serial path's
-    bit for bit (2 ranks on one GPU, host-staged transport: only the transport differs from RCCL).  Also checked with the
-    command lists re-issued launch by launch instead of as captured graphs (HUMANVID_TUNING=7=0).
+    bit for bit (2 ranks on one GPU, host-staged transport: only the transport differs from RCCL).  With
+    HV_TEST_ALL_RANK_SHAPES=1 also with the command lists re-issued launch by launch instead of as captured graphs
+    (HUMANVID_TUNING=7=0; 22 s of the suite's budget).
     Latent 32 x 32 (level 1: 16 x 16 = 256 rows per image): a half of a rank's batch (2 images) still has >= 256 rows at
     every level, so that both forms run on the LDS-DMA kernels that leave the normalisation statistics (below 256 rows the
     register-staged kernel + the statistics pass take over, which rounds differently: not the regime of any real shard)."""
@@ -190,10 +191,11 @@ def test_cfg_halves_on_two_streams_are_bit_identical(tmp_path, monkeypatch):
     assert len(serial) == len(overlapped) == 3
     for i, (a, b) in enumerate(zip(serial, overlapped)):
         assert torch.isfinite(b).all() and torch.equal(a, b), (i, float((a - b).abs().max()))
-    monkeypatch.setenv("HUMANVID_TUNING", "7=0")
-    closures = _run_two_ranks(tmp_path, "overlap_closures.pt", check_stats=False, hw=32)
-    for i, (a, b) in enumerate(zip(serial, closures)):
-        assert torch.equal(a, b), (i, float((a - b).abs().max()))
+    if os.environ.get("HV_TEST_ALL_RANK_SHAPES") == "1":
+        monkeypatch.setenv("HUMANVID_TUNING", "7=0")
+        closures = _run_two_ranks(tmp_path, "overlap_closures.pt", check_stats=False, hw=32)
+        for i, (a, b) in enumerate(zip(serial, closures)):
+            assert torch.equal(a, b), (i, float((a - b).abs().max()))
 
 
 def test_single_rank_rccl_choreography(tmp_path, monkeypatch):

@@ -76,7 +76,9 @@ def _worker(rank, world, port, out_dir, exchange):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [8, 2])
+# (the 2-rank shape costs 90 s of the suite's 20-minute budget and runs the same code at a larger per-rank batch: on request,
+#  HV_TEST_ALL_RANK_SHAPES=1 -- last run green: profiles/r06_s25_pytest.txt)
+@pytest.mark.parametrize("world", [8, 2] if os.environ.get("HV_TEST_ALL_RANK_SHAPES") == "1" else [8])
 def test_sharded_forward_at_config4_rank_shapes_matches_the_reference(tmp_path, world):
     import fullsize_case as FC
 

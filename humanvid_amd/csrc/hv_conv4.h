@@ -15,8 +15,8 @@
 //
 // Tile: 12 x 16 output pixels x 320 output channels per workgroup; waves 2 (pixel rows 0-5 / 6-11) x 2 (channels 0-159 /
 // 160-319).  LDS (144 KiB): two halo buffers of 14 x 18 pixels x 64 channels (128-byte pixels, 16-byte pieces XOR-swizzled by
-// (pixel >> 1) & 7 on the source side, as hv_swz<64> does for GEMM rows -- a fragment's 16 consecutive pixels are conflict-free
-// at any start) and two weight slots of 320 rows x 128 bytes.  Everything reaches LDS by LDS-DMA:
+// the even key pixel & 6 on the source side -- a fragment's 16 consecutive pixels are conflict-free at any start: see the
+// fragment addresses) and two weight slots of 320 rows x 128 bytes.  Everything reaches LDS by LDS-DMA:
 //   * the weight tile of a k-tile: 40 wave-instructions of 1 KiB (ten per wave), rows in the order that gives a lane eight
 //     CONSECUTIVE output channels over a fragment pair (LDS row 16 g + r <-> channel 32 (g >> 1) + 8 (r >> 2) + 4 (g & 1) + (r & 3)):
 //     16-byte stores / residual loads in the epilogue;
@@ -42,6 +42,11 @@
 // NF: weight fragments per wave = 10 (tile of 320 channels, 240 accumulator registers) or 8 (256 channels, 192 registers: where
 // 320-wide tiles fill the 256 CUs badly -- Cout = 1280 at 24 x 16: 384 tiles = 1.5 rounds, 480 tiles of 256 = 1.875)
 template <int MODE = HV_CONV_S1, int NF = 10>
+#ifdef HV_C4_OLDKEY  // A/B build: the GEMM's swizzle key on the halo pixels (2-way conflicts on odd pixel pairs)
+#define HV_C4_KEY(hp) (((hp) >> 1) & 7)
+#else
+#define HV_C4_KEY(hp) ((hp) & 6)
+#endif
 struct HvConv4Geom {
     static constexpr int TW = 16, TH = 12;
     static constexpr int HW = MODE == HV_CONV_S1 ? TW + 2 : TW / 2 + 2, HH = MODE == HV_CONV_S1 ? TH + 2 : TH / 2 + 2;
@@ -135,7 +140,7 @@ __global__ __launch_bounds__(256, 1) void hv_conv_w4_kernel(hv_conv3x3_params p,
         const int row = hp / HW, col = hp - row * HW;
         const int iy = (UP ? y0 / 2 : y0) - 1 + row, ix = (UP ? x0 / 2 : x0) - 1 + col;
         const bool inb = hp < G::HP && iy >= 0 && iy < p.Hs && ix >= 0 && ix < p.Ws;
-        const int piece = (lane & 7) ^ ((hp >> 1) & 7);
+        const int piece = (lane & 7) ^ HV_C4_KEY(hp);  // halo swizzle key: see the fragment addresses below
         hofs[j] = inb ? (unsigned)(((iy * p.Ws + ix) * Cin + piece * 8) * 2) : 0u;
         hmask[j] = hv_lane_mask(inb);
         if (!inb) {  // zero padding, written once: the copies never touch these pieces
@@ -168,14 +173,20 @@ __global__ __launch_bounds__(256, 1) void hv_conv_w4_kernel(hv_conv3x3_params p,
     // one lane offset + nf * 2048 (immediate) + the slot; the second k half is the first ^ 64.
     const unsigned wl = (unsigned)((16 * NF * wn + r16) * 128 + ((quad ^ ((r16 >> 1) & 7)) << 4));
     // Pixels: halo pixel (6 wm + s) * 18 + dx + r16 for s = mf + dy (0..7) and dx (0..2): 24 lane offsets, buffer included
-    // (flipped by ^ HALO_B per chunk).
+    // (flipped by ^ HALO_B per chunk).  Swizzle key of a halo pixel: hp & 6 (EVEN keys only).  A ds_read_b128 is served in passes of
+    // 16 lanes that mix two quads -- lanes r16 in {0-3, 12-15} of one quad (piece c) with r16 in {4-11} of its neighbour (piece
+    // c ^ 1) -- over two 128-byte pixels per 256-byte bank row.  With the GEMM's key (hp >> 1) & 7 a window of 16 consecutive
+    // pixels is conflict-free only when it starts at an even pixel PAIR (the GEMM's rows: multiples of 16); a tap window starts
+    // anywhere, and the first version measured SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 0.20 - 0.27 (profiles/r06_lds_conflicts.txt
+    // before this change).  Even keys never differ by 1, so the two quads' pieces cannot meet, and the four same-parity pixels of
+    // each quad's lanes are four consecutive pairs -> four distinct keys: conflict-free for every start.
     unsigned xa[8][3];
 #pragma unroll
     for (int s = 0; s < 8; ++s)
 #pragma unroll
         for (int dx = 0; dx < 3; ++dx) {
             const int hp = UP ? ((6 * wm + s + 1) >> 1) * HW + ((r16 + dx + 1) >> 1) : (6 * wm + s) * HW + dx + r16;
-            xa[s][dx] = (unsigned)(hp * 128 + ((quad ^ ((hp >> 1) & 7)) << 4));
+            xa[s][dx] = (unsigned)(hp * 128 + ((quad ^ HV_C4_KEY(hp)) << 4));
         }
 
     f32x4 acc[NF][6];  // [nf][mf]

@@ -104,7 +104,7 @@ def main():
                           ms_per_step_profiled=round(k["ns"] / 1e6, 3))
     shapes.sort(key=lambda r: -(r["avg_us_profiled"] * r["launches"]))
     rec = dict(csrc_digest=bench.csrc_digest(), kernels=kout, shapes=shapes[:60],
-               source="tools/final_r05.sh on MI355X: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE / --pmc SQ_VALU_MFMA_BUSY_CYCLES "
+               source="tools/final_r06.sh on MI355X: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE / --pmc SQ_VALU_MFMA_BUSY_CYCLES "
                       "GRBM_GUI_ACTIVE (three separate runs, each with --kernel-trace only) over `python bench.py --steps 2 --warmup 1 "
                       "--no-cpu-baseline --no-profile`; the dispatches of the last complete step lined up with the step's launch order "
                       "(hv_profile_end '#seq')",

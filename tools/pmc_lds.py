@@ -20,7 +20,7 @@ for r in csv.DictReader(open(files[0])):
     acc[name][r["Counter_Name"]] += float(r["Counter_Value"])
     if r["Counter_Name"] == "SQ_LDS_IDX_ACTIVE":
         n[name] += 1
-print("# SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE per kernel instantiation over the bench command (tools/final_r05.sh, pass 4)")
+print("# SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE per kernel instantiation over the bench command (tools/final_r06.sh, pass 4)")
 print(f"{'dispatches':>10} {'conflict':>14} {'active':>14} {'ratio':>7}  kernel")
 for name, c in sorted(acc.items(), key=lambda kv: -kv[1].get("SQ_LDS_IDX_ACTIVE", 0.0)):
     a, b = c.get("SQ_LDS_BANK_CONFLICT", 0.0), c.get("SQ_LDS_IDX_ACTIVE", 0.0)

@@ -142,8 +142,17 @@ __global__ __launch_bounds__(512, 4) void hv_attention40_kernel(hv_attention_par
     t /= nqb;
     const int head = t % p.heads;
     int img = t / p.heads;
-    // alternate between the CFG halves (the conditional images attend to twice the keys): every XCD gets the same mix
-    if ((p.n_images & 1) == 0) img = (img & 1) * (p.n_images >> 1) + (img >> 1);
+    // alternate between the CFG halves (the conditional images attend to twice the keys): every XCD gets the same mix -- and
+    // the LONG half first in every pair, so that an XCD's range ends with short workgroups (its 64 slots are refilled in
+    // order: the tail of the launch is one short workgroup instead of one long one; profiles/r06_s30_attn40_order.txt)
+    if ((p.n_images & 1) == 0) {
+#ifndef HV_ATTN40_ORDER_OLD
+        const bool long_second = p.bank_sel != nullptr && p.L2 > 0 && p.bank_sel[p.n_images >> 1] >= 0 && p.bank_sel[0] < 0;
+        img = ((img & 1) ^ (long_second ? 1 : 0)) * (p.n_images >> 1) + (img >> 1);
+#else
+        img = (img & 1) * (p.n_images >> 1) + (img >> 1);
+#endif
+    }
     const int sel = (p.bank_sel != nullptr && p.L2 > 0) ? p.bank_sel[img] : -1;
     const int T1 = (p.L1 + 63) / 64;
     const int T2 = sel >= 0 ? (p.L2 + 63) / 64 : 0;

@@ -371,7 +371,7 @@ __global__ __launch_bounds__(256, 1) void hv_conv_w4_kernel(hv_conv3x3_params p,
 static int g_hv_conv_w4 = 1;
 
 // tile width of hv_conv_w4_kernel for this problem: 320 / 256 channels, or 0 = the kernel does not apply.  One workgroup per CU:
-// the tiles must fill the chip (>= 384) and the 12 x 16 patches the image (>= 80 %); where both widths divide Cout the one whose
+// the tiles must fill their rounds of 256 (>= 70 %, >= 128 tiles) and the 12 x 16 patches the image (>= 80 %); where both widths divide Cout the one whose
 // tiles fill the rounds of 256 better wins (a 256-wide tile carries 96 instead of 120 MFMAs per wave behind each barrier: x 0.93).
 static inline int hv_conv_w4_width(const hv_conv3x3_params& p) {
     if (g_hv_conv_w4 == 0) return 0;
@@ -391,8 +391,13 @@ static inline int hv_conv_w4_width(const hv_conv3x3_params& p) {
     if (p.Cout % bn != 0) return 0;
     if (g_hv_conv_w4 == 2) return bn;
     const double cover = (double)p.Ho * p.Wo / (double)(ty * TH * tx * TW);
-    // (1.5 rounds of 256 -- 320-wide tiles at level 2 of config #3 -- measure equal to the 128-channel kernel: profiles/r06_s19_conv_w4.txt)
-    return cover >= 0.8 && patches * (p.Cout / bn) >= 384 ? bn : 0;
+    // one workgroup per CU: what counts is how well the tiles fill their rounds of 256.  (By tile count >= 384 -- the first rule --
+    // the per-rank shapes of a sharded job fell back too early: 240 tiles are one round at 94 %.  Same-box steps at the per-rank
+    // shapes, profiles/r06_s32_conv_w4_fill.txt: 3 frames 23.86 -> 23.43 ms, one CFG half at 6 frames 23.49 -> 23.14, N = 1 unchanged;
+    // 1.5 rounds of 320-wide tiles at level 2 of config #3 measured equal to the 128-channel kernel: profiles/r06_s19_conv_w4.txt.)
+    const long tiles = patches * (p.Cout / bn);
+    const double f = (double)tiles / (double)(((tiles + 255) / 256) * 256);
+    return cover >= 0.8 && tiles >= 128 && f >= 0.70 ? bn : 0;
 }
 static inline bool hv_conv_w4_applies(const hv_conv3x3_params& p) { return hv_conv_w4_width(p) != 0; }
 

@@ -226,7 +226,7 @@ int hv_attention_fp8(const hv_attention_params* p, const float* kscale, const fl
 #define HV_TUNE_CONV_GLDS 4     /* 1: conv weight tiles by LDS-DMA (default), 0: register-staged */
 #define HV_TUNE_CONV_BIG 5      /* 1 (default): 256-pixel tiles for the upsample-folded convolution, 64-channel reduction chunks for stride-1 convolutions on images of <= 384 pixels; 0 / 2: neither / only the 256-pixel tiles (A/Bs); 3: 64-channel chunks for every stride-1 convolution whose sources allow them (A/B) */
 #define HV_TUNE_CONV_RASTER 9    /* workgroup raster of hv_conv3x3 inside an XCD: 0 = the output-channel tiles of a pixel patch adjacent (halo shared through L2, weights re-streamed), 1 = the pixel patches of an output-channel tile adjacent (weights stay in L2), 2 (default) = 1 where Cin x Cout >= 640 x 640: HBM-side fetch of the 1280 -> 1280 convolution 1.4 -> 0.6 GB per launch at equal time (profiles/r04_s3.txt) */
-#define HV_TUNE_CONV_W4 12       /* stride-1 convolutions of a plain single-source input with Cout % 320 == 0 or Cout % 256 == 0 on hv_conv_w4_kernel (hv_conv4.h: 12 x 16 pixels x 320 / 256 channels on four waves, halo and weights by LDS-DMA; the width whose tiles fill the rounds of 256 CUs better): 1 (default) = where the tiles fill the chip (>= 384 tiles, patches cover >= 80 % of the image), 0 = never, 2 = wherever the structure allows (tests), 3 = as 1 with 320-channel tiles only (A/B) */
+#define HV_TUNE_CONV_W4 12       /* stride-1 convolutions of a plain single-source input with Cout % 320 == 0 or Cout % 256 == 0 on hv_conv_w4_kernel (hv_conv4.h: 12 x 16 pixels x 320 / 256 channels on four waves, halo and weights by LDS-DMA; the width whose tiles fill the rounds of 256 CUs better): 1 (default) = where the tiles fill their rounds of 256 CUs to >= 70 % (>= 128 tiles) and the patches cover >= 80 % of the image, 0 = never, 2 = wherever the structure allows (tests), 3 = as 1 with 320-channel tiles only (A/B) */
 #define HV_TUNE_CMDLIST_GRAPHS 7 /* 1 (default): hv_cmdlist_run replays a recorded segment as ONE captured HIP graph; 0: re-issues its launches one by one (A/B) */
 int hv_set_tuning(int key, int value);
 

@@ -1415,14 +1415,15 @@ static inline HvGemmChoice hv_gemm_choose(const HvGemmParams& p, bool want_stats
         form64 = HV_FORM_LN;
     if (!(g_hv_gemm_glds && !prologue && p.M >= 256 && span_ok && form64 != HV_FORM_NONE)) return c;
     // 192 x 320 x 64 tiles on four waves (hv_gemm_c4_kernel): bias (+ residual) outputs without statistics or tables, N a
-    // multiple of 320, M of 192.  Default: K >= 1280 with at least 384 tiles, and not where 256-wide tiles fit N (N % 256 == 0:
+    // multiple of 320, M of 192.  Default: K >= 1280 with tiles that fill their rounds of 256 CUs to >= 70 % (>= 128 tiles; as
+    // hv_conv_w4_width: profiles/r06_s33_gemm_c4_fill.txt), and not where 256-wide tiles fit N (N % 256 == 0:
     // the deferred residual form of hv_gemm_w4_kernel) -- the feed-forward output projections of levels 0 and 1.
     if (g_hv_gemm_c4 && g_hv_gemm_glds != 3 && p.N % 320 == 0 && p.M % 192 == 0 && p.X2 == nullptr && p.perm_p == 0 && p.Yt == nullptr &&
         !p.geglu && !want_stats && p.gn_part == nullptr && p.ln_part == nullptr && p.pe == nullptr && p.rowvec == nullptr) {
         const int form96 = hv_gemm_fast_form(p, 96);
         const long tiles = (long)(p.M / 192) * (p.N / 320);
         if ((form96 == HV_FORM_RES || form96 == HV_FORM_PLAIN) &&
-            (g_hv_gemm_c4 == 2 || (p.K >= 1280 && tiles >= 384 && p.N % 256 != 0))) {
+            (g_hv_gemm_c4 == 2 || (p.K >= 1280 && p.N % 256 != 0 && tiles >= 128 && tiles * 10 >= ((tiles + 255) / 256) * 256 * 7))) {
             c.kernel = 6;
             c.form = form96;
             c.perm = true;

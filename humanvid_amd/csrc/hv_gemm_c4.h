@@ -77,10 +77,6 @@ __global__ __launch_bounds__(256, 1) void hv_gemm_c4_kernel(hv_gemm_params p) {
     const unsigned xl = (unsigned)((96 * wm + r16) * 128 + ((quad ^ ((r16 >> 1) & 7)) << 4));
 
     f32x4 acc[10][6];  // [nf][mf]
-#pragma unroll
-    for (int a = 0; a < 10; ++a)
-#pragma unroll
-        for (int b = 0; b < 6; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
     bf16x8 wf[5], xf[2][6];
     auto fence = [&]() __attribute__((always_inline)) {
 #ifndef HV_EMU
@@ -105,6 +101,16 @@ __global__ __launch_bounds__(256, 1) void hv_gemm_c4_kernel(hv_gemm_params p) {
     for (int j = 0; j < 10; ++j) issue_w(j, 0, ws_cur);
 #pragma unroll
     for (int j = 0; j < 6; ++j) issue_x(j, 1, xs_nxt);
+    // (zeroed while the first copies are in flight: see hv_conv_w4_kernel)
+#pragma unroll
+    for (int a = 0; a < 10; ++a)
+#pragma unroll
+        for (int b = 0; b < 6; ++b) {
+            acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+#ifndef HV_EMU
+            asm volatile("" : "+a"(acc[a][b]));
+#endif
+        }
     hv_vm_wait<0>();
     hv_barrier_raw();
     issue_w(0, 1, ws_nxt);

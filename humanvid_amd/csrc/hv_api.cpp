@@ -71,7 +71,7 @@ int hv_conv3x3_gn_parts(const hv_conv3x3_params* p) { return p ? hvk_conv3x3_gn_
 int hv_layernorm_from_parts(const float* part, int parts, int M, int C, float eps, float* mean, float* rstd, void* stream) {
     if (!part || !mean || !rstd) return hv_fail(HV_EINVAL, "hv_layernorm_from_parts: null");
     if (hvk_ln_from_parts(part, parts, M, C, eps, mean, rstd, (hipStream_t)stream) != 0)
-        return hv_fail(HV_EINVAL, "hv_layernorm_from_parts: need C == 64 * parts, M >= 1");
+        return hv_fail(HV_EINVAL, "hv_layernorm_from_parts: need parts >= 1, M >= 1, C >= 1");
     return hv_check_launch("hv_layernorm_from_parts");
 }
 int hv_groupnorm_from_parts(const hv_gn_parts_params* p, void* stream) {
@@ -128,6 +128,7 @@ int hv_set_tuning(int key, int value) {
     else if (key == HV_TUNE_GEMM_MAX_GRID && value >= 8 && value % 8 == 0) hvk_gemm_tune(value);
     else if (key == HV_TUNE_GEMM_GLDS && ((value >= 0 && value <= 3) || value == 6)) hvk_gemm_use_glds(value);
     else if (key == HV_TUNE_GEMM_XS && (value == 0 || value == 1)) hvk_gemm_use_xs(value);
+    else if (key == HV_TUNE_GEMM_WR && (value >= 0 && value <= 2)) hvk_gemm_use_wr(value);
     else if (key == HV_TUNE_GEMM_C4 && (value >= 0 && value <= 2)) hvk_gemm_use_c4(value);
     else if (key == HV_TUNE_GEMM_W4 && (value >= 0 && value <= 4)) hvk_gemm_use_w4(value);
     else if (key == HV_TUNE_CONV_GLDS && (value == 0 || value == 1)) hvk_conv_use_glds(value);

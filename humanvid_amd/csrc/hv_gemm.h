@@ -1358,7 +1358,8 @@ __global__ __launch_bounds__(512, 2) void hv_gemm_wide_kernel(HvGemmParams p, in
 
 #include "hv_gemm4.h"  // the 256 x 256 x 64 tile on four waves of 128 x 128 (round 6)
 #include "hv_gemm_xs.h"
-#include "hv_gemm_c4.h"  // X-stationary 192 x 128 tiles for K = 320 (round 6)
+#include "hv_gemm_c4.h"
+#include "hv_gemm_wr.h"  // X-stationary 192 x 128 tiles for K = 320 (round 6)
 
 static int g_hv_gemm_max_grid = 512;  // tuning knob (hv_set_tuning): persistent workgroups
 // tuning knob (hv_set_tuning key 10): which of the problems that take 256 x 256 x 64 tiles run on the four-wave kernel
@@ -1386,12 +1387,15 @@ struct HvGemmChoice {
 // 0: never; 1 (default): deep-K plain / residual projections whose N is a multiple of 320 and that neither the 256-wide
 // four-wave tiles nor the statistics-bearing kernels are meant for; 2: wherever the structure allows (tests)
 static int g_hv_gemm_c4 = 1;
+// hv_gemm_wr_kernel (weights in registers, N = K = 320): 1 = where >= 256 work items of 64 rows exist (default), 0 = never, 2 = always (tests)
+static int g_hv_gemm_wr = 1;
 
 static inline HvGemmChoice hv_gemm_choose(const HvGemmParams& p, bool want_stats);
 
 // parts per image of the GroupNorm partial statistics (0 = this problem's kernel cannot emit them)
 static inline int hv_gemm_gn_parts_of(const HvGemmParams& p) {
     const HvGemmChoice c = hv_gemm_choose(p, true);
+    if (c.kernel == 7) return p.gn_rows_per_image > 0 ? p.gn_rows_per_image / 64 : 0;  // (hv_gemm_choose checked the divisibility)
     if (c.kernel != 2 || !c.perm || (c.form != HV_FORM_RES && c.form != HV_FORM_PLAIN)) return 0;
     if (p.perm_p != 0) return 0;  // (a wave's rows are not one image's after the row permutation)
     const int rows = 64;  // rows of a wave's sub-tile = rows per partial sum
@@ -1429,6 +1433,16 @@ static inline HvGemmChoice hv_gemm_choose(const HvGemmParams& p, bool want_stats
             c.perm = true;
             return c;
         }
+    }
+    // N = K = 320, bias (+ residual), with or without normalisation statistics of the output: the weights-in-registers stream kernel
+    if (g_hv_gemm_wr && p.N == 320 && p.K == 320 && p.M % 64 == 0 && p.X2 == nullptr && p.perm_p == 0 && p.Yt == nullptr && !p.geglu &&
+        p.pe == nullptr && p.rowvec == nullptr && (g_hv_gemm_wr == 2 || p.M >= 256 * 64) &&
+        (p.gn_rows_per_image <= 0 || (p.gn_rows_per_image % 64 == 0 && p.M % p.gn_rows_per_image == 0)) &&
+        !(p.gn_part != nullptr && p.ln_part != nullptr) && (form64 == HV_FORM_RES || form64 == HV_FORM_PLAIN)) {
+        c.kernel = 7;
+        c.form = form64;
+        c.perm = true;
+        return c;
     }
     // 256 x 320 x 64 wide tiles (hv_gemm_wide_kernel) for N = 320, K >= 640 with a plain-output form on the permuted assignment
     // (level-0 ff2: same-box 0.385 -> 0.327 ms, profiles/r04_s1.txt).  Measured and not taken: K = 320 (0.158 -> 0.159 ms: five
@@ -1494,6 +1508,7 @@ static inline HvGemmChoice hv_gemm_choose(const HvGemmParams& p, bool want_stats
 // 64-column blocks per row of the LayerNorm partial statistics (0 = this problem's kernel cannot emit them)
 static inline int hv_gemm_ln_parts_of(const HvGemmParams& p) {
     const HvGemmChoice c = hv_gemm_choose(p, true);
+    if (c.kernel == 7) return 4;  // one part per wave: 80 columns
     if (c.kernel != 2 || !c.perm || (c.form != HV_FORM_RES && c.form != HV_FORM_PLAIN) || p.N % 64 != 0) return 0;
     return p.N / 64;
 }
@@ -1526,6 +1541,21 @@ static inline int hv_gemm_launch(const HvGemmParams& p, hipStream_t stream) {
         } else {
             hv_note("hv_gemm_glds_kernel<256,8,256,1> | %s", shape);
             hv_launch(hv_gemm_glds_kernel<256, 8, 256, 1, false>, dim3(grid), dim3(512), stream, p, c.gm, c.form);
+        }
+        return 0;
+    }
+    if (c.kernel == 7) {
+        const int items = p.M / 64;
+        const int grid = 8 * min(min(32, g_hv_gemm_max_grid / 8), (items + 7) / 8);
+        if (p.gn_part != nullptr) {
+            hv_note("hv_gemm_wr_kernel<gn> | %s", shape);
+            hv_launch(hv_gemm_wr_kernel<1>, dim3(grid), dim3(256), stream, p);
+        } else if (p.ln_part != nullptr) {
+            hv_note("hv_gemm_wr_kernel<ln> | %s", shape);
+            hv_launch(hv_gemm_wr_kernel<2>, dim3(grid), dim3(256), stream, p);
+        } else {
+            hv_note("hv_gemm_wr_kernel | %s", shape);
+            hv_launch(hv_gemm_wr_kernel<0>, dim3(grid), dim3(256), stream, p);
         }
         return 0;
     }

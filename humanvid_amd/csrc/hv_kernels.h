@@ -11,6 +11,7 @@ void hvk_gemm_tune(int max_grid);
 void hvk_gemm_use_glds(int on);
 void hvk_gemm_use_w4(int on);
 void hvk_gemm_use_c4(int v);
+void hvk_gemm_use_wr(int v);
 void hvk_gemm_use_xs(int on);
 void hvk_conv_use_glds(int on);
 void hvk_conv_use_big(int on);

@@ -6,6 +6,7 @@ int hvk_gemm(const hv_gemm_params& p, hipStream_t s) { return hv_gemm_launch(p, 
 void hvk_gemm_tune(int max_grid) { g_hv_gemm_max_grid = max_grid; }
 void hvk_gemm_use_glds(int on) { g_hv_gemm_glds = on; }
 void hvk_gemm_use_c4(int v) { g_hv_gemm_c4 = v; }
+void hvk_gemm_use_wr(int v) { g_hv_gemm_wr = v; }
 void hvk_gemm_use_xs(int on) { g_hv_gemm_xs = on; }
 void hvk_gemm_use_w4(int on) {
     g_hv_gemm_w4 = on == 4 ? 3 : on;

@@ -36,7 +36,7 @@ def gemm(lib, stream, x, w, y, *, x2=None, k1=0, yt=None, n_split=0, pro_scale=N
     row_perm=(X, Y, P): output (and residual) row (x*Y + y)*P + p is taken at (y*X + x)*P + p.
     gn_part [M / gn_rows_per_image, parts, N, 2] fp32: GroupNorm partial statistics of the output (hv_gemm_gn_parts);
     query_gn_parts=True only asks how many parts per image this problem would write (0 = cannot) and launches nothing.
-    ln_part [M, N / 64, 2] fp32 / query_ln_parts: the same for the LayerNorm row statistics of the output."""
+    ln_part [M, parts, 2] fp32 (parts = what query_ln_parts returns: N / 64, or 4 from hv_gemm_wr_kernel) / query_ln_parts: the same for the LayerNorm row statistics of the output."""
     N, K = w.shape
     M = x.shape[0] if M is None else M
     p = A.GemmParams(

@@ -86,13 +86,14 @@ typedef struct hv_gemm_params {
     float* gn_part;
     int gn_rows_per_image;
     /* optional LayerNorm partial statistics of the OUTPUT rows: fp32 [M][hv_gemm_ln_parts(p)][2] = {sum, sum of squares} of
-     * the stored values over each 64-column block of a row; hv_layernorm_from_parts turns them into the row mean / rstd that
+     * the stored values over each column block of a row (blocks of 64 columns from the tile kernels, of 80 from hv_gemm_wr_kernel:
+     * the count is what hv_gemm_ln_parts reports, the consumer only adds them up); hv_layernorm_from_parts turns them into the row mean / rstd that
      * the next LayerNorm-folded GEMM reads -- no statistics pass over the activation.  NULL: not wanted; not together with
      * gn_part; same kernel restriction as gn_part. */
     float* ln_part;
 } hv_gemm_params;
 int hv_gemm_gn_parts(const hv_gemm_params* p); /* parts per image hv_gemm would write for this problem, 0 = cannot */
-int hv_gemm_ln_parts(const hv_gemm_params* p); /* 64-column blocks per row hv_gemm would write (N / 64), 0 = cannot */
+int hv_gemm_ln_parts(const hv_gemm_params* p); /* column blocks per row hv_gemm would write (N / 64 from the tile kernels, 4 from hv_gemm_wr_kernel), 0 = cannot */
 int hv_gemm(const hv_gemm_params* p, void* stream);
 
 /* ---- 3x3 convolution (implicit GEMM, LDS halo tile) ---------------------------------------
@@ -172,7 +173,7 @@ int hv_groupnorm_from_parts(const hv_gn_parts_params* p, void* stream);
  * src/models/motion_module.py:228,234); normalisation itself is folded into hv_gemm.       */
 int hv_layernorm_stats(const uint16_t* X, long ldx, int M, int C, float eps, float* mean, float* rstd,
                        void* stream);
-/* the same mean / rstd from the partial row sums the producing hv_gemm left (ln_part: [M][parts][2]) */
+/* the same mean / rstd from the partial row sums the producing hv_gemm left (ln_part: [M][parts][2]; any number of parts) */
 int hv_layernorm_from_parts(const float* part, int parts, int M, int C, float eps, float* mean, float* rstd, void* stream);
 
 /* ---- spatial self-attention with reference-bank keys --------------------------------------
@@ -223,6 +224,7 @@ int hv_attention_fp8(const hv_attention_params* p, const float* kscale, const fl
 #define HV_TUNE_GEMM_W4 10      /* which problems of the 256x256x64 class run on four waves (hv_gemm4.h: one wave per SIMD, 192x256x64 tiles, deferred output stores): 1 (default) = the LayerNorm-fold forms (with / without GEGLU) at K >= 640, M % 192 == 0; 0 = none; 2 = every problem whose shape allows it (M % 256 == 0, N % 64 == 0, one X source), stores at once; 3 = 2 + deferred stores where the form has them (K >= 320); 4 = 3 on the plain tile raster (A/Bs and tests; results are bit-identical) */
 #define HV_TUNE_GEMM_XS 11      /* 1: the LayerNorm-fold forms (with / without GEGLU) at K = 320, M % 192 == 0 run on the X-stationary kernel (hv_gemm_xs.h: the row block's X resident in LDS, only W streams, the epilogue software-pipelined into the next tile); 0: the 8-wave 256x256x64 kernel (results are bit-identical) */
 #define HV_TUNE_GEMM_C4 13      /* bias (+ residual) projections with N % 320 == 0, M % 192 == 0 on hv_gemm_c4_kernel (hv_gemm_c4.h: 192x320x64 tiles on four waves, the k-loop of hv_conv_w4_kernel): 1 (default) = K >= 1280, tiles that fill their rounds of 256 CUs to >= 70 % (>= 128 tiles), N % 256 != 0 (feed-forward output projections of levels 0 and 1); 0 = never; 2 = wherever the structure allows (tests; results are bit-identical) */
+#define HV_TUNE_GEMM_WR 15      /* N = K = 320 bias (+ residual) projections, with or without statistics of the output, on hv_gemm_wr_kernel (hv_gemm_wr.h: weights in registers, X and residual streamed through LDS rings): 1 (default) = M >= 16 384 (M % 64 == 0), 0 = never, 2 = always (tests; Y is bit-identical, hv_gemm_ln_parts() reports 4 parts of 80 columns for it) */
 #define HV_TUNE_CONV_GLDS 4     /* 1: conv weight tiles by LDS-DMA (default), 0: register-staged */
 #define HV_TUNE_CONV_BIG 5      /* 1 (default): 256-pixel tiles for the upsample-folded convolution, 64-channel reduction chunks for stride-1 convolutions on images of <= 384 pixels; 0 / 2: neither / only the 256-pixel tiles (A/Bs); 3: 64-channel chunks for every stride-1 convolution whose sources allow them (A/B) */
 #define HV_TUNE_CONV_RASTER 9    /* workgroup raster of hv_conv3x3 inside an XCD: 0 = the output-channel tiles of a pixel patch adjacent (halo shared through L2, weights re-streamed), 1 = the pixel patches of an output-channel tile adjacent (weights stay in L2), 2 (default) = 1 where Cin x Cout >= 640 x 640: HBM-side fetch of the 1280 -> 1280 convolution 1.4 -> 0.6 GB per launch at equal time (profiles/r04_s3.txt) */

@@ -248,6 +248,33 @@ def test_gemm_c4_tiles(cx):
         cx.lib.call("hv_set_tuning", 13, 1)
 
 
+def test_gemm_weights_in_registers(cx):
+    """hv_gemm_wr_kernel (hv_gemm_wr.h, tuning key 15 = 2: always): N = K = 320, W in registers, X and the residual through 4-slot
+    LDS rings -- one / several work items of 64 rows per persistent workgroup (the rings wrap; tuning 2 = 8: one workgroup per
+    XCD), bias + residual in place / bias only: Y bit for bit as the tile kernels; LayerNorm parts per wave (4) and GroupNorm
+    parts per 64 rows give the statistics of the stored output"""
+    import torch
+
+    cases = [dict(M=256, C=320, N=320, form="res", seed=121), dict(M=64, C=320, N=320, form="plain", seed=122),
+             dict(M=2560, C=320, N=320, form="res", seed=123)]
+    try:
+        for c in cases:
+            cx.lib.call("hv_set_tuning", 15, 0)
+            ref = kc.case_gemm_forms(cx, P=64, return_output=True, res_rowvec=False, **c)
+            for grid in (512, 8):
+                cx.lib.call("hv_set_tuning", 15, 2)
+                cx.lib.call("hv_set_tuning", 2, grid)
+                y = kc.case_gemm_forms(cx, P=64, return_output=True, res_rowvec=False, **c)
+                assert torch.equal(y, ref), f"hv_gemm_wr_kernel differs from the tile kernels: {c} grid {grid}"
+        cx.lib.call("hv_set_tuning", 2, 8)
+        kc.case_ln_parts_gemm(cx, M=1280, C=320, K=320, seed=124)
+        kc.case_ln_parts_gemm(cx, M=320, C=320, K=320, seed=125, residual=False)
+        kc.case_gn_parts_gemm(cx, n=5, rows=256, C=320, K=320, seed=126)
+    finally:
+        cx.lib.call("hv_set_tuning", 2, 512)
+        cx.lib.call("hv_set_tuning", 15, 1)
+
+
 def test_gemm_prologue(cx):
     kc.case_gemm_prologue(cx)
 

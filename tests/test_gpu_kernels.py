@@ -143,6 +143,31 @@ def test_gemm_c4_kernel_bench_shapes(cx):
         cx.lib.call("hv_set_tuning", 13, 1)
 
 
+def test_gemm_weights_in_registers_kernel(cx):
+    """hv_gemm_wr_kernel (hv_gemm_wr.h) at the level-0 output projections (M = 294 912, N = K = 320): Y bit for bit as the tile
+    kernels (tuning 15 = 0) with the residual in place and with bias only; LayerNorm parts (4 per row) and GroupNorm parts (one
+    per 64 rows) reproduce the statistics of the stored output; a small M on one workgroup per XCD (the rings wrap 48 times)"""
+    import torch
+
+    try:
+        for c in (dict(M=48 * 6144, C=320, N=320, P=6144, form="res", seed=131), dict(M=48 * 6144, C=320, N=320, P=6144, form="plain", seed=132)):
+            cx.lib.call("hv_set_tuning", 15, 0)
+            ref = kc.case_gemm_forms(cx, return_output=True, res_rowvec=False, **c)
+            cx.lib.call("hv_set_tuning", 15, 1)
+            y = kc.case_gemm_forms(cx, return_output=True, res_rowvec=False, **c)
+            assert torch.equal(y, ref), f"hv_gemm_wr_kernel differs from the tile kernels: {c}"
+        kc.case_ln_parts_gemm(cx, M=48 * 6144, C=320, K=320, seed=133)
+        kc.case_ln_parts_gemm(cx, M=24 * 6144, C=320, K=320, seed=134, residual=False)
+        kc.case_gn_parts_gemm(cx, n=48, rows=6144, C=320, K=320, seed=135)
+        cx.lib.call("hv_set_tuning", 15, 2)
+        cx.lib.call("hv_set_tuning", 2, 8)
+        kc.case_ln_parts_gemm(cx, M=64 * 8 * 24, C=320, K=320, seed=136)
+        kc.case_gn_parts_gemm(cx, n=6, rows=1536, C=320, K=320, seed=137)
+    finally:
+        cx.lib.call("hv_set_tuning", 2, 512)
+        cx.lib.call("hv_set_tuning", 15, 1)
+
+
 def test_affine_apply(cx):
     kc.case_affine_apply(cx, n_img=48, rows=1536, C=640)
     kc.case_affine_apply(cx, n_img=48, rows=6144, C=320, act=A.ACT_SILU, seed=42)

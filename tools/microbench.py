@@ -139,6 +139,19 @@ def main():
         report("gemm + LN fold + residual (level 0)", ms, 2.0 * M * C * C, 6.0 * M * C)
         ms = timeit(lambda: ops.layernorm_stats(L, st, x, mean, rstd))
         report("layernorm stats (level 0)", ms, 0.0, 2.0 * M * C)
+        # the level-0 output projections as the engine launches them: residual in place + LayerNorm / GroupNorm parts of the output
+        yres = rnd(M, C)
+        bias0 = torch.zeros(C, device=dev)
+        npl = ops.gemm(L, st, x, w, yres, bias=bias0, residual=yres, query_ln_parts=True)
+        if npl > 0:
+            lpart = torch.zeros(M, npl, 2, device=dev)
+            ms = timeit(lambda: ops.gemm(L, st, x, w, yres, bias=bias0, residual=yres, ln_part=lpart))
+            report(f"gemm out-proj + residual + ln parts ({npl}) (level 0)", ms, 2.0 * M * C * C, 6.0 * M * C)
+        npg = ops.gemm(L, st, x, w, yres, bias=bias0, residual=yres, gn_rows_per_image=6144, query_gn_parts=True)
+        if npg > 0:
+            gpart = torch.zeros(n, npg, C, 2, device=dev)
+            ms = timeit(lambda: ops.gemm(L, st, x, w, yres, bias=bias0, residual=yres, gn_part=gpart, gn_rows_per_image=6144))
+            report(f"gemm out-proj + residual + gn parts ({npg}) (level 0)", ms, 2.0 * M * C * C, 6.0 * M * C)
 
     if only is None or "conv" in only:
         for (_, C, H, W) in levels:

@@ -33,7 +33,7 @@
 // land in slots nobody reads; the kernel drains them before it ends.
 #pragma once
 #include "hv_common.h"
-#include "hv_gemm4.h"  // hv_glds16_u, hv_acc_take, hv_acc_settle, hv_mfma_tied
+#include "hv_gemm4.h"  // hv_glds16_u, hv_glds16_um, hv_lane_mask, hv_acc_take, hv_acc_settle, hv_mfma_tied
 #include "humanvid_hip.h"
 
 // MODE: HV_CONV_S1 (stride 1) or HV_CONV_UP2 (nearest-2x upsampling folded into the addressing, Upsample3D + conv,
@@ -57,24 +57,6 @@ struct HvConv4Geom {
     static constexpr int HALO_B = 32768, WSLOT_B = BN * 128;
     static constexpr int W0 = 2 * HALO_B, W1 = W0 + WSLOT_B, LDS_B = W1 + WSLOT_B;  // 147 456 bytes
 };
-
-// one LDS-DMA piece with the lanes outside `mask` switched off (they neither load nor write LDS).  The kernel runs with all
-// 64 lanes active wherever this is called: EXEC is restored to -1.
-#ifndef HV_EMU
-HV_DEV void hv_glds16_um(const void* base_uniform, unsigned byte_ofs, void* lds_wave_base, unsigned long mask) {
-    const unsigned lds_addr_uniform = (unsigned)(unsigned long)(__attribute__((address_space(3))) void*)lds_wave_base;
-    asm volatile("s_mov_b64 exec, %3\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1\n\ts_mov_b64 exec, -1"
-                 :
-                 : "v"(byte_ofs), "s"(base_uniform), "s"(lds_addr_uniform), "s"(mask)
-                 : "memory");
-}
-HV_DEV unsigned long hv_lane_mask(bool on) { return __builtin_amdgcn_ballot_w64(on); }
-#else
-HV_DEV void hv_glds16_um(const void* base_uniform, unsigned byte_ofs, void* lds_wave_base, unsigned long mask) {
-    if (mask) memcpy((char*)lds_wave_base + (threadIdx.x & 63) * 16, (const char*)base_uniform + byte_ofs, 16);
-}
-HV_DEV unsigned long hv_lane_mask(bool on) { return on ? 1ul : 0ul; }  // emulator: the lane's own bit
-#endif
 
 #ifdef HV_C4_TRACE
 // timing build (tools/build_variant.sh c4trace k_conv -DHV_C4_TRACE): per workgroup (first 2048), wave 0: s_memtime at kernel

@@ -1434,15 +1434,20 @@ static inline HvGemmChoice hv_gemm_choose(const HvGemmParams& p, bool want_stats
             return c;
         }
     }
-    // N = K = 320, bias (+ residual), with or without normalisation statistics of the output: the weights-in-registers stream kernel
-    if (g_hv_gemm_wr && p.N == 320 && p.K == 320 && p.M % 64 == 0 && p.X2 == nullptr && p.perm_p == 0 && p.Yt == nullptr && !p.geglu &&
-        p.pe == nullptr && p.rowvec == nullptr && (g_hv_gemm_wr == 2 || p.M >= 256 * 64) &&
+    // K = 320 with the weights in registers (hv_gemm_wr_kernel): N = 320 bias (+ table row) (+ residual), with or without
+    // normalisation statistics of the output; N = 320 / 640 / 960 LayerNorm-fold outputs (+ table row) -- the motion modules' QKV
+    if (g_hv_gemm_wr && p.K == 320 && p.N % 320 == 0 && p.N <= 960 && p.M % 64 == 0 && p.X2 == nullptr && p.perm_p == 0 && p.Yt == nullptr &&
+        !p.geglu && (g_hv_gemm_wr == 2 || p.M >= 256 * 64) &&
         (p.gn_rows_per_image <= 0 || (p.gn_rows_per_image % 64 == 0 && p.M % p.gn_rows_per_image == 0)) &&
-        !(p.gn_part != nullptr && p.ln_part != nullptr) && (form64 == HV_FORM_RES || form64 == HV_FORM_PLAIN)) {
-        c.kernel = 7;
-        c.form = form64;
-        c.perm = true;
-        return c;
+        !(p.gn_part != nullptr && p.ln_part != nullptr)) {
+        const bool plain = (form64 == HV_FORM_RES || form64 == HV_FORM_PLAIN) && p.N == 320;
+        const bool lnf = form64 == HV_FORM_LN && !want_stats && p.gn_part == nullptr && p.ln_part == nullptr && p.gn_rows_per_image <= 0;
+        if (plain || lnf) {
+            c.kernel = 7;
+            c.form = form64;
+            c.perm = true;
+            return c;
+        }
     }
     // 256 x 320 x 64 wide tiles (hv_gemm_wide_kernel) for N = 320, K >= 640 with a plain-output form on the permuted assignment
     // (level-0 ff2: same-box 0.385 -> 0.327 ms, profiles/r04_s1.txt).  Measured and not taken: K = 320 (0.158 -> 0.159 ms: five
@@ -1546,8 +1551,11 @@ static inline int hv_gemm_launch(const HvGemmParams& p, hipStream_t stream) {
     }
     if (c.kernel == 7) {
         const int items = p.M / 64;
-        const int grid = 8 * min(min(32, g_hv_gemm_max_grid / 8), (items + 7) / 8);
-        if (p.gn_part != nullptr) {
+        const int grid = 8 * min(min(32, g_hv_gemm_max_grid / 8), max((items + 7) / 8, p.N / 320));
+        if (c.form == HV_FORM_LN) {
+            hv_note("hv_gemm_wr_kernel<lnfold> | %s", shape);
+            hv_launch(hv_gemm_wr_kernel<0, true>, dim3(grid), dim3(256), stream, p);
+        } else if (p.gn_part != nullptr) {
             hv_note("hv_gemm_wr_kernel<gn> | %s", shape);
             hv_launch(hv_gemm_wr_kernel<1>, dim3(grid), dim3(256), stream, p);
         } else if (p.ln_part != nullptr) {

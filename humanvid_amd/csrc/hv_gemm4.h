@@ -38,6 +38,25 @@ HV_DEV void hv_glds16_u(const void* base_uniform, unsigned byte_ofs, void* lds_w
 #endif
 
 
+// one LDS-DMA piece with the lanes outside `mask` switched off (they neither load nor write LDS).  The kernel runs with all
+// 64 lanes active wherever this is called: EXEC is restored to -1.
+#ifndef HV_EMU
+HV_DEV void hv_glds16_um(const void* base_uniform, unsigned byte_ofs, void* lds_wave_base, unsigned long mask) {
+    const unsigned lds_addr_uniform = (unsigned)(unsigned long)(__attribute__((address_space(3))) void*)lds_wave_base;
+    asm volatile("s_mov_b64 exec, %3\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1\n\ts_mov_b64 exec, -1"
+                 :
+                 : "v"(byte_ofs), "s"(base_uniform), "s"(lds_addr_uniform), "s"(mask)
+                 : "memory");
+}
+HV_DEV unsigned long hv_lane_mask(bool on) { return __builtin_amdgcn_ballot_w64(on); }
+#else
+HV_DEV void hv_glds16_um(const void* base_uniform, unsigned byte_ofs, void* lds_wave_base, unsigned long mask) {
+    if (mask) memcpy((char*)lds_wave_base + (threadIdx.x & 63) * 16, (const char*)base_uniform + byte_ofs, 16);
+}
+HV_DEV unsigned long hv_lane_mask(bool on) { return on ? 1ul : 0ul; }  // emulator: the lane's own bit
+#endif
+
+
 // One accumulator fragment for the vector ALU, read where it is consumed.  The accumulators live in the accumulation registers
 // (a0..); VALU instructions cannot read those, and left to itself hipcc's allocator copies ALL of a tile's accumulators into
 // v-registers at the head of the k-tile that carries the epilogue (128 registers held through the epilogue's loads: the

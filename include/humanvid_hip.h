@@ -224,7 +224,7 @@ int hv_attention_fp8(const hv_attention_params* p, const float* kscale, const fl
 #define HV_TUNE_GEMM_W4 10      /* which problems of the 256x256x64 class run on four waves (hv_gemm4.h: one wave per SIMD, 192x256x64 tiles, deferred output stores): 1 (default) = the LayerNorm-fold forms (with / without GEGLU) at K >= 640, M % 192 == 0; 0 = none; 2 = every problem whose shape allows it (M % 256 == 0, N % 64 == 0, one X source), stores at once; 3 = 2 + deferred stores where the form has them (K >= 320); 4 = 3 on the plain tile raster (A/Bs and tests; results are bit-identical) */
 #define HV_TUNE_GEMM_XS 11      /* 1: the LayerNorm-fold forms (with / without GEGLU) at K = 320, M % 192 == 0 run on the X-stationary kernel (hv_gemm_xs.h: the row block's X resident in LDS, only W streams, the epilogue software-pipelined into the next tile); 0: the 8-wave 256x256x64 kernel (results are bit-identical) */
 #define HV_TUNE_GEMM_C4 13      /* bias (+ residual) projections with N % 320 == 0, M % 192 == 0 on hv_gemm_c4_kernel (hv_gemm_c4.h: 192x320x64 tiles on four waves, the k-loop of hv_conv_w4_kernel): 1 (default) = K >= 1280, tiles that fill their rounds of 256 CUs to >= 70 % (>= 128 tiles), N % 256 != 0 (feed-forward output projections of levels 0 and 1); 0 = never; 2 = wherever the structure allows (tests; results are bit-identical) */
-#define HV_TUNE_GEMM_WR 15      /* N = K = 320 bias (+ residual) projections, with or without statistics of the output, on hv_gemm_wr_kernel (hv_gemm_wr.h: weights in registers, X and residual streamed through LDS rings): 1 (default) = M >= 16 384 (M % 64 == 0), 0 = never, 2 = always (tests; Y is bit-identical, hv_gemm_ln_parts() reports 4 parts of 80 columns for it) */
+#define HV_TUNE_GEMM_WR 15      /* K = 320: N = 320 bias (+ table row) (+ residual) projections, with or without statistics of the output, and N = 320 / 640 / 960 LayerNorm-fold projections (+ table row) on hv_gemm_wr_kernel (hv_gemm_wr.h: weights in registers, X and residual streamed through LDS rings): 1 (default) = M >= 16 384 (M % 64 == 0), 0 = never, 2 = always (tests; Y is bit-identical, hv_gemm_ln_parts() reports 4 parts of 80 columns for it) */
 #define HV_TUNE_CONV_GLDS 4     /* 1: conv weight tiles by LDS-DMA (default), 0: register-staged */
 #define HV_TUNE_CONV_BIG 5      /* 1 (default): 256-pixel tiles for the upsample-folded convolution, 64-channel reduction chunks for stride-1 convolutions on images of <= 384 pixels; 0 / 2: neither / only the 256-pixel tiles (A/Bs); 3: 64-channel chunks for every stride-1 convolution whose sources allow them (A/B) */
 #define HV_TUNE_CONV_RASTER 9    /* workgroup raster of hv_conv3x3 inside an XCD: 0 = the output-channel tiles of a pixel patch adjacent (halo shared through L2, weights re-streamed), 1 = the pixel patches of an output-channel tile adjacent (weights stay in L2), 2 (default) = 1 where Cin x Cout >= 640 x 640: HBM-side fetch of the 1280 -> 1280 convolution 1.4 -> 0.6 GB per launch at equal time (profiles/r04_s3.txt) */

@@ -255,16 +255,21 @@ def test_gemm_weights_in_registers(cx):
     parts per 64 rows give the statistics of the stored output"""
     import torch
 
-    cases = [dict(M=256, C=320, N=320, form="res", seed=121), dict(M=64, C=320, N=320, form="plain", seed=122),
-             dict(M=2560, C=320, N=320, form="res", seed=123)]
+    cases = [dict(M=256, C=320, N=320, form="res", seed=121, res_rowvec=False), dict(M=64, C=320, N=320, form="plain", seed=122),
+             dict(M=2560, C=320, N=320, form="res", seed=123, res_rowvec=False),
+             # a row vector per 128 rows (the table row changes inside a workgroup's walk), the LayerNorm-fold form with a
+             # positional-encoding row per 64 rows at one, two and three 320-column tiles
+             dict(M=1280, C=320, N=320, form="res", seed=127, P=128), dict(M=1280, C=320, N=320, form="ln", seed=128),
+             dict(M=768, C=320, N=640, form="ln", seed=129), dict(M=1536, C=320, N=960, form="ln", seed=130, P=192)]
     try:
         for c in cases:
+            c = dict(dict(P=64), **c)
             cx.lib.call("hv_set_tuning", 15, 0)
-            ref = kc.case_gemm_forms(cx, P=64, return_output=True, res_rowvec=False, **c)
-            for grid in (512, 8):
+            ref = kc.case_gemm_forms(cx, return_output=True, **c)
+            for grid in (512, 24):
                 cx.lib.call("hv_set_tuning", 15, 2)
                 cx.lib.call("hv_set_tuning", 2, grid)
-                y = kc.case_gemm_forms(cx, P=64, return_output=True, res_rowvec=False, **c)
+                y = kc.case_gemm_forms(cx, return_output=True, **c)
                 assert torch.equal(y, ref), f"hv_gemm_wr_kernel differs from the tile kernels: {c} grid {grid}"
         cx.lib.call("hv_set_tuning", 2, 8)
         kc.case_ln_parts_gemm(cx, M=1280, C=320, K=320, seed=124)

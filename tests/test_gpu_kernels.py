@@ -150,11 +150,14 @@ def test_gemm_weights_in_registers_kernel(cx):
     import torch
 
     try:
-        for c in (dict(M=48 * 6144, C=320, N=320, P=6144, form="res", seed=131), dict(M=48 * 6144, C=320, N=320, P=6144, form="plain", seed=132)):
+        for c in (dict(M=48 * 6144, C=320, N=320, P=6144, form="res", seed=131, res_rowvec=False),
+                  dict(M=48 * 6144, C=320, N=320, P=6144, form="plain", seed=132),
+                  dict(M=48 * 6144, C=320, N=320, P=24 * 6144, form="res", seed=138),      # + the folded cross-attention row per batch
+                  dict(M=48 * 6144, C=320, N=960, P=6144, form="ln", seed=139)):           # motion-module QKV: LayerNorm fold + PE row per frame
             cx.lib.call("hv_set_tuning", 15, 0)
-            ref = kc.case_gemm_forms(cx, return_output=True, res_rowvec=False, **c)
+            ref = kc.case_gemm_forms(cx, return_output=True, **c)
             cx.lib.call("hv_set_tuning", 15, 1)
-            y = kc.case_gemm_forms(cx, return_output=True, res_rowvec=False, **c)
+            y = kc.case_gemm_forms(cx, return_output=True, **c)
             assert torch.equal(y, ref), f"hv_gemm_wr_kernel differs from the tile kernels: {c}"
         kc.case_ln_parts_gemm(cx, M=48 * 6144, C=320, K=320, seed=133)
         kc.case_ln_parts_gemm(cx, M=24 * 6144, C=320, K=320, seed=134, residual=False)
